@@ -1,0 +1,251 @@
+/*
+ * kabc.h -- C ABI of the MI355X (gfx950) walker-update path of KissABC.
+ *
+ * The reference (KissABC.jl v3.0.1) has NO FFI: its "operator API" is the Julia
+ * method contract of AbstractDensity (src/types.jl:3-8) driven by
+ * AbstractMCMC.step (src/KissABC.jl:35-80) and by smc() (src/smc.jl:92-206).
+ * Each entry point below cites the reference interface it replaces; the Julia
+ * `ccall` stub a maintainer would add is shown in INTEGRATION.md and shipped as
+ * kissabc.jl_amd/julia/KissABCHip.jl.
+ *
+ * Conventions: extern "C", plain pointers and sizes, no torch/HIP types in the
+ * signatures (a HIP stream crosses as void*).  Every function returns a
+ * kabc_status_t; kabc_last_error() returns a thread-local message that carries
+ * the reference's own error text where the reference raises one.  Host buffers
+ * are caller-owned; device memory is library-owned behind opaque handles unless
+ * the caller lends device buffers explicitly (sharded mode).  A handle is
+ * single-threaded; distinct handles may be used from distinct threads (each
+ * owns a HIP stream) -- the MCMCThreads analogue (src/KissABC.jl:108).
+ */
+#ifndef KABC_H
+#define KABC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KABC_VERSION 100 /* 0.1.0 */
+#define KABC_MAX_DIM 16  /* compile-time upper bound on length(prior) on the device path */
+
+typedef enum kabc_status {
+    KABC_OK = 0,
+    KABC_ERR_INVALID_ARG = 1,     /* reference: error(...) on argument checks            */
+    KABC_ERR_RETRY_EXHAUSTED = 2, /* src/KissABC.jl:58-59                                */
+    KABC_ERR_INVALID_STATE = 3,   /* src/types.jl:152 "starting sample invalid."         */
+    KABC_ERR_DEVICE = 4,          /* HIP runtime error / no gfx950 device / no kernels   */
+    KABC_ERR_UNSUPPORTED = 5,     /* model outside the DeviceCost / prior surface        */
+    KABC_ERR_NAN_COST = 6         /* Statistics.quantile: "undefined in presence of NaNs" */
+} kabc_status_t;
+
+/* ---- Factored prior surface (src/priors.jl:10-49) ------------------------ */
+typedef enum kabc_prior_kind {
+    KABC_PRIOR_UNIFORM = 1,          /* Uniform(a,b)            p = (a, b)            */
+    KABC_PRIOR_NORMAL = 2,           /* Normal(mu,sigma)        p = (mu, sigma)       */
+    KABC_PRIOR_TRUNCNORMAL = 3,      /* Truncated(Normal(mu,sigma), lo, hi) p = (mu, sigma, lo, hi) */
+    KABC_PRIOR_BETA = 4,             /* Beta(alpha,beta)        p = (alpha, beta)     */
+    KABC_PRIOR_DISCRETE_UNIFORM = 5, /* DiscreteUniform(a,b)    p = (a, b)  [discrete] */
+    KABC_PRIOR_NEGBINOMIAL = 6,      /* NegativeBinomial(r,p)   p = (r, p)  [discrete] */
+    KABC_PRIOR_EXPONENTIAL = 7,      /* Exponential(theta)      p = (theta)           */
+    KABC_PRIOR_GAMMA = 8,            /* Gamma(alpha, theta)     p = (alpha, theta)    */
+    KABC_PRIOR_LOGNORMAL = 9,        /* LogNormal(mu, sigma)    p = (mu, sigma)       */
+    KABC_PRIOR__COUNT = 10
+} kabc_prior_kind_t;
+
+/* one univariate component of Factored(...) */
+typedef struct kabc_prior {
+    int32_t kind; /* kabc_prior_kind_t */
+    int32_t reserved;
+    double p[4];
+} kabc_prior_t;
+
+/* DeviceCost: replaces the `cost` closure (src/types.jl:124,137; src/smc.jl:94).
+ * ids and formulas: include/kabc_costs.h */
+typedef struct kabc_cost {
+    int32_t id;
+    int32_t nparams;
+    const double* params; /* host pointer, copied at create */
+    int64_t ndata;
+    const double* data; /* host pointer, copied at create */
+} kabc_cost_t;
+
+typedef enum kabc_posterior_kind {
+    KABC_POSTERIOR_KERNELIZED = 1, /* ApproxKernelizedPosterior, src/types.jl:122-157; eps = scale   */
+    KABC_POSTERIOR_THRESHOLD = 2   /* ApproxPosterior,           src/types.jl:158-186; eps = maxcost */
+} kabc_posterior_kind_t;
+
+/* ApproxKernelizedPosterior(prior, cost, scale) / ApproxPosterior(prior, cost, maxcost) */
+typedef struct kabc_model {
+    const kabc_prior_t* prior; /* D components */
+    int32_t D;                 /* length(prior), 1..KABC_MAX_DIM */
+    int32_t posterior;         /* kabc_posterior_kind_t */
+    double eps;                /* scale (kernelized) or maxcost (threshold) */
+    kabc_cost_t cost;
+} kabc_model_t;
+
+/* counters the metric is computed from */
+typedef struct kabc_stats {
+    uint64_t proposals;  /* transition! calls                                   */
+    uint64_t cost_evals; /* cost closure calls (skipped when logprior = -Inf)   */
+    uint64_t accepted;   /* accepted transitions                                */
+} kabc_stats_t;
+
+typedef struct kabc_ctx kabc_ctx_t;
+typedef struct kabc_ais kabc_ais_t;
+
+int32_t kabc_version(void);
+const char* kabc_last_error(void);
+/* number of visible gfx950 devices (0 when none; never an error) */
+int32_t kabc_device_count(void);
+
+/* device context: selects the GPU, owns one HIP stream.  stream = NULL creates
+ * a private stream; otherwise the caller's hipStream_t is used (e.g. torch's
+ * current stream so that RCCL collectives issued by the host order correctly). */
+kabc_status_t kabc_ctx_create(int32_t device_id, void* stream, kabc_ctx_t** out);
+kabc_status_t kabc_ctx_destroy(kabc_ctx_t* ctx);
+kabc_status_t kabc_ctx_synchronize(kabc_ctx_t* ctx);
+
+/* ---- Factored utilities (device kernels; host in, host out) ----------------
+ * logpdf(d::Factored, x) for n rows x[n][D]      -- src/priors.jl:275-281
+ * push_p(d::Factored, x)                          -- src/types.jl:111-114
+ * rand(rng, d::Factored) for walkers first..first+n of stream (seed, domain, attempt)
+ *                                                 -- src/priors.jl:287-288 */
+kabc_status_t kabc_factored_logpdf(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                                   int64_t n, const double* x, double* out);
+kabc_status_t kabc_factored_push_p(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                                   int64_t n, const double* x, double* out);
+kabc_status_t kabc_factored_rand(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                                 uint64_t seed, uint32_t domain, int64_t first_walker, int64_t n,
+                                 uint64_t attempt, double* out);
+
+/* ---- AIS: sample(model, AIS(N), Ns; ntransitions, discard_initial, retry_sampling)
+ *
+ * Ensemble layout.  Walker ids g = 0..N-1.  Half 0 = ids [0, N0), half 1 = ids
+ * [N0, N), N0 = ceil(N/2).  Each half is a row-major [rows][D] f64 array; the
+ * log-density pair (logprior, loglikelihood|cost) of src/types.jl:139,172 is two
+ * f64 arrays per half.
+ *
+ * Schedule.  The reference sweeps serially: step() gives walker i `ntransitions`
+ * consecutive transition!() calls against the other, momentarily frozen walkers
+ * (src/KissABC.jl:74-79).  Here one GENERATION does the same for every walker:
+ * half 0 then half 1, each walker of the active half receiving `ntransitions`
+ * consecutive transitions with partners drawn from the frozen complementary
+ * half.  One generation therefore yields N samples = N reference step() calls.
+ */
+
+/* AIS(nparticles) bound to a model.  Replaces the sampler tag + model pair of
+ * src/KissABC.jl:21-23,35-48.  Fails with the reference's message when
+ * nparticles < length(model)+5 (src/KissABC.jl:43-48). */
+kabc_status_t kabc_ais_create(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t nparticles,
+                              uint64_t seed, kabc_ais_t** out);
+
+/* Sharded variant: this process owns rows [rank*rows_h/world, (rank+1)*rows_h/world)
+ * of each half of an ensemble of n_total walkers (n_total divisible by 2*world).
+ * dev_half0 / dev_half1 are caller-provided DEVICE buffers of n_total/2 * D
+ * doubles each (e.g. torch tensors) holding the GLOBAL halves: kernels update
+ * the owned rows in place and read partners from any row; the host all-gathers
+ * the owned segment after each kabc_ais_half_generation (one RCCL all-gather
+ * per half).  Draws are keyed by global walker id, so results are identical for
+ * every world size. */
+kabc_status_t kabc_ais_create_sharded(kabc_ctx_t* ctx, const kabc_model_t* model,
+                                      int64_t n_total, int32_t rank, int32_t world,
+                                      uint64_t seed, void* dev_half0, void* dev_half1,
+                                      kabc_ais_t** out);
+
+/* step(rng, model, spl; retry_sampling) -- src/KissABC.jl:35-64: draw the owned
+ * walkers from the prior, evaluate loglike, re-draw invalid ones; fails with
+ * "Prior leads to ∞ costs too often, tune the prior or increase `retry_sampling`."
+ * when more than retry_sampling * nparticles re-draws are needed. */
+kabc_status_t kabc_ais_init(kabc_ais_t* h, int32_t retry_sampling);
+
+/* Asynchronous: enqueue `ntransitions` transition!() calls (src/transition.jl:67-82)
+ * for every owned walker of `half` on the context stream.  trace_row, if not
+ * NULL, is a DEVICE pointer receiving push_p(x) of the owned rows of that half
+ * ([rows_owned][D]) after the last transition (the sample step() returns,
+ * src/KissABC.jl:78).  Advances nothing else; pair it with kabc_ais_end_generation. */
+kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntransitions,
+                                       void* dev_trace_rows);
+/* advance the transition counter by ntransitions after both halves ran */
+kabc_status_t kabc_ais_end_generation(kabc_ais_t* h, int32_t ntransitions);
+
+/* step(rng, model, spl, state; ntransitions) x N x ngenerations -- src/KissABC.jl:66-80.
+ * Runs ngenerations generations (single-process handles only).  out_samples, if
+ * not NULL, is a HOST buffer [ngenerations][N][D] receiving push_p(walker) in
+ * walker-id order after each generation: exactly the samples the reference's
+ * step() emits over N*ngenerations calls.  stats (optional) accumulates. */
+kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntransitions,
+                               double* out_samples, kabc_stats_t* stats);
+
+/* AISState (src/KissABC.jl:25-33) <-> host.  x: [N][D] unrounded positions in
+ * walker-id order (owned rows only when sharded: [n_owned][D], half 0 rows
+ * first); logprior, loglik: [N]; t = transitions done per walker. */
+kabc_status_t kabc_ais_get_state(kabc_ais_t* h, double* x, double* logprior, double* loglik,
+                                 uint64_t* t);
+kabc_status_t kabc_ais_set_state(kabc_ais_t* h, const double* x, const double* logprior,
+                                 const double* loglik, uint64_t t);
+/* cumulative counters since create (device-side counters, read synchronously) */
+kabc_status_t kabc_ais_get_stats(kabc_ais_t* h, kabc_stats_t* stats);
+/* number of walkers this handle owns, and per half */
+int64_t kabc_ais_owned(const kabc_ais_t* h, int32_t half);
+/* Per-launch timing: bracket each of the next `max_launches` half-generation
+ * kernels with a hipEvent pair on the context stream (0 disables).
+ * kabc_ais_kernel_ms returns their average device time in ms and rewinds. */
+kabc_status_t kabc_ais_set_timing(kabc_ais_t* h, int32_t max_launches);
+double kabc_ais_kernel_ms(kabc_ais_t* h, int64_t* nlaunches);
+/* Test hook: record (move, accepted, a, b, c, cost_evaluated) as 6 int32 per
+ * walker and sub-step of the NEXT generation ([N_owned][ntransitions][6], walker-id
+ * order; partner ids are row indices inside the complementary half).  0 disables. */
+kabc_status_t kabc_ais_set_debug(kabc_ais_t* h, int32_t ntransitions);
+kabc_status_t kabc_ais_get_debug(kabc_ais_t* h, int32_t* out, int64_t n_int32);
+kabc_status_t kabc_ais_destroy(kabc_ais_t* h);
+
+/* ---- smc(prior, cost; kwargs...) -- src/smc.jl:92-206 -------------------- */
+typedef struct kabc_smc_opts {
+    int64_t nparticles;  /* 100   */
+    double alpha;        /* 0.95  */
+    int32_t mcmc_retrys; /* 0     */
+    int32_t verbose;     /* false */
+    double mcmc_tol;     /* 0.015 */
+    double epstol;       /* 0.0   */
+    double r_epstol;     /* (1-alpha)^1.5/50 ; pass NaN for this default */
+    double min_r_ess;    /* alpha^2          ; pass NaN for this default */
+    double max_stretch;  /* 2.0   */
+    uint64_t seed;
+    int64_t max_iterations; /* safety bound on the outer loop; 0 = 100000 */
+} kabc_smc_opts_t;
+
+typedef struct kabc_smc_iter {
+    double eps;         /* ϵ of this iteration (src/smc.jl:134)              */
+    int64_t ess;        /* sum(alive) before resampling (src/smc.jl:142)     */
+    int64_t accepted;   /* accepted[] at the end of the MCMC step            */
+    int32_t resampled;  /* 1 if step 2 ran (src/smc.jl:145)                  */
+    int32_t flag;       /* `flag` of src/smc.jl:135-141                      */
+    int32_t mcmc_passes; /* r at loop exit                                   */
+    int32_t reserved;
+} kabc_smc_iter_t;
+
+typedef struct kabc_smc_result {
+    double* theta;  /* host [N][D], push_p'ed positions of ALL particles        */
+    double* cost;   /* host [N]      = field C of the reference's return value  */
+    uint8_t* alive; /* host [N]      ; P = theta[alive]                         */
+    double eps;     /* field ϵ                                                  */
+    int64_t iterations;
+    int64_t n_alive;
+    uint64_t cost_evals;
+    uint64_t proposals;
+    kabc_smc_iter_t* iter_log; /* optional host [iter_log_cap] */
+    int64_t iter_log_cap;
+    double kernel_ms_mcmc; /* avg device ms of the propose+accept kernel */
+    int64_t mcmc_launches;
+} kabc_smc_result_t;
+
+void kabc_smc_default_opts(kabc_smc_opts_t* o);
+kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                           const kabc_cost_t* cost, const kabc_smc_opts_t* opts,
+                           kabc_smc_result_t* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KABC_H */

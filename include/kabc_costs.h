@@ -1,0 +1,206 @@
+/*
+ * kabc_costs.h -- the DeviceCost library.
+ *
+ * In the reference the `cost` argument of ApproxKernelizedPosterior /
+ * ApproxPosterior / smc is an arbitrary Julia closure (src/types.jl:124,137;
+ * src/smc.jl:94,176).  A gfx950 kernel cannot call a Julia closure, so on this
+ * path a cost is a DeviceCost: an id + parameter/data arrays whose formula is
+ * defined ONCE here as a host+device inline.  The same definition is evaluated
+ * by the HIP kernels and by the CPU oracle, i.e. it plays the role of the user's
+ * closure handed to both the reference path and the accelerated path.
+ *
+ * Each entry cites the reference workload it restates.  `x` is the push_p'ed
+ * parameter vector (discrete coordinates already rounded, src/types.jl:109-114).
+ * Stochastic simulators draw from the kabc_cost_rng_t stream they are given.
+ */
+#ifndef KABC_COSTS_H
+#define KABC_COSTS_H
+
+#include "kabc_philox.h"
+
+enum {
+    KABC_COST_GAUSS_DIST = 1,         /* ||x - c||_2 ; params c[D]                   */
+    KABC_COST_ROSENBROCK = 2,         /* sqrt(sum 100(x[k+1]-x[k]^2)^2 + (1-x[k])^2)  (C3, C5)      */
+    KABC_COST_HIER_GAUSS_SIM = 3,     /* hierarchical Gaussian simulator, RMS to data  (C4)         */
+    KABC_COST_NORMAL_MEANSTD_SIM = 4, /* README.md:43-49: n draws N(mu,sigma), hypot(dmean, 50 dstd) */
+    KABC_COST_DIRAC_SQ = 5,           /* test/runtests.jl:79-80: |x^2 + 1 - target|                 */
+    KABC_COST_ABS_DIFF = 6,           /* test/runtests.jl:178:   |x - target|                       */
+    KABC_COST_NORM_SHELL = 7,         /* test/runtests.jl:186:   | ||x||_2 - target |               */
+    KABC_COST_NOISY_QUAD_DU = 8,      /* test/runtests.jl:108-109: |(n^2+du)(n+0.01 randn) - target| */
+    KABC_COST_MIXTURE = 9,            /* test/runtests.jl:145-146: |mu + rand((0.1 randn, randn)) - target| */
+    KABC_COST_NOISY_BANANA = 10,      /* test/runtests.jl:242,248: noisy Rosenbrock, optional Inf   */
+    KABC_COST_WIENER_RMS = 11,        /* test/runtests.jl:116-126: drifted Wiener RMS curve         */
+    KABC_COST__COUNT = 12
+};
+
+/* does the cost consume random numbers? (host-side bookkeeping only) */
+KABC_HD int kabc_cost_is_stochastic(int id) {
+    return id == KABC_COST_HIER_GAUSS_SIM || id == KABC_COST_NORMAL_MEANSTD_SIM ||
+           id == KABC_COST_NOISY_QUAD_DU || id == KABC_COST_MIXTURE ||
+           id == KABC_COST_NOISY_BANANA || id == KABC_COST_WIENER_RMS;
+}
+
+KABC_HD double kabc_cost_gauss_dist(const double* x, int D, const double* params) {
+    double s = 0.0;
+    for (int k = 0; k < D; ++k) {
+        double d = x[k] - params[k];
+        s += d * d;
+    }
+    return kabc_sqrt(s);
+}
+
+KABC_HD double kabc_cost_rosenbrock(const double* x, int D) {
+    double s = 0.0;
+    for (int k = 0; k + 1 < D; ++k) {
+        double a = x[k + 1] - x[k] * x[k];
+        double b = 1.0 - x[k];
+        s += 100.0 * a * a + b * b;
+    }
+    return kabc_sqrt(s);
+}
+
+/* theta = (m, s, z_1..z_G), G = D-2 groups of 8 observations each:
+ * ybar_g = m + s z_g + randn/sqrt(8);  cost = RMS(ybar - data[0..G)). */
+KABC_HD double kabc_cost_hier_gauss_sim(const double* x, int D, const double* data,
+                                        kabc_cost_rng_t* rng) {
+    int G = D - 2;
+    double m = x[0], s = x[1];
+    double acc = 0.0;
+    for (int g = 0; g < G; g += 2) {
+        double z0, z1;
+        kabc_cost_rng_normal2(rng, &z0, &z1);
+        double y0 = m + s * x[2 + g] + z0 * 0x1.6a09e667f3bcdp-2; /* 1/sqrt(8) */
+        double d0 = y0 - data[g];
+        acc += d0 * d0;
+        if (g + 1 < G) {
+            double y1 = m + s * x[3 + g] + z1 * 0x1.6a09e667f3bcdp-2;
+            double d1 = y1 - data[g + 1];
+            acc += d1 * d1;
+        }
+    }
+    return kabc_sqrt(acc / (double)G);
+}
+
+/* params = (n, mean(tdata), std(tdata)); x = (mu, sigma).  The n draws are
+ * mu + sigma z_j, so mean = mu + sigma mean(z), std = |sigma| std(z). */
+KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* params,
+                                            kabc_cost_rng_t* rng) {
+    int n = (int)params[0];
+    double sz = 0.0, szz = 0.0;
+    for (int j = 0; j < n; j += 2) {
+        double z0, z1;
+        kabc_cost_rng_normal2(rng, &z0, &z1);
+        sz += z0;
+        szz += z0 * z0;
+        if (j + 1 < n) {
+            sz += z1;
+            szz += z1 * z1;
+        }
+    }
+    double dn = (double)n;
+    double mz = sz / dn;
+    double vz = (szz - dn * mz * mz) / (dn - 1.0);
+    if (vz < 0.0) vz = 0.0;
+    double mean = x[0] + x[1] * mz;
+    double sd = kabc_fabs(x[1]) * kabc_sqrt(vz);
+    double a = mean - params[1];
+    double b = 50.0 * (sd - params[2]);
+    return kabc_sqrt(a * a + b * b);
+}
+
+KABC_HD double kabc_cost_dirac_sq(const double* x, const double* params) {
+    return kabc_fabs(x[0] * x[0] + 1.0 - params[0]);
+}
+
+KABC_HD double kabc_cost_abs_diff(const double* x, const double* params) {
+    return kabc_fabs(x[0] - params[0]);
+}
+
+KABC_HD double kabc_cost_norm_shell(const double* x, int D, const double* params) {
+    double s = 0.0;
+    for (int k = 0; k < D; ++k) s += x[k] * x[k];
+    return kabc_fabs(kabc_sqrt(s) - params[0]);
+}
+
+KABC_HD double kabc_cost_noisy_quad_du(const double* x, const double* params,
+                                       kabc_cost_rng_t* rng) {
+    double z0, z1;
+    kabc_cost_rng_normal2(rng, &z0, &z1);
+    double n = x[0], du = x[1];
+    return kabc_fabs((n * n + du) * (n + z0 * 0.01) - params[0]);
+}
+
+KABC_HD double kabc_cost_mixture(const double* x, const double* params, kabc_cost_rng_t* rng) {
+    double z0, z1, u0, u1;
+    kabc_cost_rng_normal2(rng, &z0, &z1);
+    kabc_cost_rng_uniform2(rng, &u0, &u1);
+    double e = (u0 < 0.5) ? z0 * 0.1 : z1;
+    return kabc_fabs(x[0] + e - params[0]);
+}
+
+/* params[0] = probability of returning +Inf (0 for cc, 0.5 for cc2) */
+KABC_HD double kabc_cost_noisy_banana(const double* x, const double* params,
+                                      kabc_cost_rng_t* rng) {
+    double z0, z1, u0, u1;
+    kabc_cost_rng_normal2(rng, &z0, &z1);
+    kabc_cost_rng_uniform2(rng, &u0, &u1);
+    double a = x[0] + z0 * 0.01 - x[1] * x[1];
+    double b = x[1] - 1.0 + z1 * 0.01;
+    double c = 50.0 * a * a + b * b;
+    return (u0 < params[0]) ? KABC_INF : c;
+}
+
+/* data = tdata[0..T]; x = (mu, sigma); one multiplicative jitter per call */
+KABC_HD double kabc_cost_wiener_rms(const double* x, const double* data, int64_t ndata,
+                                    kabc_cost_rng_t* rng) {
+    double u0, u1;
+    kabc_cost_rng_uniform2(rng, &u0, &u1);
+    double jit = 0.95 + 0.1 * u0;
+    double acc = 0.0;
+    for (int64_t t = 0; t < ndata; ++t) {
+        double dt = (double)t;
+        double v = kabc_sqrt(x[0] * x[0] * dt * dt + x[1] * x[1] * dt) * jit;
+        acc += kabc_fabs(v - data[t]);
+    }
+    return acc / (double)ndata;
+}
+
+/* runtime dispatch (oracle, host checks).  The HIP kernels dispatch at compile
+ * time on the id and call the functions above directly. */
+KABC_HD double kabc_cost_eval(int id, const double* x, int D, const double* params,
+                              const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
+    switch (id) {
+        case KABC_COST_GAUSS_DIST: return kabc_cost_gauss_dist(x, D, params);
+        case KABC_COST_ROSENBROCK: return kabc_cost_rosenbrock(x, D);
+        case KABC_COST_HIER_GAUSS_SIM: return kabc_cost_hier_gauss_sim(x, D, data, rng);
+        case KABC_COST_NORMAL_MEANSTD_SIM: return kabc_cost_normal_meanstd_sim(x, params, rng);
+        case KABC_COST_DIRAC_SQ: return kabc_cost_dirac_sq(x, params);
+        case KABC_COST_ABS_DIFF: return kabc_cost_abs_diff(x, params);
+        case KABC_COST_NORM_SHELL: return kabc_cost_norm_shell(x, D, params);
+        case KABC_COST_NOISY_QUAD_DU: return kabc_cost_noisy_quad_du(x, params, rng);
+        case KABC_COST_MIXTURE: return kabc_cost_mixture(x, params, rng);
+        case KABC_COST_NOISY_BANANA: return kabc_cost_noisy_banana(x, params, rng);
+        case KABC_COST_WIENER_RMS: return kabc_cost_wiener_rms(x, data, ndata, rng);
+        default: return KABC_NAN;
+    }
+}
+
+/* minimum / exact dimension each cost accepts; 0 = any D >= 1 */
+KABC_HD int kabc_cost_dim_ok(int id, int D) {
+    switch (id) {
+        case KABC_COST_GAUSS_DIST: return D >= 1;
+        case KABC_COST_ROSENBROCK: return D >= 2;
+        case KABC_COST_HIER_GAUSS_SIM: return D >= 3;
+        case KABC_COST_NORMAL_MEANSTD_SIM: return D == 2;
+        case KABC_COST_DIRAC_SQ: return D == 1;
+        case KABC_COST_ABS_DIFF: return D == 1;
+        case KABC_COST_NORM_SHELL: return D >= 1;
+        case KABC_COST_NOISY_QUAD_DU: return D == 2;
+        case KABC_COST_MIXTURE: return D == 1;
+        case KABC_COST_NOISY_BANANA: return D == 2;
+        case KABC_COST_WIENER_RMS: return D == 2;
+        default: return 0;
+    }
+}
+
+#endif /* KABC_COSTS_H */

@@ -1,0 +1,23 @@
+"""kissabc.jl_amd -- MI355X (gfx950) walker-update path of KissABC behind the
+reference's own user surface (see include/kabc.h for the C ABI it sits on).
+
+Import name: `kissabc_jl_amd` (the directory name has a dot; the repo-root
+module kissabc_jl_amd.py registers this package under that name).
+"""
+from . import costs
+from ._cdefs import KABC_MAX_DIM
+from ._lib import Context, KabcError, LIB_PATH, default_context
+from .api import (AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, MCMCThreads,
+                  Particles, sample, smc)
+from .costs import DeviceCost
+from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, LogNormal,
+                            NegativeBinomial, Normal, Truncated, TruncatedNormal, Uniform,
+                            truncated)
+
+__all__ = [
+    "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "MCMCThreads",
+    "Particles", "sample", "smc", "DeviceCost", "costs", "Factored", "Uniform", "Normal",
+    "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
+    "Exponential", "Gamma", "LogNormal", "Context", "KabcError", "default_context", "LIB_PATH",
+    "KABC_MAX_DIM",
+]

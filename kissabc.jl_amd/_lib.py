@@ -1,0 +1,80 @@
+"""Loader of the C-ABI library (kissabc.jl_amd/lib/libkabc_hip.so).
+
+There is NO fallback: if the HIP extension is missing or no gfx950 device is
+visible, the product path raises.  (The CPU oracle lives under oracle/ and is
+only ever used by tests/, smoke() and bench.py's cpu_baseline leg.)
+"""
+import ctypes as C
+import os
+
+from . import _cdefs
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkabc_hip.so")
+_lib = None
+
+
+class KabcError(RuntimeError):
+    """Raised for every non-zero kabc_status_t; .status holds the code and the
+    message is the library's (for reference-defined errors: the reference's text)."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (or `make -C kissabc.jl_amd/csrc`). The KissABC MI355X path has no "
+                "CPU fallback.")
+        _lib = _cdefs.bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        msg = load().kabc_last_error()
+        raise KabcError(status, msg.decode("utf-8", "replace") if msg else f"kabc status {status}")
+
+
+class Context:
+    """kabc_ctx_t: one GPU + one HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        lib = load()
+        self._h = C.c_void_p()
+        check(lib.kabc_ctx_create(int(device), C.c_void_p(stream) if stream else None,
+                                  C.byref(self._h)))
+        self.device = device
+
+    @property
+    def handle(self):
+        return self._h
+
+    def synchronize(self):
+        check(load().kabc_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            load().kabc_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    ctx = _default_ctx.get(device)
+    if ctx is None:
+        ctx = _default_ctx[device] = Context(device)
+    return ctx

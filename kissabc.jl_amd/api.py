@@ -1,0 +1,307 @@
+"""Host-side mirror of the reference's user API for the walker-update path:
+
+    ApproxKernelizedPosterior(prior, cost, scale)      src/types.jl:122-131
+    ApproxPosterior(prior, cost, maxcost)              src/types.jl:158-164
+    AIS(nparticles)                                    src/KissABC.jl:21-23
+    sample(model, AIS(N), Ns; ntransitions, discard_initial, retry_sampling)
+    sample(model, AIS(N), MCMCThreads(), Ns, Nc; ...)  src/KissABC.jl:106-173
+    smc(prior, cost; kwargs...)                        src/smc.jl:92-206
+
+Everything numerical happens in libkabc_hip.so (gfx950 kernels) behind the C
+ABI of include/kabc.h.  This file only marshals arguments and shapes results
+(bundle_samples / chainsstack, src/KissABC.jl:82-104).
+"""
+import collections
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _cdefs as cd
+from . import _lib
+from .costs import DeviceCost
+from .distributions import Factored, UnivariateDistribution, as_factored
+
+
+class Particles:
+    """Minimal stand-in for MonteCarloMeasurements.Particles (one parameter's
+    samples): the container `bundle_samples` builds (src/KissABC.jl:91)."""
+
+    def __init__(self, particles):
+        self.particles = np.asarray(particles)
+
+    def __len__(self):
+        return self.particles.shape[0]
+
+    def mean(self):
+        return float(np.mean(self.particles))
+
+    def std(self):
+        return float(np.std(self.particles, ddof=1))
+
+    def isapprox(self, c, nsigma=2.0):
+        """MonteCarloMeasurements `p ≈ c`: |mean − c| < nsigma · std."""
+        return abs(self.mean() - c) < nsigma * self.std()
+
+    def __array__(self, dtype=None, copy=None):
+        return self.particles if dtype is None else self.particles.astype(dtype)
+
+    def __repr__(self):
+        return f"{self.mean():.4g} ± {self.std():.2g}"
+
+
+class _ApproxModel:
+    posterior = 0
+
+    def __init__(self, prior, cost, eps):
+        self.prior = as_factored(prior)
+        self.scalar = isinstance(prior, UnivariateDistribution)
+        if not isinstance(cost, DeviceCost):
+            raise TypeError(
+                "on the MI355X path `cost` must be a DeviceCost (kissabc_jl_amd.costs.*): a host "
+                "closure cannot be called from a gfx950 kernel")
+        self.cost = cost
+        self.eps = float(eps)
+
+    def __len__(self):  # length(density) = length(prior), src/types.jl:119
+        return len(self.prior)
+
+    def to_c(self):
+        m = cd.Model()
+        self._prior_c = self.prior.to_c()
+        m.prior = C.cast(self._prior_c, C.POINTER(cd.Prior))
+        m.D = len(self.prior)
+        m.posterior = self.posterior
+        m.eps = self.eps
+        m.cost = self.cost.to_c()
+        return m
+
+
+class ApproxKernelizedPosterior(_ApproxModel):
+    """Gaussian-kernel ABC density; `scale` = target_average_cost (src/types.jl:212-221)."""
+    posterior = cd.POSTERIOR_KERNELIZED
+
+    @property
+    def scale(self):
+        return self.eps
+
+
+class ApproxPosterior(_ApproxModel):
+    """Hard-threshold ABC density; `maxcost` (src/types.jl:222-231)."""
+    posterior = cd.POSTERIOR_THRESHOLD
+
+    @property
+    def maxcost(self):
+        return self.eps
+
+
+class AIS:
+    """AIS(nparticles) -- src/KissABC.jl:21-23"""
+
+    def __init__(self, nparticles):
+        self.nparticles = int(nparticles)
+
+
+class MCMCThreads:
+    """Tag for independent chains (AbstractMCMC.MCMCThreads, re-exported at
+    src/KissABC.jl:9,175).  On this path chains are independent ensembles with
+    distinct seeds run one after the other on the device."""
+
+
+class AisEnsemble:
+    """kabc_ais_t: the device-resident AISState (src/KissABC.jl:25-33)."""
+
+    def __init__(self, model, nparticles, seed=0, ctx=None, sharded=None):
+        self.model = model
+        self.ctx = ctx or _lib.default_context()
+        self.N = int(nparticles)
+        self.D = len(model)
+        self._cmodel = model.to_c()
+        self._h = C.c_void_p()
+        lib = _lib.load()
+        if sharded is None:
+            _lib.check(lib.kabc_ais_create(self.ctx.handle, C.byref(self._cmodel), self.N,
+                                           int(seed), C.byref(self._h)))
+        else:
+            rank, world, p0, p1 = sharded
+            _lib.check(lib.kabc_ais_create_sharded(self.ctx.handle, C.byref(self._cmodel), self.N,
+                                                   rank, world, int(seed), C.c_void_p(p0),
+                                                   C.c_void_p(p1), C.byref(self._h)))
+        self.owned = (lib.kabc_ais_owned(self._h, 0), lib.kabc_ais_owned(self._h, 1))
+
+    # step(rng, model, spl; retry_sampling) -- src/KissABC.jl:35-64
+    def init(self, retry_sampling=100):
+        _lib.check(_lib.load().kabc_ais_init(self._h, int(retry_sampling)))
+        return self
+
+    # step(rng, model, spl, state; ntransitions) x N x ngenerations -- src/KissABC.jl:66-80
+    def advance(self, ngenerations, ntransitions=1, collect=False):
+        lib = _lib.load()
+        out = None
+        ptr = None
+        if collect:
+            out = np.empty((int(ngenerations), self.N, self.D))
+            ptr = out.ctypes.data_as(cd.c_double_p)
+        st = cd.Stats()
+        _lib.check(lib.kabc_ais_advance(self._h, int(ngenerations), int(ntransitions), ptr,
+                                        C.byref(st)))
+        self.last_stats = {"proposals": st.proposals, "cost_evals": st.cost_evals,
+                           "accepted": st.accepted}
+        return out
+
+    def half_generation(self, half, ntransitions, trace_ptr=None):
+        _lib.check(_lib.load().kabc_ais_half_generation(
+            self._h, int(half), int(ntransitions), C.c_void_p(trace_ptr) if trace_ptr else None))
+
+    def end_generation(self, ntransitions):
+        _lib.check(_lib.load().kabc_ais_end_generation(self._h, int(ntransitions)))
+
+    def state(self):
+        n = self.owned[0] + self.owned[1]
+        x = np.empty((n, self.D))
+        lp = np.empty(n)
+        ll = np.empty(n)
+        t = C.c_uint64()
+        _lib.check(_lib.load().kabc_ais_get_state(
+            self._h, x.ctypes.data_as(cd.c_double_p), lp.ctypes.data_as(cd.c_double_p),
+            ll.ctypes.data_as(cd.c_double_p), C.byref(t)))
+        return x, lp, ll, t.value
+
+    def set_state(self, x, lp, ll, t=0):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        lp = np.ascontiguousarray(lp, dtype=np.float64)
+        ll = np.ascontiguousarray(ll, dtype=np.float64)
+        _lib.check(_lib.load().kabc_ais_set_state(
+            self._h, x.ctypes.data_as(cd.c_double_p), lp.ctypes.data_as(cd.c_double_p),
+            ll.ctypes.data_as(cd.c_double_p), int(t)))
+
+    def stats(self):
+        st = cd.Stats()
+        _lib.check(_lib.load().kabc_ais_get_stats(self._h, C.byref(st)))
+        return {"proposals": st.proposals, "cost_evals": st.cost_evals, "accepted": st.accepted}
+
+    def set_timing(self, max_launches):
+        _lib.check(_lib.load().kabc_ais_set_timing(self._h, int(max_launches)))
+
+    def kernel_ms(self):
+        n = C.c_int64()
+        ms = _lib.load().kabc_ais_kernel_ms(self._h, C.byref(n))
+        return ms, n.value
+
+    def set_debug(self, ntransitions):
+        _lib.check(_lib.load().kabc_ais_set_debug(self._h, int(ntransitions)))
+
+    def get_debug(self, ntransitions):
+        n = self.owned[0] + self.owned[1]
+        out = np.empty((n, int(ntransitions), 6), dtype=np.int32)
+        _lib.check(_lib.load().kabc_ais_get_debug(
+            self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size))
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.load().kabc_ais_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _bundle(samples, scalar):
+    """bundle_samples (src/KissABC.jl:82-94): [Ns][D] -> one Particles per parameter."""
+    P = [Particles(samples[:, k]) for k in range(samples.shape[1])]
+    return P[0] if (len(P) == 1 or scalar) else P
+
+
+def sample(model, spl, *args, ntransitions=1, discard_initial=0, retry_sampling=100, seed=0,
+           progress=False, ctx=None, return_array=False, **kwargs):
+    """sample(model, AIS(N), Ns; ...) and sample(model, AIS(N), MCMCThreads(), Ns, Nc; ...).
+
+    The device advances a whole generation (every walker `ntransitions` times) per
+    launch pair and a generation yields the N samples the reference's N
+    consecutive step() calls would emit (src/KissABC.jl:66-80), so
+    ceil(discard_initial/N) generations are discarded and ceil(Ns/N) are kept.
+    """
+    if not isinstance(spl, AIS):
+        raise TypeError("sampler must be AIS(nparticles)")
+    if args and isinstance(args[0], MCMCThreads):
+        _, Ns, Nc = args
+        chains = [sample(model, spl, int(Ns), ntransitions=ntransitions,
+                         discard_initial=discard_initial, retry_sampling=retry_sampling,
+                         seed=int(seed) + 0x9E3779B97F4A7C15 * (c + 1) % (1 << 63), ctx=ctx,
+                         return_array=True) for c in range(int(Nc))]
+        stacked = np.concatenate(chains, axis=0)  # chainsstack, src/KissABC.jl:96-104
+        return stacked if return_array else _bundle(stacked, model.scalar)
+    (Ns,) = args
+    Ns = int(Ns)
+    N = spl.nparticles
+    ens = AisEnsemble(model, N, seed=seed, ctx=ctx)
+    try:
+        ens.init(retry_sampling)
+        gd = -(-int(discard_initial) // N)
+        if gd:
+            ens.advance(gd, ntransitions)
+        gk = max(1, -(-Ns // N))
+        out = ens.advance(gk, ntransitions, collect=True).reshape(gk * N, len(model))[:Ns]
+    finally:
+        ens.close()
+    return out if return_array else _bundle(out, model.scalar)
+
+
+SmcResult = collections.namedtuple("SmcResult", ["P", "C", "ϵ", "info"])
+
+
+def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.015, epstol=0.0,
+        r_epstol=None, min_r_ess=None, max_stretch=2.0, verbose=False, parallel=False, seed=0,
+        ctx=None, return_array=False):
+    """smc(prior, cost; ...) -- src/smc.jl:92-206, same keywords and defaults.
+    `parallel` is accepted and ignored (every particle is a GPU lane).
+    Returns (P, C, ϵ) as the reference does (+ an `info` dict)."""
+    fac = as_factored(prior)
+    scalar = isinstance(prior, UnivariateDistribution)
+    if not isinstance(cost, DeviceCost):
+        raise TypeError("`cost` must be a DeviceCost on the MI355X path")
+    lib = _lib.load()
+    ctx = ctx or _lib.default_context()
+    o = cd.SmcOpts()
+    lib.kabc_smc_default_opts(C.byref(o))
+    o.nparticles = int(nparticles)
+    o.alpha = float(alpha)
+    o.mcmc_retrys = int(mcmc_retrys)
+    o.verbose = int(bool(verbose))
+    o.mcmc_tol = float(mcmc_tol)
+    o.epstol = float(epstol)
+    o.r_epstol = math.nan if r_epstol is None else float(r_epstol)
+    o.min_r_ess = math.nan if min_r_ess is None else float(min_r_ess)
+    o.max_stretch = float(max_stretch)
+    o.seed = int(seed)
+    N, D = int(nparticles), len(fac)
+    n_alloc = max(N, 1)
+    theta = np.empty((n_alloc, D))
+    Cst = np.empty(n_alloc)
+    alive = np.zeros(n_alloc, dtype=np.uint8)
+    log = (cd.SmcIter * 4096)()
+    r = cd.SmcResult()
+    r.theta = theta.ctypes.data_as(cd.c_double_p)
+    r.cost = Cst.ctypes.data_as(cd.c_double_p)
+    r.alive = alive.ctypes.data_as(C.POINTER(C.c_uint8))
+    r.iter_log = log
+    r.iter_log_cap = 4096
+    cc = cost.to_c()
+    _lib.check(lib.kabc_smc_run(ctx.handle, fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    mask = alive.astype(bool)
+    kept = theta[mask]
+    nit = min(r.iterations, 4096)
+    info = {
+        "iterations": r.iterations, "n_alive": r.n_alive, "cost_evals": r.cost_evals,
+        "proposals": r.proposals, "alive": mask, "theta_all": theta,
+        "kernel_ms_mcmc": r.kernel_ms_mcmc, "mcmc_launches": r.mcmc_launches,
+        "log": [dict(eps=log[i].eps, ess=log[i].ess, accepted=log[i].accepted,
+                     resampled=log[i].resampled, flag=log[i].flag, passes=log[i].mcmc_passes)
+                for i in range(nit)],
+    }
+    P = kept if return_array else _bundle(kept, scalar)
+    return SmcResult(P, Cst, r.eps, info)

@@ -1,0 +1,580 @@
+// capi_ais.hip -- the AIS entry points of the C ABI (include/kabc.h):
+// AIS(N) + AISState + step(init) + step(advance) of src/KissABC.jl:21-80,
+// executed by the gfx950 kernels in ais_kernels.hpp.
+#include <vector>
+
+#include "ais_kernels.hpp"
+#include "host_common.hpp"
+
+namespace kabc {
+
+#define KABC_DECL_COST(id) AisLaunchFn find_ais_kernel_cost_##id(int D);
+KABC_DECL_COST(1)
+KABC_DECL_COST(2)
+KABC_DECL_COST(3)
+KABC_DECL_COST(4)
+KABC_DECL_COST(5)
+KABC_DECL_COST(6)
+KABC_DECL_COST(7)
+KABC_DECL_COST(8)
+KABC_DECL_COST(9)
+KABC_DECL_COST(10)
+KABC_DECL_COST(11)
+
+AisLaunchFn find_ais_kernel(int cost_id, int D) {
+    switch (cost_id) {
+        case 1: return find_ais_kernel_cost_1(D);
+        case 2: return find_ais_kernel_cost_2(D);
+        case 3: return find_ais_kernel_cost_3(D);
+        case 4: return find_ais_kernel_cost_4(D);
+        case 5: return find_ais_kernel_cost_5(D);
+        case 6: return find_ais_kernel_cost_6(D);
+        case 7: return find_ais_kernel_cost_7(D);
+        case 8: return find_ais_kernel_cost_8(D);
+        case 9: return find_ais_kernel_cost_9(D);
+        case 10: return find_ais_kernel_cost_10(D);
+        case 11: return find_ais_kernel_cost_11(D);
+        default: return nullptr;
+    }
+}
+
+template <int D>
+static void launch_init_d(const InitArgs& a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.rows_owned + kAisBlock - 1) / kAisBlock);
+    if (grid == 0) return;
+    hipLaunchKernelGGL((ais_init_kernel<D>), dim3(grid), dim3(kAisBlock), 0, s, a);
+}
+
+template <int... Ds>
+static void launch_init_table(int D, const InitArgs& a, hipStream_t s,
+                              std::integer_sequence<int, Ds...>) {
+    using Fn = void (*)(const InitArgs&, hipStream_t);
+    static const Fn fns[] = {&launch_init_d<Ds + 1>...};
+    fns[D - 1](a, s);
+}
+
+void launch_ais_init(int D, const InitArgs& a, hipStream_t s) {
+    launch_init_table(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+}
+
+}  // namespace kabc
+
+using namespace kabc;
+
+struct kabc_ais {
+    kabc_ctx_t* ctx;
+    int32_t D, posterior, cost_id;
+    double eps;
+    kabc_prior_t raw[KABC_MAX_DIM];
+    PriorSet prior;
+    double* d_cost_params;
+    double* d_cost_data;
+    int64_t cost_ndata;
+    int64_t N;             // total walkers (all ranks)
+    int64_t rows[2];       // global rows per half
+    int64_t row_first[2];  // first owned row per half
+    int64_t rows_owned[2];
+    uint32_t id_base[2];   // global walker id of row 0 of each half
+    double* d_half[2];     // global halves [rows[h]][D]
+    bool own_halves;
+    double* d_lp[2];
+    double* d_ll[2];
+    DevCounters* d_counters;
+    uint64_t seed, t;
+    int32_t rank, world;
+    AisLaunchFn launch;
+    bool initialised;
+    // trace staging
+    double* d_trace;
+    int64_t trace_cap_gens;
+    // debug records (tests)
+    int32_t* d_dbg;
+    int64_t dbg_cap;  // in int32 units
+    // timing
+    bool timing;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used;
+    kabc_stats_t last;  // counters at the last kabc_ais_advance return
+};
+
+static kabc_status_t check_handle(const kabc_ais_t* h) {
+    if (!h) {
+        set_error("AIS handle is NULL");
+        return KABC_ERR_INVALID_ARG;
+    }
+    return KABC_OK;
+}
+
+static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, int64_t n_total,
+                                       int32_t rank, int32_t world, uint64_t seed, void* ext0,
+                                       void* ext1, kabc_ais_t** out) {
+    if (!ctx || !m || !out || !m->prior) {
+        set_error("kabc_ais_create: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (m->D < 1 || m->D > KABC_MAX_DIM) {
+        set_error("length(prior) = %d is outside the device path's range 1..%d", m->D,
+                  KABC_MAX_DIM);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    // src/KissABC.jl:43-48
+    if (n_total < m->D + 5) {
+        set_error("nparticles = %lld is insufficient, set number of particles in AIS(⋅) atleast to %d",
+                  (long long)n_total, m->D + 5);
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (n_total >= (1ll << 31)) {
+        set_error("nparticles must be < 2^31");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (m->posterior != KABC_POSTERIOR_KERNELIZED && m->posterior != KABC_POSTERIOR_THRESHOLD) {
+        set_error("unknown posterior kind %d", m->posterior);
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && n_total % (2 * world) != 0)) {
+        set_error("sharded AIS needs nparticles divisible by 2*world (got %lld, world %d)",
+                  (long long)n_total, world);
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (!kabc_cost_dim_ok(m->cost.id, m->D)) {
+        set_error("DeviceCost id %d does not accept D = %d", m->cost.id, m->D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    AisLaunchFn fn = find_ais_kernel(m->cost.id, m->D);
+    if (!fn) {
+        set_error("no gfx950 kernel instantiated for cost id %d, D = %d", m->cost.id, m->D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    kabc_ais_t* h = new kabc_ais_t();
+    h->ctx = ctx;
+    h->D = m->D;
+    h->posterior = m->posterior;
+    h->cost_id = m->cost.id;
+    h->eps = m->eps;
+    std::memset(h->raw, 0, sizeof h->raw);
+    std::memcpy(h->raw, m->prior, sizeof(kabc_prior_t) * m->D);
+    if (!prepare_priors(h->raw, h->D, h->prior)) {
+        delete h;
+        set_error("invalid prior parameters");
+        return KABC_ERR_INVALID_ARG;
+    }
+    h->launch = fn;
+    h->N = n_total;
+    h->rows[0] = (n_total + 1) / 2;
+    h->rows[1] = n_total / 2;
+    h->id_base[0] = 0;
+    h->id_base[1] = (uint32_t)h->rows[0];
+    h->rank = rank;
+    h->world = world;
+    for (int hf = 0; hf < 2; ++hf) {
+        if (world == 1) {
+            h->row_first[hf] = 0;
+            h->rows_owned[hf] = h->rows[hf];
+        } else {
+            const int64_t per = h->rows[hf] / world;
+            h->row_first[hf] = per * rank;
+            h->rows_owned[hf] = per;
+        }
+    }
+    h->seed = seed;
+    h->t = 0;
+    h->initialised = false;
+    h->d_trace = nullptr;
+    h->trace_cap_gens = 0;
+    h->d_dbg = nullptr;
+    h->dbg_cap = 0;
+    h->timing = false;
+    h->ev_used = 0;
+    h->last = kabc_stats_t{0, 0, 0};
+    h->d_cost_params = h->d_cost_data = nullptr;
+    h->cost_ndata = m->cost.ndata;
+    h->own_halves = (ext0 == nullptr);
+
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (m->cost.nparams > 0) {
+        KABC_HIP_CHECK(hipMalloc(&h->d_cost_params, sizeof(double) * m->cost.nparams));
+        KABC_HIP_CHECK(hipMemcpyAsync(h->d_cost_params, m->cost.params,
+                                      sizeof(double) * m->cost.nparams, hipMemcpyHostToDevice, s));
+    }
+    if (m->cost.ndata > 0) {
+        KABC_HIP_CHECK(hipMalloc(&h->d_cost_data, sizeof(double) * m->cost.ndata));
+        KABC_HIP_CHECK(hipMemcpyAsync(h->d_cost_data, m->cost.data, sizeof(double) * m->cost.ndata,
+                                      hipMemcpyHostToDevice, s));
+    }
+    for (int hf = 0; hf < 2; ++hf) {
+        if (h->own_halves) {
+            KABC_HIP_CHECK(hipMalloc(&h->d_half[hf], sizeof(double) * h->rows[hf] * h->D));
+            KABC_HIP_CHECK(hipMemsetAsync(h->d_half[hf], 0, sizeof(double) * h->rows[hf] * h->D, s));
+        } else {
+            h->d_half[hf] = (double*)(hf == 0 ? ext0 : ext1);
+        }
+        const size_t nb = sizeof(double) * (size_t)(h->rows_owned[hf] > 0 ? h->rows_owned[hf] : 1);
+        KABC_HIP_CHECK(hipMalloc(&h->d_lp[hf], nb));
+        KABC_HIP_CHECK(hipMalloc(&h->d_ll[hf], nb));
+    }
+    KABC_HIP_CHECK(hipMalloc(&h->d_counters, sizeof(DevCounters)));
+    KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
+    KABC_HIP_CHECK(hipStreamSynchronize(s));
+    *out = h;
+    return KABC_OK;
+}
+
+static kabc_status_t read_counters(kabc_ais_t* h, DevCounters* c) {
+    KABC_HIP_CHECK(hipMemcpyAsync(c, h->d_counters, sizeof(DevCounters), hipMemcpyDeviceToHost,
+                                  h->ctx->stream));
+    KABC_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+    return KABC_OK;
+}
+
+static kabc_status_t check_device_error(kabc_ais_t* h, const DevCounters& c) {
+    (void)h;
+    if (c.error == 1) {
+        set_error("ld_correction is invalid");  // src/types.jl:151
+        return KABC_ERR_INVALID_STATE;
+    }
+    if (c.error == 2) {
+        set_error("starting sample invalid.");  // src/types.jl:152
+        return KABC_ERR_INVALID_STATE;
+    }
+    return KABC_OK;
+}
+
+extern "C" {
+
+kabc_status_t kabc_ais_create(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t nparticles,
+                              uint64_t seed, kabc_ais_t** out) {
+    return ais_create_common(ctx, model, nparticles, 0, 1, seed, nullptr, nullptr, out);
+}
+
+kabc_status_t kabc_ais_create_sharded(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t n_total,
+                                      int32_t rank, int32_t world, uint64_t seed, void* dev_half0,
+                                      void* dev_half1, kabc_ais_t** out) {
+    if (!dev_half0 || !dev_half1) {
+        set_error("kabc_ais_create_sharded: device half buffers must be provided");
+        return KABC_ERR_INVALID_ARG;
+    }
+    return ais_create_common(ctx, model, n_total, rank, world, seed, dev_half0, dev_half1, out);
+}
+
+kabc_status_t kabc_ais_init(kabc_ais_t* h, int32_t retry_sampling) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    if (retry_sampling < 0) {
+        set_error("retry_sampling must be >= 0");
+        return KABC_ERR_INVALID_ARG;
+    }
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
+    for (int hf = 0; hf < 2; ++hf) {
+        InitArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.x_act = h->d_half[hf];
+        a.lp = h->d_lp[hf];
+        a.ll = h->d_ll[hf];
+        a.counters = h->d_counters;
+        a.cost_params = h->d_cost_params;
+        a.cost_data = h->d_cost_data;
+        a.cost_ndata = h->cost_ndata;
+        a.row_first = h->row_first[hf];
+        a.rows_owned = h->rows_owned[hf];
+        a.seed = h->seed;
+        a.id_base = h->id_base[hf];
+        a.posterior = h->posterior;
+        a.cost_id = h->cost_id;
+        a.eps = h->eps;
+        // the budget is per ensemble (src/KissABC.jl:52); a shard gets its share
+        a.retry_budget = (unsigned long long)retry_sampling *
+                         (unsigned long long)(h->rows_owned[0] + h->rows_owned[1]);
+        a.prior = h->prior;
+        std::memcpy(a.raw, h->raw, sizeof a.raw);
+        launch_ais_init(h->D, a, s);
+        KABC_HIP_CHECK(hipGetLastError());
+    }
+    DevCounters c;
+    if (read_counters(h, &c)) return KABC_ERR_DEVICE;
+    if (c.init_failed) {
+        // src/KissABC.jl:58-59
+        set_error("Prior leads to ∞ costs too often, tune the prior or increase `retry_sampling`.");
+        return KABC_ERR_RETRY_EXHAUSTED;
+    }
+    h->t = 0;
+    h->initialised = true;
+    h->last = kabc_stats_t{0, 0, 0};
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntransitions,
+                                       void* dev_trace_rows) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    if (!h->initialised) {
+        set_error("kabc_ais_init / kabc_ais_set_state has not been called");
+        return KABC_ERR_INVALID_STATE;
+    }
+    if ((half != 0 && half != 1) || ntransitions < 1) {
+        set_error("half must be 0/1 and ntransitions >= 1");
+        return KABC_ERR_INVALID_ARG;
+    }
+    AisArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.x_act = h->d_half[half];
+    a.x_comp = h->d_half[1 - half];
+    a.lp = h->d_lp[half];
+    a.ll = h->d_ll[half];
+    a.trace = (double*)dev_trace_rows;
+    a.dbg = nullptr;
+    if (h->d_dbg) {
+        // layout [N][nt][6] in walker-id order of the owned rows (half 0 first)
+        const int64_t off = (half == 0 ? 0 : h->rows_owned[0]) * (int64_t)ntransitions * 6;
+        if (off + h->rows_owned[half] * (int64_t)ntransitions * 6 <= h->dbg_cap)
+            a.dbg = h->d_dbg + off;
+    }
+    a.counters = h->d_counters;
+    a.cost_params = h->d_cost_params;
+    a.cost_data = h->d_cost_data;
+    a.cost_ndata = h->cost_ndata;
+    a.row_first = h->row_first[half];
+    a.rows_owned = h->rows_owned[half];
+    a.n_comp = h->rows[1 - half];
+    a.seed = h->seed;
+    a.t0 = h->t;
+    a.id_base = h->id_base[half];
+    a.nt = ntransitions;
+    a.posterior = h->posterior;
+    a.eps = h->eps;
+    a.prior = h->prior;
+    hipStream_t s = h->ctx->stream;
+    const bool timed = h->timing && (h->ev_used + 2 <= h->ev.size());
+    if (timed) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
+    h->launch(a, s);
+    if (timed) {
+        KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], s));
+        h->ev_used += 2;
+    }
+    KABC_HIP_CHECK(hipGetLastError());
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_end_generation(kabc_ais_t* h, int32_t ntransitions) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    h->t += (uint64_t)ntransitions;
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntransitions,
+                               double* out_samples, kabc_stats_t* stats) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    if (h->world != 1) {
+        set_error("kabc_ais_advance drives single-process handles; sharded handles are driven "
+                  "with kabc_ais_half_generation + an all-gather per half");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (ngenerations < 0 || ntransitions < 1) {
+        set_error("ngenerations must be >= 0 and ntransitions >= 1");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (!h->initialised) {
+        set_error("kabc_ais_init / kabc_ais_set_state has not been called");
+        return KABC_ERR_INVALID_STATE;
+    }
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    const int64_t gen_elems = h->N * h->D;
+    int64_t chunk = 1;
+    if (out_samples) {
+        chunk = (int64_t)((256ull << 20) / (sizeof(double) * (size_t)gen_elems));
+        if (chunk < 1) chunk = 1;
+        if (chunk > ngenerations) chunk = ngenerations;
+        if (chunk > h->trace_cap_gens) {
+            if (h->d_trace) KABC_HIP_CHECK(hipFree(h->d_trace));
+            h->d_trace = nullptr;
+            KABC_HIP_CHECK(hipMalloc(&h->d_trace, sizeof(double) * gen_elems * chunk));
+            h->trace_cap_gens = chunk;
+        }
+    }
+    for (int64_t g0 = 0; g0 < ngenerations; g0 += chunk) {
+        const int64_t gc = (ngenerations - g0 < chunk) ? ngenerations - g0 : chunk;
+        for (int64_t g = 0; g < gc; ++g) {
+            double* tr0 = out_samples ? h->d_trace + g * gen_elems : nullptr;
+            double* tr1 = out_samples ? tr0 + h->rows[0] * h->D : nullptr;
+            kabc_status_t st = kabc_ais_half_generation(h, 0, ntransitions, tr0);
+            if (st) return st;
+            st = kabc_ais_half_generation(h, 1, ntransitions, tr1);
+            if (st) return st;
+            h->t += (uint64_t)ntransitions;
+        }
+        if (out_samples) {
+            KABC_HIP_CHECK(hipMemcpyAsync(out_samples + g0 * gen_elems, h->d_trace,
+                                          sizeof(double) * gen_elems * gc, hipMemcpyDeviceToHost,
+                                          s));
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+        }
+    }
+    DevCounters c;
+    if (read_counters(h, &c)) return KABC_ERR_DEVICE;
+    kabc_status_t st = check_device_error(h, c);
+    if (st) return st;
+    if (stats) {
+        stats->proposals += c.proposals - h->last.proposals;
+        stats->cost_evals += c.cost_evals - h->last.cost_evals;
+        stats->accepted += c.accepted - h->last.accepted;
+    }
+    h->last.proposals = c.proposals;
+    h->last.cost_evals = c.cost_evals;
+    h->last.accepted = c.accepted;
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_get_state(kabc_ais_t* h, double* x, double* logprior, double* loglik,
+                                 uint64_t* t) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    int64_t off = 0;
+    for (int hf = 0; hf < 2; ++hf) {
+        const int64_t n = h->rows_owned[hf];
+        if (n > 0) {
+            if (x)
+                KABC_HIP_CHECK(hipMemcpyAsync(x + off * h->D,
+                                              h->d_half[hf] + h->row_first[hf] * h->D,
+                                              sizeof(double) * n * h->D, hipMemcpyDeviceToHost, s));
+            if (logprior)
+                KABC_HIP_CHECK(hipMemcpyAsync(logprior + off, h->d_lp[hf], sizeof(double) * n,
+                                              hipMemcpyDeviceToHost, s));
+            if (loglik)
+                KABC_HIP_CHECK(hipMemcpyAsync(loglik + off, h->d_ll[hf], sizeof(double) * n,
+                                              hipMemcpyDeviceToHost, s));
+        }
+        off += n;
+    }
+    KABC_HIP_CHECK(hipStreamSynchronize(s));
+    if (t) *t = h->t;
+    DevCounters c;
+    if (read_counters(h, &c)) return KABC_ERR_DEVICE;
+    return check_device_error(h, c);
+}
+
+kabc_status_t kabc_ais_set_state(kabc_ais_t* h, const double* x, const double* logprior,
+                                 const double* loglik, uint64_t t) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    if (!x || !logprior || !loglik) {
+        set_error("kabc_ais_set_state: NULL buffer");
+        return KABC_ERR_INVALID_ARG;
+    }
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    int64_t off = 0;
+    for (int hf = 0; hf < 2; ++hf) {
+        const int64_t n = h->rows_owned[hf];
+        if (n > 0) {
+            KABC_HIP_CHECK(hipMemcpyAsync(h->d_half[hf] + h->row_first[hf] * h->D, x + off * h->D,
+                                          sizeof(double) * n * h->D, hipMemcpyHostToDevice, s));
+            KABC_HIP_CHECK(hipMemcpyAsync(h->d_lp[hf], logprior + off, sizeof(double) * n,
+                                          hipMemcpyHostToDevice, s));
+            KABC_HIP_CHECK(hipMemcpyAsync(h->d_ll[hf], loglik + off, sizeof(double) * n,
+                                          hipMemcpyHostToDevice, s));
+        }
+        off += n;
+    }
+    KABC_HIP_CHECK(hipStreamSynchronize(s));
+    h->t = t;
+    h->initialised = true;
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_get_stats(kabc_ais_t* h, kabc_stats_t* stats) {
+    if (check_handle(h) || !stats) return KABC_ERR_INVALID_ARG;
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    DevCounters c;
+    if (read_counters(h, &c)) return KABC_ERR_DEVICE;
+    stats->proposals = c.proposals;
+    stats->cost_evals = c.cost_evals;
+    stats->accepted = c.accepted;
+    return check_device_error(h, c);
+}
+
+int64_t kabc_ais_owned(const kabc_ais_t* h, int32_t half) {
+    if (!h || (half != 0 && half != 1)) return -1;
+    return h->rows_owned[half];
+}
+
+kabc_status_t kabc_ais_set_timing(kabc_ais_t* h, int32_t max_launches) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear();
+    h->ev_used = 0;
+    h->timing = max_launches > 0;
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipEvent_t e;
+        KABC_HIP_CHECK(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    return KABC_OK;
+}
+
+double kabc_ais_kernel_ms(kabc_ais_t* h, int64_t* nlaunches) {
+    if (nlaunches) *nlaunches = 0;
+    if (!h || h->ev_used == 0) return 0.0;
+    (void)hipSetDevice(h->ctx->device);
+    if (hipStreamSynchronize(h->ctx->stream) != hipSuccess) return 0.0;
+    double total = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) {
+            total += ms;
+            ++n;
+        }
+    }
+    h->ev_used = 0;
+    if (nlaunches) *nlaunches = n;
+    return n ? total / (double)n : 0.0;
+}
+
+kabc_status_t kabc_ais_set_debug(kabc_ais_t* h, int32_t ntransitions) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    if (h->d_dbg) (void)hipFree(h->d_dbg);
+    h->d_dbg = nullptr;
+    h->dbg_cap = 0;
+    if (ntransitions > 0) {
+        h->dbg_cap = (h->rows_owned[0] + h->rows_owned[1]) * (int64_t)ntransitions * 6;
+        KABC_HIP_CHECK(hipMalloc(&h->d_dbg, sizeof(int32_t) * h->dbg_cap));
+        KABC_HIP_CHECK(hipMemset(h->d_dbg, 0xff, sizeof(int32_t) * h->dbg_cap));
+    }
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_get_debug(kabc_ais_t* h, int32_t* out, int64_t n_int32) {
+    if (check_handle(h) || !out) return KABC_ERR_INVALID_ARG;
+    if (!h->d_dbg || n_int32 > h->dbg_cap) {
+        set_error("debug records not enabled or buffer too large");
+        return KABC_ERR_INVALID_ARG;
+    }
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    KABC_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+    KABC_HIP_CHECK(hipMemcpy(out, h->d_dbg, sizeof(int32_t) * n_int32, hipMemcpyDeviceToHost));
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_destroy(kabc_ais_t* h) {
+    if (!h) return KABC_OK;
+    (void)hipSetDevice(h->ctx->device);
+    (void)hipStreamSynchronize(h->ctx->stream);
+    for (int hf = 0; hf < 2; ++hf) {
+        if (h->own_halves && h->d_half[hf]) (void)hipFree(h->d_half[hf]);
+        if (h->d_lp[hf]) (void)hipFree(h->d_lp[hf]);
+        if (h->d_ll[hf]) (void)hipFree(h->d_ll[hf]);
+    }
+    if (h->d_cost_params) (void)hipFree(h->d_cost_params);
+    if (h->d_cost_data) (void)hipFree(h->d_cost_data);
+    if (h->d_counters) (void)hipFree(h->d_counters);
+    if (h->d_trace) (void)hipFree(h->d_trace);
+    if (h->d_dbg) (void)hipFree(h->d_dbg);
+    for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    delete h;
+    return KABC_OK;
+}
+
+}  // extern "C"

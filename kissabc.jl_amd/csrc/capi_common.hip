@@ -1,0 +1,248 @@
+// capi_common.hip -- context, error plumbing, prior preparation and the small
+// Factored utility kernels (logpdf / rand) of the C ABI (include/kabc.h).
+#include "ais_kernels.hpp"
+#include "host_common.hpp"
+
+namespace kabc {
+
+static thread_local char g_err[768];
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_err; }
+
+static double std_normal_cdf(double z) { return 0.5 * std::erfc(-z * M_SQRT1_2); }
+
+bool prepare_prior(const kabc_prior_t& pr, PriorDev& q) {
+    q.kind = pr.kind;
+    q.discrete = kabc_prior_is_discrete(pr.kind);
+    for (int j = 0; j < 4; ++j) q.p[j] = pr.p[j];
+    q.c0 = q.c1 = 0.0;
+    const double a = pr.p[0], b = pr.p[1];
+    switch (pr.kind) {
+        case KABC_PRIOR_UNIFORM:
+            if (!(b > a)) return false;
+            q.c0 = -kabc_log(b - a);
+            return true;
+        case KABC_PRIOR_NORMAL:
+        case KABC_PRIOR_LOGNORMAL:
+            if (!(b > 0)) return false;
+            q.c0 = kabc_log(b);
+            return true;
+        case KABC_PRIOR_TRUNCNORMAL: {
+            if (!(b > 0) || !(pr.p[3] > pr.p[2])) return false;
+            q.c0 = kabc_log(b);
+            const double zl = (pr.p[2] - a) / b, zh = (pr.p[3] - a) / b;
+            const double tp = (zl > 0) ? std_normal_cdf(-zl) - std_normal_cdf(-zh)
+                                       : std_normal_cdf(zh) - std_normal_cdf(zl);
+            q.c1 = std::log(tp);
+            return true;
+        }
+        case KABC_PRIOR_BETA:
+            if (!(a > 0) || !(b > 0)) return false;
+            q.c0 = std::lgamma(a) + std::lgamma(b) - std::lgamma(a + b);
+            return true;
+        case KABC_PRIOR_DISCRETE_UNIFORM:
+            if (!(b >= a) || a != kabc_rint(a) || b != kabc_rint(b)) return false;
+            q.c0 = -kabc_log(b - a + 1.0);
+            return true;
+        case KABC_PRIOR_NEGBINOMIAL:
+            if (!(a > 0) || !(b > 0) || !(b <= 1)) return false;
+            q.c0 = a * kabc_log(b) - std::lgamma(a);
+            q.c1 = kabc_log1p(-b);
+            return true;
+        case KABC_PRIOR_EXPONENTIAL:
+            if (!(a > 0)) return false;
+            q.c0 = kabc_log(a);
+            return true;
+        case KABC_PRIOR_GAMMA:
+            if (!(a > 0) || !(b > 0)) return false;
+            q.c0 = std::lgamma(a) + a * kabc_log(b);
+            return true;
+        default: return false;
+    }
+}
+
+bool prepare_priors(const kabc_prior_t* prior, int D, PriorSet& out) {
+    if (!prior || D < 1 || D > KABC_MAX_DIM) return false;
+    std::memset(&out, 0, sizeof out);
+    for (int k = 0; k < D; ++k)
+        if (!prepare_prior(prior[k], out.c[k])) return false;
+    return true;
+}
+
+// ---- Factored utility kernels (runtime D; not on the hot path) --------------
+struct PriorUtilArgs {
+    const double* x;
+    double* out;
+    int64_t n;
+    int32_t D;
+    int32_t mode;  // 0 logpdf, 1 push_p
+    uint64_t seed;
+    uint64_t attempt;
+    uint32_t first_walker;
+    uint32_t domain;
+    PriorSet prior;
+    kabc_prior_t raw[KABC_MAX_DIM];
+};
+
+__global__ void __launch_bounds__(256) prior_logpdf_kernel(const PriorUtilArgs A) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    double s = 0.0;
+    for (int k = 0; k < A.D; ++k) {
+        const double xv = A.x[i * A.D + k];
+        const double v = A.prior.c[k].discrete ? kabc_rint(xv) : xv;
+        if (A.mode == 1) {
+            A.out[i * A.D + k] = v;
+        } else {
+            // logpdf(Factored, x) is evaluated on x as given (src/priors.jl:275-281)
+            const double l = comp_logpdf(A.prior.c[k], xv);
+            s = (k == 0) ? l : s + l;
+        }
+    }
+    if (A.mode == 0) A.out[i] = s;
+}
+
+__global__ void __launch_bounds__(256) prior_rand_kernel(const PriorUtilArgs A) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.n) return;
+    for (int k = 0; k < A.D; ++k) {
+        kabc_slotwin_t win = {A.seed, A.attempt, A.first_walker + (uint32_t)i, A.domain,
+                              (uint32_t)k * KABC_SLOTS_PER_DIM};
+        A.out[i * A.D + k] = kabc_sample_prior(&A.raw[k], &win);
+    }
+}
+
+}  // namespace kabc
+
+using namespace kabc;
+
+extern "C" {
+
+int32_t kabc_version(void) { return KABC_VERSION; }
+const char* kabc_last_error(void) { return get_error(); }
+
+int32_t kabc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+kabc_status_t kabc_ctx_create(int32_t device_id, void* stream, kabc_ctx_t** out) {
+    if (!out) {
+        set_error("kabc_ctx_create: out is NULL");
+        return KABC_ERR_INVALID_ARG;
+    }
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("kabc_ctx_create: no HIP device visible (the gfx950 kernels cannot run; "
+                  "there is no CPU fallback)");
+        return KABC_ERR_DEVICE;
+    }
+    if (device_id < 0 || device_id >= n) {
+        set_error("kabc_ctx_create: device %d out of range [0,%d)", device_id, n);
+        return KABC_ERR_INVALID_ARG;
+    }
+    KABC_HIP_CHECK(hipSetDevice(device_id));
+    kabc_ctx_t* c = new kabc_ctx_t();
+    c->device = device_id;
+    c->own_stream = (stream == nullptr);
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            delete c;
+            set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+            return KABC_ERR_DEVICE;
+        }
+    }
+    *out = c;
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ctx_destroy(kabc_ctx_t* ctx) {
+    if (!ctx) return KABC_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ctx_synchronize(kabc_ctx_t* ctx) {
+    if (!ctx) {
+        set_error("ctx is NULL");
+        return KABC_ERR_INVALID_ARG;
+    }
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    KABC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return KABC_OK;
+}
+
+static kabc_status_t prior_util(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D, int64_t n,
+                                const double* x, double* out, int mode, uint64_t seed,
+                                uint64_t attempt, uint32_t first_walker, uint32_t domain) {
+    if (!ctx || !prior || !out || n < 0) {
+        set_error("invalid argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    PriorUtilArgs A;
+    std::memset(&A, 0, sizeof A);
+    if (!prepare_priors(prior, D, A.prior)) {
+        set_error("invalid prior (kind/parameters) or D outside 1..%d", KABC_MAX_DIM);
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (n == 0) return KABC_OK;
+    std::memcpy(A.raw, prior, sizeof(kabc_prior_t) * D);
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t in_bytes = sizeof(double) * n * D;
+    const size_t out_bytes = sizeof(double) * n * ((mode == 0) ? 1 : D);
+    double *dx = nullptr, *dout = nullptr;
+    if (mode != 2) {
+        KABC_HIP_CHECK(hipMalloc(&dx, in_bytes));
+        KABC_HIP_CHECK(hipMemcpyAsync(dx, x, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    KABC_HIP_CHECK(hipMalloc(&dout, out_bytes));
+    A.x = dx;
+    A.out = dout;
+    A.n = n;
+    A.D = D;
+    A.mode = mode;
+    A.seed = seed;
+    A.attempt = attempt;
+    A.first_walker = first_walker;
+    A.domain = domain;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (mode == 2)
+        hipLaunchKernelGGL(prior_rand_kernel, dim3(grid), dim3(256), 0, ctx->stream, A);
+    else
+        hipLaunchKernelGGL(prior_logpdf_kernel, dim3(grid), dim3(256), 0, ctx->stream, A);
+    KABC_HIP_CHECK(hipGetLastError());
+    KABC_HIP_CHECK(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KABC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (dx) (void)hipFree(dx);
+    (void)hipFree(dout);
+    return KABC_OK;
+}
+
+kabc_status_t kabc_factored_logpdf(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                                   int64_t n, const double* x, double* out) {
+    return prior_util(ctx, prior, D, n, x, out, 0, 0, 0, 0, 0);
+}
+kabc_status_t kabc_factored_push_p(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                                   int64_t n, const double* x, double* out) {
+    return prior_util(ctx, prior, D, n, x, out, 1, 0, 0, 0, 0);
+}
+kabc_status_t kabc_factored_rand(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                                 uint64_t seed, uint32_t domain, int64_t first_walker, int64_t n,
+                                 uint64_t attempt, double* out) {
+    return prior_util(ctx, prior, D, n, nullptr, out, 2, seed, attempt, (uint32_t)first_walker,
+                      domain);
+}
+
+}  // extern "C"

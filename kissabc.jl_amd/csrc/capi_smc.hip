@@ -1,0 +1,325 @@
+// capi_smc.hip -- kabc_smc_run: smc(prior, cost; kwargs...) of src/smc.jl:92-206
+// driven from the host, one ε-iteration = one select kernel + 1..(1+mcmc_retrys)
+// propose/accept kernels; the host reads one small control record per pass.
+#include <cmath>
+#include <vector>
+
+#define KABC_SMC_SINGLE_UNIT 1
+#include "host_common.hpp"
+#include "smc_kernels.hpp"
+
+namespace kabc {
+
+#define KABC_DECL_COST(id) SmcLaunchFn find_smc_kernel_cost_##id(int D);
+KABC_DECL_COST(1)
+KABC_DECL_COST(2)
+KABC_DECL_COST(3)
+KABC_DECL_COST(4)
+KABC_DECL_COST(5)
+KABC_DECL_COST(6)
+KABC_DECL_COST(7)
+KABC_DECL_COST(8)
+KABC_DECL_COST(9)
+KABC_DECL_COST(10)
+KABC_DECL_COST(11)
+
+SmcLaunchFn find_smc_kernel(int cost_id, int D) {
+    switch (cost_id) {
+        case 1: return find_smc_kernel_cost_1(D);
+        case 2: return find_smc_kernel_cost_2(D);
+        case 3: return find_smc_kernel_cost_3(D);
+        case 4: return find_smc_kernel_cost_4(D);
+        case 5: return find_smc_kernel_cost_5(D);
+        case 6: return find_smc_kernel_cost_6(D);
+        case 7: return find_smc_kernel_cost_7(D);
+        case 8: return find_smc_kernel_cost_8(D);
+        case 9: return find_smc_kernel_cost_9(D);
+        case 10: return find_smc_kernel_cost_10(D);
+        case 11: return find_smc_kernel_cost_11(D);
+        default: return nullptr;
+    }
+}
+
+template <int D>
+static void launch_smc_init_d(const SmcInitArgs& a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.N + kSmcBlock - 1) / kSmcBlock);
+    hipLaunchKernelGGL((smc_init_kernel<D>), dim3(grid), dim3(kSmcBlock), 0, s, a);
+}
+template <int... Ds>
+static void launch_smc_init(int D, const SmcInitArgs& a, hipStream_t s,
+                            std::integer_sequence<int, Ds...>) {
+    using Fn = void (*)(const SmcInitArgs&, hipStream_t);
+    static const Fn fns[] = {&launch_smc_init_d<Ds + 1>...};
+    fns[D - 1](a, s);
+}
+
+struct DevBufs {
+    std::vector<void*> ptrs;
+    ~DevBufs() {
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    template <class T>
+    hipError_t alloc(T** p, size_t n) {
+        hipError_t e = hipMalloc(p, sizeof(T) * (n ? n : 1));
+        if (e == hipSuccess) ptrs.push_back(*p);
+        return e;
+    }
+};
+
+}  // namespace kabc
+
+using namespace kabc;
+
+extern "C" {
+
+void kabc_smc_default_opts(kabc_smc_opts_t* o) {
+    if (!o) return;
+    o->nparticles = 100;
+    o->alpha = 0.95;
+    o->mcmc_retrys = 0;
+    o->verbose = 0;
+    o->mcmc_tol = 0.015;
+    o->epstol = 0.0;
+    o->r_epstol = NAN;
+    o->min_r_ess = NAN;
+    o->max_stretch = 2.0;
+    o->seed = 0;
+    o->max_iterations = 0;
+}
+
+kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                           const kabc_cost_t* cost, const kabc_smc_opts_t* o,
+                           kabc_smc_result_t* res) {
+    if (!ctx || !prior || !cost || !o || !res) {
+        set_error("kabc_smc_run: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    const int64_t N = o->nparticles;
+    const double alpha = o->alpha;
+    const double r_epstol = std::isnan(o->r_epstol) ? std::pow(1.0 - alpha, 1.5) / 50.0 : o->r_epstol;
+    const double min_r_ess = std::isnan(o->min_r_ess) ? alpha * alpha : o->min_r_ess;
+    // src/smc.jl:107-118, same messages
+#define KABC_REQ(cond, msg)          \
+    if (!(cond)) {                   \
+        set_error(msg);              \
+        return KABC_ERR_INVALID_ARG; \
+    }
+    KABC_REQ(min_r_ess > 0, "min_r_ess must be > 0.")
+    KABC_REQ(o->mcmc_retrys >= 0, "mcmc_retrys must be >= 0.")
+    KABC_REQ(alpha > 0, "alpha must be > 0.")
+    KABC_REQ(r_epstol >= 0, "r_epstol must be >= 0")
+    KABC_REQ(o->mcmc_tol >= 0, "mcmc_tol must be >= 0")
+    KABC_REQ(o->max_stretch > 1, "max_stretch must be > 1")
+#undef KABC_REQ
+    if (D < 1 || D > KABC_MAX_DIM) {
+        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    PriorSet P;
+    if (!prepare_priors(prior, D, P)) {
+        set_error("invalid prior parameters");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (!kabc_cost_dim_ok(cost->id, D)) {
+        set_error("DeviceCost id %d does not accept D = %d", cost->id, D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    SmcLaunchFn mcmc = find_smc_kernel(cost->id, D);
+    if (!mcmc) {
+        set_error("no gfx950 kernel instantiated for cost id %d, D = %d", cost->id, D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    {
+        const double mn = alpha < min_r_ess ? alpha : min_r_ess;
+        const int64_t min_n = (int64_t)std::ceil(3.0 * D / mn);
+        if (N < min_n) {
+            set_error("nparticles must be >= %lld.", (long long)min_n);
+            return KABC_ERR_INVALID_ARG;
+        }
+        if (N >= (1ll << 31)) {
+            set_error("nparticles must be < 2^31");
+            return KABC_ERR_INVALID_ARG;
+        }
+    }
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBufs bufs;
+    double *th[2], *X[2], *lp[2], *d_params = nullptr, *d_data = nullptr, *d_out = nullptr;
+    uint8_t* alive;
+    int32_t *ridx, *cidx;
+    SmcCtrl* ctrl;
+    for (int b = 0; b < 2; ++b) {
+        KABC_HIP_CHECK(bufs.alloc(&th[b], (size_t)N * D));
+        KABC_HIP_CHECK(bufs.alloc(&X[b], (size_t)N));
+        KABC_HIP_CHECK(bufs.alloc(&lp[b], (size_t)N));
+    }
+    KABC_HIP_CHECK(bufs.alloc(&alive, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&ridx, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&ctrl, 1));
+    KABC_HIP_CHECK(bufs.alloc(&d_out, (size_t)N * D));
+    KABC_HIP_CHECK(hipMemsetAsync(ctrl, 0, sizeof(SmcCtrl), s));
+    if (cost->nparams > 0) {
+        KABC_HIP_CHECK(bufs.alloc(&d_params, (size_t)cost->nparams));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_params, cost->params, sizeof(double) * cost->nparams,
+                                      hipMemcpyHostToDevice, s));
+    }
+    if (cost->ndata > 0) {
+        KABC_HIP_CHECK(bufs.alloc(&d_data, (size_t)cost->ndata));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_data, cost->data, sizeof(double) * cost->ndata,
+                                      hipMemcpyHostToDevice, s));
+    }
+    hipEvent_t ev0, ev1;
+    KABC_HIP_CHECK(hipEventCreate(&ev0));
+    KABC_HIP_CHECK(hipEventCreate(&ev1));
+    double mcmc_ms = 0.0;
+    int64_t mcmc_launches = 0;
+
+    // :119-125
+    {
+        SmcInitArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.theta = th[0];
+        a.X = X[0];
+        a.lpi = lp[0];
+        a.alive = alive;
+        a.ctrl = ctrl;
+        a.cost_params = d_params;
+        a.cost_data = d_data;
+        a.cost_ndata = cost->ndata;
+        a.N = N;
+        a.seed = o->seed;
+        a.cost_id = cost->id;
+        a.prior = P;
+        std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
+        launch_smc_init(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+        KABC_HIP_CHECK(hipGetLastError());
+    }
+    int cur = 0;
+    double eps = INFINITY;
+    int64_t iteration = 0;
+    uint64_t pass = 0;
+    const int64_t max_it = o->max_iterations > 0 ? o->max_iterations : 100000;
+    SmcCtrl hc;
+    std::memset(&hc, 0, sizeof hc);
+    kabc_status_t rc = KABC_OK;
+    while (true) {
+        ++iteration;
+        const double epsv = eps;
+        // Step 1 + 2 (decision and index) on the device
+        SmcSelectArgs sa;
+        sa.X = X[cur];
+        sa.alive = alive;
+        sa.ridx = ridx;
+        sa.cidx = cidx;
+        sa.ctrl = ctrl;
+        sa.N = N;
+        sa.alpha = alpha;
+        sa.min_r_ess = min_r_ess;
+        hipLaunchKernelGGL(smc_select_kernel, dim3(1), dim3(kSelBlock), 0, s, sa);
+        KABC_HIP_CHECK(hipGetLastError());
+        // Step 3
+        int passes = 0;
+        for (int r = 1; r <= 1 + o->mcmc_retrys; ++r) {
+            ++pass;
+            ++passes;
+            SmcMcmcArgs ma;
+            std::memset(&ma, 0, sizeof ma);
+            ma.theta_src = th[cur];
+            ma.X_src = X[cur];
+            ma.lpi_src = lp[cur];
+            ma.theta_dst = th[1 - cur];
+            ma.X_dst = X[1 - cur];
+            ma.lpi_dst = lp[1 - cur];
+            ma.alive = alive;
+            ma.ridx = (r == 1) ? ridx : nullptr;
+            ma.ctrl = ctrl;
+            ma.cost_params = d_params;
+            ma.cost_data = d_data;
+            ma.cost_ndata = cost->ndata;
+            ma.N = N;
+            ma.seed = o->seed;
+            ma.pass = pass;
+            ma.max_stretch = o->max_stretch;
+            ma.prior = P;
+            KABC_HIP_CHECK(hipEventRecord(ev0, s));
+            mcmc(ma, s);
+            KABC_HIP_CHECK(hipEventRecord(ev1, s));
+            KABC_HIP_CHECK(hipGetLastError());
+            cur = 1 - cur;
+            KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+                mcmc_ms += ms;
+                ++mcmc_launches;
+            }
+            if (hc.error) break;
+            if ((double)hc.accepted >= o->mcmc_tol * (double)N) break;  // :192
+        }
+        if (hc.error) {
+            if (hc.error == 1) {
+                set_error("quantiles are undefined in presence of NaNs");
+                rc = KABC_ERR_NAN_COST;
+            } else {
+                set_error("collection must be non-empty");
+                rc = KABC_ERR_INVALID_STATE;
+            }
+            break;
+        }
+        eps = hc.eps;
+        if (o->verbose)
+            fprintf(stderr, "(iteration, ϵ, ESS) = (%lld, %.17g, %lld)\n", (long long)iteration,
+                    eps, (long long)hc.ess);
+        if (res->iter_log && iteration <= res->iter_log_cap) {
+            kabc_smc_iter_t* L = &res->iter_log[iteration - 1];
+            L->eps = eps;
+            L->ess = hc.ess;
+            L->accepted = (int64_t)hc.accepted;
+            L->resampled = hc.resampled;
+            L->flag = hc.flag;
+            L->mcmc_passes = passes;
+            L->reserved = 0;
+        }
+        // :194-198
+        const double acc = (double)hc.accepted;
+        if (2.0 * std::fabs(epsv - eps) < r_epstol * (std::fabs(epsv) + std::fabs(eps)) ||
+            eps <= o->epstol || acc < o->mcmc_tol * (double)N)
+            break;
+        if (iteration >= max_it) break;
+    }
+    if (rc == KABC_OK) {
+        // :200-205
+        SmcFinalArgs fa;
+        fa.theta = th[cur];
+        fa.out = d_out;
+        fa.N = N;
+        fa.D = D;
+        fa.prior = P;
+        hipLaunchKernelGGL(smc_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
+                           fa);
+        KABC_HIP_CHECK(hipGetLastError());
+        if (res->theta)
+            KABC_HIP_CHECK(hipMemcpyAsync(res->theta, d_out, sizeof(double) * N * D,
+                                          hipMemcpyDeviceToHost, s));
+        if (res->cost)
+            KABC_HIP_CHECK(hipMemcpyAsync(res->cost, X[cur], sizeof(double) * N,
+                                          hipMemcpyDeviceToHost, s));
+        if (res->alive)
+            KABC_HIP_CHECK(hipMemcpyAsync(res->alive, alive, (size_t)N, hipMemcpyDeviceToHost, s));
+        KABC_HIP_CHECK(hipStreamSynchronize(s));
+        res->eps = eps;
+        res->iterations = iteration;
+        res->n_alive = hc.n_alive;
+        res->cost_evals = hc.cost_evals;
+        res->proposals = hc.proposals;
+        res->kernel_ms_mcmc = mcmc_launches ? mcmc_ms / (double)mcmc_launches : 0.0;
+        res->mcmc_launches = mcmc_launches;
+    }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// kabc_device.hpp -- device-side building blocks shared by the gfx950 kernels.
+//
+// Data layout in HBM (DESIGN.md "Layout"):
+//   half h of the ensemble : row-major [rows_h][D] f64  (one walker = one
+//     D*8-byte row; D = 8 -> one 64-byte line, fetched by a single lane with
+//     dwordx4 loads both for its own row and for a randomly drawn partner)
+//   logprior / loglik|cost : [rows_owned] f64 each, per half
+// Random draws are counter-based (include/kabc_philox.h): no RNG state in memory.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <utility>
+
+#include "kabc.h"
+#include "kabc_costs.h"
+#include "kabc_math.h"
+#include "kabc_philox.h"
+#include "kabc_sampling.h"
+
+namespace kabc {
+
+constexpr int kWave = 64;
+
+// one prepared component of Factored(...): parameters + derived normalisers
+struct PriorDev {
+    int32_t kind;
+    int32_t discrete;
+    double p[4];
+    double c0, c1;
+};
+
+struct PriorSet {
+    PriorDev c[KABC_MAX_DIM];
+};
+
+// Distributions.logpdf(p_k, x) on the device.  Same formulas, same operation
+// order as the host-side definition pinned by tests/golden/priors_logpdf.json.
+__device__ __forceinline__ double comp_logpdf(const PriorDev& q, double x) {
+    const double a = q.p[0], b = q.p[1];
+    switch (q.kind) {
+        case KABC_PRIOR_UNIFORM: return (x >= a && x <= b) ? q.c0 : -KABC_INF;
+        case KABC_PRIOR_NORMAL: {
+            const double z = (x - a) / b;
+            return -(z * z + KABC_LOG_2PI) / 2.0 - q.c0;
+        }
+        case KABC_PRIOR_TRUNCNORMAL: {
+            if (!(x >= q.p[2] && x <= q.p[3])) return -KABC_INF;
+            const double z = (x - a) / b;
+            return -(z * z + KABC_LOG_2PI) / 2.0 - q.c0 - q.c1;
+        }
+        case KABC_PRIOR_BETA: {
+            if (!(x >= 0.0 && x <= 1.0)) return -KABC_INF;
+            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log(x);
+            const double t2 = (b == 1.0) ? 0.0 : (b - 1.0) * kabc_log1p(-x);
+            return t1 + t2 - q.c0;
+        }
+        case KABC_PRIOR_DISCRETE_UNIFORM:
+            return (x >= a && x <= b && x == kabc_rint(x)) ? q.c0 : -KABC_INF;
+        case KABC_PRIOR_NEGBINOMIAL: {
+            if (!(x >= 0.0) || x != kabc_rint(x)) return -KABC_INF;
+            return q.c0 + x * q.c1 + kabc_lgamma(x + a) - kabc_lgamma(x + 1.0);
+        }
+        case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -q.c0 - x / a : -KABC_INF;
+        case KABC_PRIOR_GAMMA: {
+            if (!(x >= 0.0)) return -KABC_INF;
+            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log(x);
+            return t1 - x / b - q.c0;
+        }
+        case KABC_PRIOR_LOGNORMAL: {
+            if (!(x > 0.0)) return -KABC_INF;
+            const double lx = kabc_log(x);
+            const double z = (lx - a) / b;
+            return -(z * z + KABC_LOG_2PI) / 2.0 - q.c0 - lx;
+        }
+        default: return KABC_NAN;
+    }
+}
+
+// push_p (src/types.jl:109-114) followed by logpdf(d::Factored, x) = left-to-right
+// sum over components (src/priors.jl:275-281).  xp receives push_p(x).
+template <int D>
+__device__ __forceinline__ double factored_logpdf_push(const PriorSet& P, const double* x,
+                                                       double* xp) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double v = P.c[k].discrete ? kabc_rint(x[k]) : x[k];
+        xp[k] = v;
+        const double l = comp_logpdf(P.c[k], v);
+        s = (k == 0) ? l : s + l;
+    }
+    return s;
+}
+
+// compile-time cost dispatch on the DeviceCost id (formulas: include/kabc_costs.h)
+template <int COST, int D>
+__device__ __forceinline__ double eval_cost(const double* xp, const double* __restrict__ params,
+                                            const double* __restrict__ data, int64_t ndata,
+                                            kabc_cost_rng_t* rng) {
+    if constexpr (COST == KABC_COST_GAUSS_DIST) return kabc_cost_gauss_dist(xp, D, params);
+    else if constexpr (COST == KABC_COST_ROSENBROCK) return kabc_cost_rosenbrock(xp, D);
+    else if constexpr (COST == KABC_COST_HIER_GAUSS_SIM) return kabc_cost_hier_gauss_sim(xp, D, data, rng);
+    else if constexpr (COST == KABC_COST_NORMAL_MEANSTD_SIM) return kabc_cost_normal_meanstd_sim(xp, params, rng);
+    else if constexpr (COST == KABC_COST_DIRAC_SQ) return kabc_cost_dirac_sq(xp, params);
+    else if constexpr (COST == KABC_COST_ABS_DIFF) return kabc_cost_abs_diff(xp, params);
+    else if constexpr (COST == KABC_COST_NORM_SHELL) return kabc_cost_norm_shell(xp, D, params);
+    else if constexpr (COST == KABC_COST_NOISY_QUAD_DU) return kabc_cost_noisy_quad_du(xp, params, rng);
+    else if constexpr (COST == KABC_COST_MIXTURE) return kabc_cost_mixture(xp, params, rng);
+    else if constexpr (COST == KABC_COST_NOISY_BANANA) return kabc_cost_noisy_banana(xp, params, rng);
+    else if constexpr (COST == KABC_COST_WIENER_RMS) return kabc_cost_wiener_rms(xp, data, ndata, rng);
+    else return KABC_NAN;
+}
+
+// row load/store: 16-byte vector accesses when the row is a multiple of 16 bytes
+template <int D>
+__device__ __forceinline__ void load_row(const double* __restrict__ p, double* out) {
+    if constexpr (D % 2 == 0) {
+        const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+        for (int k = 0; k < D / 2; ++k) {
+            const double2 v = q[k];
+            out[2 * k] = v.x;
+            out[2 * k + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) out[k] = p[k];
+    }
+}
+template <int D>
+__device__ __forceinline__ void store_row(double* __restrict__ p, const double* v) {
+    if constexpr (D % 2 == 0) {
+        double2* q = reinterpret_cast<double2*>(p);
+#pragma unroll
+        for (int k = 0; k < D / 2; ++k) q[k] = make_double2(v[2 * k], v[2 * k + 1]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) p[k] = v[k];
+    }
+}
+
+// sum a per-lane counter over the wave (DPP/permute shuffles) -- result in lane 0
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// compile-time mirror of kabc_cost_dim_ok (include/kabc_costs.h)
+constexpr bool cost_dim_ok_c(int id, int D) {
+    switch (id) {
+        case KABC_COST_GAUSS_DIST: return D >= 1;
+        case KABC_COST_ROSENBROCK: return D >= 2;
+        case KABC_COST_HIER_GAUSS_SIM: return D >= 3;
+        case KABC_COST_NORMAL_MEANSTD_SIM: return D == 2;
+        case KABC_COST_DIRAC_SQ: return D == 1;
+        case KABC_COST_ABS_DIFF: return D == 1;
+        case KABC_COST_NORM_SHELL: return D >= 1;
+        case KABC_COST_NOISY_QUAD_DU: return D == 2;
+        case KABC_COST_MIXTURE: return D == 1;
+        case KABC_COST_NOISY_BANANA: return D == 2;
+        case KABC_COST_WIENER_RMS: return D == 2;
+        default: return false;
+    }
+}
+
+// device-side counters shared by a handle
+struct DevCounters {
+    unsigned long long proposals;
+    unsigned long long cost_evals;
+    unsigned long long accepted;
+    unsigned long long retries;   // init: total re-draws (src/KissABC.jl:57)
+    int32_t error;                // 0 ok, 1 correction invalid, 2 starting sample invalid
+    int32_t init_failed;          // retry budget exhausted
+};
+
+}  // namespace kabc

@@ -1,0 +1,36 @@
+// smc_inst.hip -- instantiates smc_mcmc_kernel<D, COST> for one DeviceCost id
+// (-DKABC_INST_COST=<id>) and every dimension the cost accepts.
+#include "smc_kernels.hpp"
+
+#ifndef KABC_INST_COST
+#error "compile with -DKABC_INST_COST=<cost id>"
+#endif
+
+namespace kabc {
+
+template <int D, int COST>
+static void launch_mcmc(const SmcMcmcArgs& a, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.N + kSmcBlock - 1) / kSmcBlock);
+    if (grid == 0) return;
+    hipLaunchKernelGGL((smc_mcmc_kernel<D, COST>), dim3(grid), dim3(kSmcBlock), 0, s, a);
+}
+
+template <int COST, int D>
+static SmcLaunchFn pick() {
+    if constexpr (cost_dim_ok_c(COST, D)) return &launch_mcmc<D, COST>;
+    else return nullptr;
+}
+
+template <int COST, int... Ds>
+static SmcLaunchFn table(int D, std::integer_sequence<int, Ds...>) {
+    SmcLaunchFn fns[] = {pick<COST, Ds + 1>()...};
+    return (D >= 1 && D <= (int)sizeof...(Ds)) ? fns[D - 1] : nullptr;
+}
+
+#define KABC_CAT2(a, b) a##b
+#define KABC_CAT(a, b) KABC_CAT2(a, b)
+SmcLaunchFn KABC_CAT(find_smc_kernel_cost_, KABC_INST_COST)(int D) {
+    return table<KABC_INST_COST>(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+}
+
+}  // namespace kabc
