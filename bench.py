@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- walker proposal+cost evaluations per second of the AIS hot path.
+
+Workload (BASELINE.json configs[2]): AIS, 65 536 walkers per GPU,
+D = 8, prior Factored(Uniform(-5,5))^8, cost sqrt(sum 100(x[k+1]-x[k]^2)^2 +
+(1-x[k])^2), ApproxKernelizedPosterior scale 1.0, ntransitions = 16, seed 1.
+A "step" is one GENERATION: every walker receives `ntransitions` transition!()
+calls (two half-generation kernel launches per GPU; for N>1 one RCCL all-gather
+after each).  Weak scaling: per-GPU walkers are fixed, N_total = 65 536 * gpus.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the half-generation kernel:
+algorithmic bytes per launch = rows * ntransitions * 8(3D+4)
+over the kernel's average duration measured with hipEvents on its stream over
+the timed region.  `cpu_baseline` times the CPU oracle's faithful serial
+restatement of the reference on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WALKERS_PER_GPU = 65536
+D = 8
+NT = 16
+SEED = 1
+HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_model(k):
+    prior = k.Factored(*[k.Uniform(-5, 5)] * D)
+    return k.ApproxKernelizedPosterior(prior, k.costs.Rosenbrock(), 1.0)
+
+
+def cpu_baseline(k, budget_s):
+    """Oracle, serial reference schedule (src/KissABC.jl:66-80), 1 core, same model,
+    bounded sample: N = 65 536 walkers, as many step() calls as fit the budget."""
+    from oracle import oracle as orc
+    model = build_model(k)
+    o = orc.OracleAIS(model, WALKERS_PER_GPU, seed=SEED).init()
+    o.steps_serial(2048, NT, collect=False)  # warm-up
+    nsteps, done, t0 = 4096, 0, time.perf_counter()
+    while True:
+        o.steps_serial(nsteps, NT, collect=False)
+        done += nsteps
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return {
+        "value": done * NT / el, "unit": "evals/s", "cores": 1, "kind": "port",
+        "sample": f"oracle ref_serial (C restatement of src/transition.jl + src/KissABC.jl:66-80), "
+                  f"N={WALKERS_PER_GPU} D={D} rosenbrock, {done} step() calls x ntransitions={NT} "
+                  f"in {el:.1f}s on 1 host core",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--ntransitions", type=int, default=NT)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    nt = args.ntransitions
+
+    import torch
+    import torch.distributed as dist
+
+    import kissabc_jl_amd as k
+    from kissabc_jl_amd.sharded import ShardedAIS
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    model = build_model(k)
+    n_total = WALKERS_PER_GPU * world
+    sh = ShardedAIS(model, n_total, seed=SEED, device=dev).init()
+    ens = sh.engine.ens
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        sh.generation(nt)
+    sync()
+    st0 = sh.global_stats()
+    ens.set_timing(2 * args.steps)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sh.generation(nt)
+    sync()
+    el = time.perf_counter() - t0
+    kms, nl = ens.kernel_ms()
+    ens.set_timing(0)
+    st1 = sh.global_stats()
+    tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    el = float(tmax.item())
+
+    if rank == 0:
+        proposals = st1["proposals"] - st0["proposals"]
+        cost_evals = st1["cost_evals"] - st0["cost_evals"]
+        assert proposals == n_total * nt * args.steps, (proposals, n_total * nt * args.steps)
+        bytes_per_eval = 8 * (3 * D + 4)
+        rows = WALKERS_PER_GPU // 2
+        alg_bytes_launch = rows * nt * bytes_per_eval
+        achieved = alg_bytes_launch / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        out = {
+            "metric": "walker proposal+cost evals/sec at N=65536 walkers, D=8",
+            "value": proposals / el, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "AIS C3: 65536 walkers/GPU x 8-param Rosenbrock-like cost, "
+                                   "Uniform(-5,5)^8 prior, kernelized scale 1.0",
+                       "walkers_per_gpu": WALKERS_PER_GPU, "walkers_total": n_total, "D": D,
+                       "ntransitions": nt, "evals_per_step": n_total * nt, "seed": SEED,
+                       "parallelism": f"walker-sharded x{world}, 1 all-gather per half-generation"
+                       if world > 1 else "single GPU"},
+            "cost_evals_per_s": cost_evals / el,
+            "accept_rate": (st1["accepted"] - st0["accepted"]) / max(1, proposals),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ais_half_kernel<8, rosenbrock>",
+                         "kernel_avg_ms": kms, "kernel_launches_timed": nl,
+                         "algorithmic_bytes_per_launch": alg_bytes_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(k, args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

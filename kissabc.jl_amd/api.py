@@ -251,7 +251,14 @@ def sample(model, spl, *args, ntransitions=1, discard_initial=0, retry_sampling=
     return out if return_array else _bundle(out, model.scalar)
 
 
-SmcResult = collections.namedtuple("SmcResult", ["P", "C", "ϵ", "info"])
+class SmcResult(collections.namedtuple("SmcResult", ["P", "C", "eps", "info"])):
+    """(P, C, ϵ) of src/smc.jl:205 (+ info); `.ϵ`/`.ε` alias `.eps`."""
+    __slots__ = ()
+
+    def __getattr__(self, name):
+        if name in ("\u03b5", "\u03f5"):
+            return self.eps
+        raise AttributeError(name)
 
 
 def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.015, epstol=0.0,

@@ -1,0 +1,109 @@
+"""CPU: the arithmetic contract (include/kabc_math.h, kabc_philox.h) against
+independent implementations: glibc libm through numpy, mpmath, and the
+Random123 known-answer vectors for Philox4x32-10."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import ulp_diff
+
+rng = np.random.default_rng(1)
+
+
+def test_philox_kat_oracle_restatement(orc):
+    # Random123 kat_vectors, philox4x32 10 rounds
+    assert orc.philox([0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert orc.philox([0xffffffff] * 4, [0xffffffff] * 2) == \
+        [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert orc.philox([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344],
+                      [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_philox_shared_header_matches_restatement(orc, k):
+    """kabc_philox.h (used by costs/sampling on host AND device) vs the oracle's
+    independent Philox: a Uniform(0,1) prior draw is u01(lo64(block))."""
+    from kissabc_jl_amd import _cdefs as cd
+    seed = 0x0123456789ABCDEF
+    n = 64
+    draws = orc.factored_rand(k.Factored(k.Uniform(0, 1), k.Uniform(0, 1)), n, seed=seed,
+                              domain=cd.DOM_SMC_INIT, first_walker=5, attempt=3)
+    for i in range(n):
+        for dim in range(2):
+            w = orc.philox([5 + i, 3, dim * 128, cd.DOM_SMC_INIT],
+                           [seed & 0xffffffff, seed >> 32])
+            lo = (w[1] << 32) | w[0]
+            u = ((lo >> 12) + 0.5) * 2.0 ** -52
+            assert draws[i, dim] == u
+
+
+def test_log_exp_log1p_within_1ulp_of_libm(orc):
+    u = rng.random(200000)
+    e = rng.integers(-300, 300, 200000)
+    x = np.ldexp(u + 0.5, e)
+    assert ulp_diff(orc.math_vec("log", x), np.log(x)).max() <= 1.0
+    assert ulp_diff(orc.math_vec("log", u), np.log(u)).max() <= 1.0
+    y = (u - 0.5) * 1400
+    assert ulp_diff(orc.math_vec("exp", y), np.exp(y)).max() <= 1.0
+    y = (u - 0.5) * 4
+    assert ulp_diff(orc.math_vec("exp", y), np.exp(y)).max() <= 1.0
+    z = np.ldexp(2 * u - 1, -rng.integers(0, 60, 200000))
+    z = z[z > -1]
+    assert ulp_diff(orc.math_vec("log1p", z), np.log1p(z)).max() <= 1.0
+
+
+def test_math_special_values(orc):
+    with np.errstate(all="ignore"):
+        x = np.array([0.0, -0.0, -1.0, np.inf, np.nan, 5e-324, 1.0, 2.2250738585072014e-308])
+        got, ref = orc.math_vec("log", x), np.log(x)
+    assert np.array_equal(got, ref, equal_nan=True)
+    x = np.array([710.0, -746.0, 0.0, -0.0, np.inf, -np.inf, 709.7, -745.0, -710.0])
+    with np.errstate(all="ignore"):
+        assert np.array_equal(orc.math_vec("exp", x), np.exp(x))
+    x = np.array([-1.0, -2.0, 0.0, 1e-300, np.inf])
+    with np.errstate(all="ignore"):
+        assert np.array_equal(orc.math_vec("log1p", x), np.log1p(x), equal_nan=True)
+
+
+def test_sqrt_rint_are_ieee(orc):
+    x = np.ldexp(rng.random(100000) + 0.5, rng.integers(-500, 500, 100000))
+    assert np.array_equal(orc.math_vec("sqrt", x), np.sqrt(x))
+    y = np.concatenate([rng.normal(0, 100, 1000), [0.5, 1.5, 2.5, -0.5, -1.5, 1e300]])
+    assert np.array_equal(orc.math_vec("rint", y), np.rint(y))  # ties to even = round(Int, x)
+
+
+def test_sincos2pi(orc):
+    import mpmath as mp
+    mp.mp.dps = 40
+    u = np.concatenate([rng.random(2000), [0.0, 0.125, 0.25, 0.5, 0.75, 1.0 - 2 ** -53]])
+    sc = orc.math_vec("sincos2pi", u)
+    for ui, (s, c) in zip(u, sc):
+        a = 2 * mp.pi * mp.mpf(float(ui))
+        assert abs(mp.sin(a) - s) < 5e-16 and abs(mp.cos(a) - c) < 5e-16
+
+
+def test_lgamma(orc):
+    from scipy.special import gammaln
+    x = np.concatenate([np.ldexp(rng.random(20000) + 0.5, rng.integers(-10, 14, 20000)),
+                        np.arange(1, 200, dtype=float), [0.5, 1.5]])
+    got, ref = orc.math_vec("lgamma", x), gammaln(x)
+    assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < 4e-14
+
+
+def test_box_muller_moments(orc):
+    r = rng.integers(0, 2 ** 64, size=400000, dtype=np.uint64)
+    z = orc.normal_pairs(r).ravel()
+    assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
+    from scipy import stats
+    assert stats.kstest(z[:50000], "norm").pvalue > 1e-3
+    assert np.all(np.isfinite(z))
+
+
+def test_cdf_g_inv_closed_forms(orc):
+    # src/transition.jl:46: cdf_g_inv(0,a) = 1/a, cdf_g_inv(1,a) = a
+    for a in (2.0, 3.0, 7.5):
+        assert orc.cdf_g_inv(0.0, a) == pytest.approx(1 / a, rel=4e-16)
+        assert orc.cdf_g_inv(1.0, a) == pytest.approx(a, rel=4e-16)
+    z = np.array([orc.cdf_g_inv(u, 3.0) for u in rng.random(1000)])
+    assert z.min() >= 1 / 3 - 1e-15 and z.max() <= 3 + 1e-15
