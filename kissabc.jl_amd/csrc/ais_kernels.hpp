@@ -22,6 +22,7 @@ struct AisArgs {
     double* trace;          // optional [rows_owned][D]: push_p(x) after the last transition
     int32_t* dbg;           // optional [rows_owned][nt][6] per-transition records
     DevCounters* counters;
+    unsigned long long* slots;  // [kCounterSlots][8] per-workgroup counter lines (no contention)
     const double* cost_params;
     const double* cost_data;
     int64_t cost_ndata;
@@ -34,8 +35,13 @@ struct AisArgs {
     int32_t nt;             // ntransitions
     int32_t posterior;      // kabc_posterior_kind_t
     double eps;             // scale | maxcost
-    PriorSet prior;
+    double reps;            // RN(1/eps) for kabc_div_rc
+    double box_lp;          // prior class BOX: the in-support log-density (ordered sum of c0)
+    int32_t ablate;         // timing experiments only (KABC_ABLATE): 1 no consumer, 2 no producers
+    const PriorDev* prior;  // [D] prepared components, device memory (scalar-loaded)
 };
+
+constexpr int kCounterSlots = 1024;  // one 64-byte line per workgroup (mod 1024)
 
 struct InitArgs {
     double* x_act;
@@ -57,7 +63,50 @@ struct InitArgs {
     kabc_prior_t raw[KABC_MAX_DIM];
 };
 
-constexpr int kAisBlock = 64;  // one wavefront per workgroup: 512 WGs at N/2 = 32768
+constexpr int kInitBlock = 64;
+
+// ---- geometry of the half-generation kernel --------------------------------
+// One workgroup = one BATCH of 64 walkers = 4 wavefronts with fixed roles:
+//   wave 0      : CONSUMER.  Lane l owns walker l of the batch and runs the
+//                 state-dependent chain proposal -> push_p -> prior logpdf ->
+//                 cost -> accept for `ntransitions` consecutive sub-steps with
+//                 x, logprior, loglik in registers.
+//   waves 1..3  : PRODUCERS.  Everything a transition draws is a pure function
+//                 of (seed, walker, t, slot) (include/kabc_philox.h), i.e. it does
+//                 not depend on the walker's state.  Producer wave q prepares
+//                 sub-step q of the NEXT chunk of kChunk sub-steps: move id,
+//                 partner rows, log(u_accept), Z and (D-1)log Z, gamma, the
+//                 normal variates -- as SoA records in LDS.
+// The three moves need very different amounts of randomness (stretch 2 Philox
+// blocks, DE 3 + (D+2)/2 Box-Muller blocks, walk 3 + 2).  A lane-per-walker
+// kernel serialises all three under divergence in every wavefront; here the
+// producers turn the variable part into dense work lists (wave ballot + mbcnt
+// compaction in LDS) so that every Philox/Box-Muller instruction runs with
+// (nearly) all 64 lanes doing useful work.  Records are double-buffered: the
+// consumer reads chunk c while the producers fill chunk c+1; one workgroup
+// barrier per chunk.
+constexpr int kAisBlock = 256;
+constexpr int kBatch = 64;   // walkers per workgroup
+constexpr int kChunk = 3;    // sub-steps per record buffer = number of producer waves
+
+template <int D>
+struct RecGeom {
+    static constexpr int NB = (D + 2) / 2;                 // normal blocks of a DE move
+    static constexpr int NZ = (D + 1 > 4) ? (D + 1) : 4;   // doubles per record
+};
+
+// SoA record buffer of one chunk, lane-contiguous (conflict-free ds_read_b64)
+template <int D>
+struct ChunkRec {
+    uint32_t mva[kChunk][kBatch];   // (move << 30) | partner row a
+    uint32_t bb[kChunk][kBatch];    // partner row b (DE, walk)
+    uint32_t cc[kChunk][kBatch];    // partner row c (walk)
+    double logu[kChunk][kBatch];    // log(u) = -randexp(rng)          (src/types.jl:156)
+    // stretch: zs[0] = Z, zs[1] = (D-1) log Z     (src/transition.jl:56-58)
+    // de     : zs[0] = gamma, zs[1..D] = randn per coordinate (:3, :13)
+    // walk   : zs[0..2] = the three randn           (:38-40)
+    double zs[kChunk][RecGeom<D>::NZ][kBatch];
+};
 
 template <int POSTERIOR_RUNTIME = 0>
 __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
@@ -66,20 +115,53 @@ __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
                                                   : (kabc_isfinite(ll) && kabc_isfinite(lp));
 }
 
+// Prior classes (chosen on the host, identical results):
+//   BOX     every component is Uniform / DiscreteUniform: logpdf is the constant
+//           c0_1 + ... + c0_D (summed left to right on the host, as
+//           src/priors.jl:275-281 would) inside the box and -Inf outside
+//   SIMPLE  no per-walker transcendental (adds Normal, truncated Normal, Exponential)
+//   GENERAL everything (Beta, NegativeBinomial, Gamma, LogNormal ...)
+enum { kPriorBox = 0, kPriorSimple = 1, kPriorGeneral = 2 };
+
+struct BoxPrior {
+    const double* lo;   // LDS, [D]
+    const double* hi;   // LDS, [D]
+    uint32_t dmask;     // bit k: component k is discrete (push_p rounds)
+    double lp;          // in-support log-density
+};
+
 // loglike(density, push_p(density, y)) -- src/types.jl:133-140, :166-173
-template <int D, int COST>
-__device__ __forceinline__ void loglike(const PriorSet& P, int posterior, double eps,
-                                        const double* y, const double* cost_params,
-                                        const double* cost_data, int64_t ndata,
-                                        kabc_cost_rng_t* rng, double& lp, double& ll, bool& ev) {
+template <int D, int COST, int PC>
+__device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const BoxPrior& B,
+                                        int posterior, double eps, double reps, const double* y,
+                                        const double* cost_params, const double* cost_data,
+                                        int64_t ndata, kabc_cost_rng_t* rng, double& lp,
+                                        double& ll, bool& ev) {
     double yp[D];
-    lp = factored_logpdf_push<D>(P, y, yp);
+    if constexpr (PC == kPriorBox) {
+        double lo[D], hi[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            lo[k] = B.lo[k];
+            hi[k] = B.hi[k];
+        }
+        bool in = true;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double v = ((B.dmask >> k) & 1u) ? kabc_rint(y[k]) : y[k];
+            yp[k] = v;
+            in = in && (v >= lo[k]) && (v <= hi[k]);
+        }
+        lp = in ? B.lp : -KABC_INF;
+    } else {
+        lp = factored_logpdf_push<D, PC == kPriorSimple>(P, y, yp);
+    }
     ev = kabc_isfinite(lp);
     if (posterior == KABC_POSTERIOR_KERNELIZED) {
         ll = lp;
         if (ev) {
             const double c = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
-            const double q = c / eps;
+            const double q = kabc_div_rc(c, eps, reps);
             ll = -0.5 * (q * q);
         }
     } else {
@@ -88,162 +170,317 @@ __device__ __forceinline__ void loglike(const PriorSet& P, int posterior, double
     }
 }
 
-template <int D, int COST>
-__global__ void __launch_bounds__(kAisBlock) ais_half_kernel(const AisArgs A) {
-    const int64_t r = (int64_t)blockIdx.x * kAisBlock + threadIdx.x;
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS traffic of one wavefront completes in order; this only stops the
+    // compiler from moving LDS accesses across the point.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// PRODUCER: fill sub-step `si` (transition counter t) of a record buffer for the
+// 64 walkers of the batch.  Runs in ONE wavefront; lists are wave-private.
+template <int D>
+__device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R, int si,
+                                                uint64_t t, uint32_t w_base, int n_active,
+                                                uint16_t* listN, uint8_t* listB, int lane) {
+    constexpr int NB = RecGeom<D>::NB;
+    const uint64_t nc = (uint64_t)A.n_comp;
+    const bool active = lane < n_active;
+    int move = 0;
+    uint32_t a = 0;
+    // -- phase A: one (walker, t) per lane: move id, partner a, log u, stretch factor
+    if (active) {
+        const uint32_t w = w_base + (uint32_t)lane;
+        const kabc_u128_t B0 = kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_AIS_MOVE);
+        const kabc_u128_t B1 = kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_AIS_MOVE);
+        const uint32_t m7 = (uint32_t)(((uint64_t)B0.w[2] * 7u) >> 32);  // rand((1,1,1,1,2,2,3))
+        move = (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
+        a = (uint32_t)kabc_index(kabc_lo64(B0), nc);
+        R.logu[si][lane] = kabc_log(kabc_u01(kabc_lo64(B1)));
+        if (move == 1) {
+            // Z = cdf_g_inv(rand(rng), 3.0); correction (D-1) log Z
+            const double sq3 = kabc_sqrt(3.0), isq3 = kabc_sqrt(1.0 / 3.0);
+            const double u = kabc_u01(kabc_hi64(B1));
+            const double tz = u * (sq3 - isq3) + isq3;
+            const double Z = tz * tz;
+            R.zs[si][0][lane] = Z;
+            R.zs[si][1][lane] = (double)(D - 1) * kabc_log(Z);
+        }
+    }
+    R.mva[si][lane] = ((uint32_t)move << 30) | a;
+    R.bb[si][lane] = a;  // valid row for the consumer's unconditional prefetch
+    R.cc[si][lane] = a;
+    // -- compaction of the move-dependent extra work (wave ballot + mbcnt)
+    const unsigned long long mDE = __ballot(move == 2), mWK = __ballot(move == 3);
+    const unsigned long long mB = mDE | mWK;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int nB = __popcll(mB);
+    const int nN = NB * __popcll(mDE) + 2 * __popcll(mWK);
+    if (move >= 2) {
+        listB[__popcll(mB & below)] = (uint8_t)lane;
+        const int base = NB * __popcll(mDE & below) + 2 * __popcll(mWK & below);
+        const int cnt = (move == 2) ? NB : 2;
+        for (int j = 0; j < cnt; ++j) listN[base + j] = (uint16_t)((lane << 4) | j);
+    }
+    wave_lds_fence();
+    // -- phase B2: partner rows b (and c) for DE / walk lanes, dense
+#pragma unroll 1
+    for (int e = lane; e < nB; e += kWave) {
+        const int l = listB[e];
+        const uint32_t al = R.mva[si][l] & 0x3fffffffu;
+        const kabc_u128_t B2 =
+            kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 2u, KABC_DOM_AIS_MOVE);
+        int64_t b = (int64_t)kabc_index(kabc_lo64(B2), nc - 1u);
+        b += (b >= (int64_t)al);
+        const int64_t lo = (int64_t)al < b ? (int64_t)al : b, hi = (int64_t)al < b ? b : (int64_t)al;
+        int64_t c = (int64_t)kabc_index(kabc_hi64(B2), nc - 2u);
+        c += (c >= lo);
+        c += (c >= hi);
+        R.bb[si][l] = (uint32_t)b;
+        R.cc[si][l] = (uint32_t)c;
+    }
+    wave_lds_fence();
+    // walk lanes start fetching their three partner rows now; the loads fly
+    // under the Box-Muller phase
+    double wa[D], wb[D], wc[D];
+    if (move == 3) {
+        load_row<D>(A.x_comp + (int64_t)a * D, wa);
+        load_row<D>(A.x_comp + (int64_t)R.bb[si][lane] * D, wb);
+        load_row<D>(A.x_comp + (int64_t)R.cc[si][lane] * D, wc);
+    }
+    // -- phase N: Box-Muller blocks, dense
+#pragma unroll 1
+    for (int e = lane; e < nN; e += kWave) {
+        const int ent = listN[e];
+        const int l = ent >> 4, j = ent & 15;
+        const kabc_u128_t Bn = kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 3u + (uint32_t)j,
+                                                 KABC_DOM_AIS_MOVE);
+        double z0, z1;
+        kabc_normal_pair(kabc_lo64(Bn), kabc_hi64(Bn), &z0, &z1);
+        const int lim = ((R.mva[si][l] >> 30) == 2u) ? D : 2;  // last variate index used
+        if (2 * j <= lim) R.zs[si][2 * j][l] = z0;
+        if (2 * j + 1 <= lim) R.zs[si][2 * j + 1][l] = z1;
+    }
+    wave_lds_fence();
+    // -- phase C: gamma = 2.38/sqrt(2D) * exp(0.1 randn)   (src/transition.jl:3)
+    if (move == 2) {
+        const double z0 = R.zs[si][0][lane];
+        R.zs[si][0][lane] = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp(z0 * 0.1);
+    } else if (move == 3) {
+        // ais_walk_propose (src/transition.jl:24-43): Xs = (a + (b + c)) / 3,
+        // W = z1 (a - Xs) + z2 (b - Xs) + z3 (c - Xs); the consumer adds x_i.
+        const double z0 = R.zs[si][0][lane], z1 = R.zs[si][1][lane], z2 = R.zs[si][2][lane];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const double Xs = kabc_div_rc(wa[k] + (wb[k] + wc[k]), 3.0, 1.0 / 3.0);
+            R.zs[si][k][lane] = z0 * (wa[k] - Xs) + z1 * (wb[k] - Xs) + z2 * (wc[k] - Xs);
+        }
+    }
+}
+
+template <int D, int COST, int PC>
+__global__ void __launch_bounds__(kAisBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
+ais_half_kernel(const AisArgs A) {
+    __shared__ ChunkRec<D> rec[2];
+    __shared__ uint16_t listN[kChunk][kBatch * RecGeom<D>::NB];
+    __shared__ uint8_t listB[kChunk][kBatch];
+    // prepared prior components: read by the consumer with wave-uniform LDS
+    // addresses (broadcast).  By-value kernel arguments made hipcc pin ~250 SGPRs
+    // and spill them to VGPR lanes (385 v_readlane per transition).
+    __shared__ PriorDev sprior[D];
+    __shared__ double sbox_lo[D], sbox_hi[D];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    const int64_t r0 = (int64_t)blockIdx.x * kBatch;
+    const int64_t rem = A.rows_owned - r0;
+    const int n_active = rem >= kBatch ? kBatch : (int)rem;
+    const uint32_t w_base = A.id_base + (uint32_t)(A.row_first + r0);
+    const int nchunks = (A.nt + kChunk - 1) / kChunk;
+
+    // consumer state (wave 0)
+    const bool active = (wave == 0) && (lane < n_active);
+    const int64_t r = r0 + lane;
+    const int64_t row = A.row_first + r;
+    double x[D];
+    double lp = 0.0, ll = 0.0;
     unsigned long long n_eval = 0, n_acc = 0;
     int err = 0;
-    const bool active = r < A.rows_owned;
     if (active) {
-        const int64_t row = A.row_first + r;
-        const uint32_t w = A.id_base + (uint32_t)row;
-        double x[D];
         load_row<D>(A.x_act + row * D, x);
-        double lp = A.lp[r], ll = A.ll[r];
-        const uint64_t nc = (uint64_t)A.n_comp;
-        const double sq3 = kabc_sqrt(3.0), isq3 = kabc_sqrt(1.0 / 3.0);
+        lp = A.lp[r];
+        ll = A.ll[r];
+    }
 
-        for (int s = 0; s < A.nt; ++s) {
-            const uint64_t t = A.t0 + (uint64_t)s;
-            const kabc_u128_t B0 = kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_AIS_MOVE);
-            const kabc_u128_t B1 = kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_AIS_MOVE);
-            // p = rand(rng, (1,1,1,1,2,2,3))
-            const uint32_t m7 = (uint32_t)(((uint64_t)B0.w[2] * 7u) >> 32);
-            const int move = (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
-            const int64_t a = (int64_t)kabc_index(kabc_lo64(B0), nc);
-            int64_t b = -1, c = -1;
-            double xa[D];
-            load_row<D>(A.x_comp + a * D, xa);
-            double y[D];
-            double corr = 0.0;
-            if (move == 1) {
-                // stretch_propose, Z = cdf_g_inv(rand(rng), 3.0)
-                const double u = kabc_u01(kabc_hi64(B1));
-                const double tz = u * (sq3 - isq3) + isq3;
-                const double Z = tz * tz;
+    if (threadIdx.x < D * (int)(sizeof(PriorDev) / 8))
+        reinterpret_cast<double*>(sprior)[threadIdx.x] =
+            reinterpret_cast<const double*>(A.prior)[threadIdx.x];
+    if (threadIdx.x < D) {
+        sbox_lo[threadIdx.x] = A.prior[threadIdx.x].p[0];
+        sbox_hi[threadIdx.x] = A.prior[threadIdx.x].p[1];
+    }
+    uint32_t dmask = 0;
+    for (int k = 0; k < D; ++k) dmask |= (A.prior[k].discrete ? 1u : 0u) << k;
+    const BoxPrior box = {sbox_lo, sbox_hi, dmask, A.box_lp};
+
+    // prologue: producers fill chunk 0
+    if (wave > 0) {
+        const int si = wave - 1;
+        if (si < A.nt && !(A.ablate & 4))
+            produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listN[si],
+                               listB[si], lane);
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    for (int c = 0; c < nchunks; ++c) {
+        const int s0 = c * kChunk;
+        if (wave > 0) {
+            // PRODUCER: sub-step (s0 + kChunk + wave - 1) of the next chunk
+            const int si = wave - 1;
+            const int s = s0 + kChunk + si;
+            if (s < A.nt && !(A.ablate & 2))
+                produce_substep<D>(A, rec[(c + 1) & 1], si, A.t0 + (uint64_t)s, w_base, n_active,
+                                   listN[si], listB[si], lane);
+        } else if (active && !(A.ablate & 1)) {
+            // CONSUMER
+            const ChunkRec<D>& R = rec[(A.ablate & 2) ? 0 : (c & 1)];
+            const int ns = (A.nt - s0 < kChunk) ? (A.nt - s0) : kChunk;
+            // partner rows: pa/pb serve this sub-step, na/nb are the next one's, in
+            // flight while this one computes.  Both rows are fetched for every lane
+            // whatever its move (bb defaults to a): no divergence around the loads.
+            double pa[D], pb[D], na[D], nb[D];
+            load_row<D>(A.x_comp + (int64_t)(R.mva[0][lane] & 0x3fffffffu) * D, pa);
+            load_row<D>(A.x_comp + (int64_t)R.bb[0][lane] * D, pb);
+#pragma unroll 1
+            for (int si = 0; si < ns && !err; ++si) {
+                const uint64_t t = A.t0 + (uint64_t)(s0 + si);
+                // (1) every LDS word of this sub-step in one batch, plus the partner
+                //     ids of the next one
+                const int sn = (si + 1 < ns) ? si + 1 : si;
+                const uint32_t mva = R.mva[si][lane];
+                const uint32_t mvan = R.mva[sn][lane], bn = R.bb[sn][lane];
+                const double logu = R.logu[si][lane];
+                double zs[D + 1];
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const double W = (x[k] - xa[k]) * Z;
-                    y[k] = xa[k] + W;
-                }
-                corr = (double)(D - 1) * kabc_log(Z);
-            } else {
-                const kabc_u128_t B2 = kabc_stream_block(A.seed, w, t, 2u, KABC_DOM_AIS_MOVE);
-                b = (int64_t)kabc_index(kabc_lo64(B2), nc - 1u);
-                b += (b >= a);
-                double xb[D];
-                load_row<D>(A.x_comp + b * D, xb);
-                if (move == 2) {
-                    // de_propose
-                    double z[D + 2];
-#pragma unroll
-                    for (int j = 0; j < (D + 2) / 2; ++j) {
-                        const kabc_u128_t Bn =
-                            kabc_stream_block(A.seed, w, t, 3u + (uint32_t)j, KABC_DOM_AIS_MOVE);
-                        kabc_normal_pair(kabc_lo64(Bn), kabc_hi64(Bn), &z[2 * j], &z[2 * j + 1]);
-                    }
-                    const double gamma =
-                        2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp(z[0] * 0.1);
+                for (int j = 0; j < D + 1; ++j) zs[j] = R.zs[si][j][lane];
+                // (2) prefetch
+                load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
+                load_row<D>(A.x_comp + (int64_t)bn * D, nb);
+                // scheduling fences: without them hipcc interleaves the phases of a
+                // sub-step for ILP and needs > 300 VGPRs (spills, 1 wave per SIMD)
+                __builtin_amdgcn_sched_barrier(0);
+                const uint32_t move = mva >> 30;
+                double y[D];
+                double corr = 0.0;
+                if (move == 1u) {
+                    // stretch_propose  src/transition.jl:51-59
+                    const double Z = zs[0];
+                    corr = zs[1];
 #pragma unroll
                     for (int k = 0; k < D; ++k) {
-                        const double Wk = (xa[k] - xb[k]) * gamma;
-                        const double sk = kabc_fabs(xa[k] - xb[k]) + kabc_fabs(x[k] - xb[k]) +
-                                          kabc_fabs(xa[k] - x[k]);
-                        const double Tk = gamma * sk / 300.0 * z[1 + k];
+                        const double W = (x[k] - pa[k]) * Z;
+                        y[k] = pa[k] + W;
+                    }
+                } else if (move == 2u) {
+                    // de_propose  src/transition.jl:2-22
+                    const double gamma = zs[0];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        const double Wk = (pa[k] - pb[k]) * gamma;
+                        const double sk = kabc_fabs(pa[k] - pb[k]) + kabc_fabs(x[k] - pb[k]) +
+                                          kabc_fabs(pa[k] - x[k]);
+                        const double Tk = kabc_div_rc(gamma * sk, 300.0, 1.0 / 300.0) * zs[1 + k];
                         y[k] = x[k] + Wk + Tk;
                     }
                 } else {
-                    // ais_walk_propose
-                    const int64_t lo = a < b ? a : b, hi = a < b ? b : a;
-                    c = (int64_t)kabc_index(kabc_hi64(B2), nc - 2u);
-                    c += (c >= lo);
-                    c += (c >= hi);
-                    double xc[D];
-                    load_row<D>(A.x_comp + c * D, xc);
-                    double z[4];
+                    // ais_walk_propose  src/transition.jl:24-43
+                    // W does not depend on x_i: the producer has already formed it
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const kabc_u128_t Bn =
-                            kabc_stream_block(A.seed, w, t, 3u + (uint32_t)j, KABC_DOM_AIS_MOVE);
-                        kabc_normal_pair(kabc_lo64(Bn), kabc_hi64(Bn), &z[2 * j], &z[2 * j + 1]);
-                    }
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double Xs = (xa[k] + (xb[k] + xc[k])) / 3.0;
-                        const double Wk =
-                            z[0] * (xa[k] - Xs) + z[1] * (xb[k] - Xs) + z[2] * (xc[k] - Xs);
-                        y[k] = x[k] + Wk;
+                    for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ld = loglike(density, push_p(density, p))   src/transition.jl:75
+                kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u};
+                double nlp, nll;
+                bool ev;
+                loglike<D, COST, PC>(sprior, box, A.posterior, A.eps, A.reps, y, A.cost_params,
+                                     A.cost_data, A.cost_ndata, &rng, nlp, nll, ev);
+                __builtin_amdgcn_sched_barrier(0);
+                n_eval += ev ? 1u : 0u;
+                // accept(...)  src/types.jl:144-157, :178-186
+                bool acc = false;
+                if (!kabc_isfinite(corr)) err = 1;
+                else if (!ld_valid(A.posterior, lp, ll)) err = 2;
+                else if (ld_valid(A.posterior, nlp, nll)) {
+                    const double e = -logu;  // randexp(rng)
+                    if (A.posterior == KABC_POSTERIOR_KERNELIZED) {
+                        const double lW = corr + (nlp + nll) - (lp + ll);
+                        acc = (-e <= lW);
+                    } else {
+                        const double lW = corr + nlp - lp;
+                        const double mx = (A.eps > ll) ? A.eps : ll;
+                        const double lW2 = mx - nll;
+                        acc = (-e <= lW) && (lW2 >= 0.0);
                     }
                 }
-            }
-            // ld = loglike(density, push_p(density, p))
-            kabc_cost_rng_t rng = {A.seed, t, w, KABC_DOM_AIS_COST, 0u};
-            double nlp, nll;
-            bool ev;
-            loglike<D, COST>(A.prior, A.posterior, A.eps, y, A.cost_params, A.cost_data,
-                             A.cost_ndata, &rng, nlp, nll, ev);
-            n_eval += ev ? 1u : 0u;
-            // accept(...)
-            bool acc = false;
-            if (!kabc_isfinite(corr)) err = 1;
-            else if (!ld_valid(A.posterior, lp, ll)) err = 2;
-            else if (ld_valid(A.posterior, nlp, nll)) {
-                const double e = -kabc_log(kabc_u01(kabc_lo64(B1)));  // randexp(rng)
-                if (A.posterior == KABC_POSTERIOR_KERNELIZED) {
-                    const double lW = corr + (nlp + nll) - (lp + ll);
-                    acc = (-e <= lW);
-                } else {
-                    const double lW = corr + nlp - lp;
-                    const double mx = (A.eps > ll) ? A.eps : ll;
-                    const double lW2 = mx - nll;
-                    acc = (-e <= lW) && (lW2 >= 0.0);
+                if (acc) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) x[k] = y[k];
+                    lp = nlp;
+                    ll = nll;
+                    n_acc += 1u;
+                }
+                if (A.dbg) {
+                    int32_t* d = A.dbg + (r * A.nt + (s0 + si)) * 6;
+                    d[0] = (int32_t)move;
+                    d[1] = acc ? 1 : 0;
+                    d[2] = (int32_t)(mva & 0x3fffffffu);
+                    d[3] = move >= 2u ? (int32_t)R.bb[si][lane] : -1;
+                    d[4] = move == 3u ? (int32_t)R.cc[si][lane] : -1;
+                    d[5] = ev ? 1 : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    pa[k] = na[k];
+                    pb[k] = nb[k];
                 }
             }
-            if (acc) {
-#pragma unroll
-                for (int k = 0; k < D; ++k) x[k] = y[k];
-                lp = nlp;
-                ll = nll;
-                n_acc += 1u;
-            }
-            if (A.dbg) {
-                int32_t* d = A.dbg + (r * A.nt + s) * 6;
-                d[0] = move;
-                d[1] = acc ? 1 : 0;
-                d[2] = (int32_t)a;
-                d[3] = (int32_t)b;
-                d[4] = (int32_t)c;
-                d[5] = ev ? 1 : 0;
-            }
-            if (err) break;
         }
-        store_row<D>(A.x_act + row * D, x);
-        A.lp[r] = lp;
-        A.ll[r] = ll;
-        if (A.trace) {
-            double xp[D];
+        __syncthreads();
+    }
+
+    if (wave == 0) {
+        if (active) {
+            store_row<D>(A.x_act + row * D, x);
+            A.lp[r] = lp;
+            A.ll[r] = ll;
+            if (A.trace) {
+                double xp[D];
 #pragma unroll
-            for (int k = 0; k < D; ++k) xp[k] = A.prior.c[k].discrete ? kabc_rint(x[k]) : x[k];
-            store_row<D>(A.trace + r * D, xp);
+                for (int k = 0; k < D; ++k)
+                    xp[k] = sprior[k].discrete ? kabc_rint(x[k]) : x[k];
+                store_row<D>(A.trace + r * D, xp);
+            }
         }
+        // one atomic per batch and counter
+        const unsigned long long se = wave_sum(n_eval);
+        const unsigned long long sa = wave_sum(n_acc);
+        if (lane == 0) {
+            unsigned long long* sl = A.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 8;
+            atomicAdd(&sl[0], (unsigned long long)n_active * (unsigned long long)A.nt);
+            atomicAdd(&sl[1], se);
+            atomicAdd(&sl[2], sa);
+        }
+        if (err) atomicMax(&A.counters->error, err);
     }
-    // one atomic per wave and counter
-    const unsigned long long se = wave_sum(n_eval);
-    const unsigned long long sa = wave_sum(n_acc);
-    const unsigned long long sp = wave_sum(active ? (unsigned long long)A.nt : 0ull);
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        atomicAdd(&A.counters->proposals, sp);
-        atomicAdd(&A.counters->cost_evals, se);
-        atomicAdd(&A.counters->accepted, sa);
-    }
-    if (err) atomicMax(&A.counters->error, err);
 }
 
 // step(rng, model, spl::AIS; retry_sampling): one thread per owned walker; the
 // retry budget is global (src/KissABC.jl:52-60), kept in a device counter.
 template <int D>
-__global__ void __launch_bounds__(kAisBlock) ais_init_kernel(const InitArgs A) {
-    const int64_t r = (int64_t)blockIdx.x * kAisBlock + threadIdx.x;
+__global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) {
+    const int64_t r = (int64_t)blockIdx.x * kInitBlock + threadIdx.x;
     if (r >= A.rows_owned) return;
     const int64_t row = A.row_first + r;
     const uint32_t w = A.id_base + (uint32_t)row;
@@ -263,7 +500,7 @@ __global__ void __launch_bounds__(kAisBlock) ais_init_kernel(const InitArgs A) {
             if (kabc_isfinite(lp)) {
                 const double c = kabc_cost_eval(A.cost_id, xp, D, A.cost_params, A.cost_data,
                                                 A.cost_ndata, &rng);
-                const double q = c / A.eps;
+                const double q = kabc_div_rc(c, A.eps, 1.0 / A.eps);
                 ll = -0.5 * (q * q);
             }
         } else {
@@ -287,7 +524,7 @@ __global__ void __launch_bounds__(kAisBlock) ais_init_kernel(const InitArgs A) {
 
 // launchers (defined by the instantiation units)
 using AisLaunchFn = void (*)(const AisArgs&, hipStream_t);
-AisLaunchFn find_ais_kernel(int cost_id, int D);
+AisLaunchFn find_ais_kernel(int cost_id, int D, int prior_class);
 void launch_ais_init(int D, const InitArgs& a, hipStream_t s);
 
 }  // namespace kabc

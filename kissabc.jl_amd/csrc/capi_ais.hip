@@ -1,6 +1,7 @@
 // capi_ais.hip -- the AIS entry points of the C ABI (include/kabc.h):
 // AIS(N) + AISState + step(init) + step(advance) of src/KissABC.jl:21-80,
 // executed by the gfx950 kernels in ais_kernels.hpp.
+#include <cstdlib>
 #include <vector>
 
 #include "ais_kernels.hpp"
@@ -8,7 +9,7 @@
 
 namespace kabc {
 
-#define KABC_DECL_COST(id) AisLaunchFn find_ais_kernel_cost_##id(int D);
+#define KABC_DECL_COST(id) AisLaunchFn find_ais_kernel_cost_##id(int D, int pc);
 KABC_DECL_COST(1)
 KABC_DECL_COST(2)
 KABC_DECL_COST(3)
@@ -21,28 +22,28 @@ KABC_DECL_COST(9)
 KABC_DECL_COST(10)
 KABC_DECL_COST(11)
 
-AisLaunchFn find_ais_kernel(int cost_id, int D) {
+AisLaunchFn find_ais_kernel(int cost_id, int D, int pc) {
     switch (cost_id) {
-        case 1: return find_ais_kernel_cost_1(D);
-        case 2: return find_ais_kernel_cost_2(D);
-        case 3: return find_ais_kernel_cost_3(D);
-        case 4: return find_ais_kernel_cost_4(D);
-        case 5: return find_ais_kernel_cost_5(D);
-        case 6: return find_ais_kernel_cost_6(D);
-        case 7: return find_ais_kernel_cost_7(D);
-        case 8: return find_ais_kernel_cost_8(D);
-        case 9: return find_ais_kernel_cost_9(D);
-        case 10: return find_ais_kernel_cost_10(D);
-        case 11: return find_ais_kernel_cost_11(D);
+        case 1: return find_ais_kernel_cost_1(D, pc);
+        case 2: return find_ais_kernel_cost_2(D, pc);
+        case 3: return find_ais_kernel_cost_3(D, pc);
+        case 4: return find_ais_kernel_cost_4(D, pc);
+        case 5: return find_ais_kernel_cost_5(D, pc);
+        case 6: return find_ais_kernel_cost_6(D, pc);
+        case 7: return find_ais_kernel_cost_7(D, pc);
+        case 8: return find_ais_kernel_cost_8(D, pc);
+        case 9: return find_ais_kernel_cost_9(D, pc);
+        case 10: return find_ais_kernel_cost_10(D, pc);
+        case 11: return find_ais_kernel_cost_11(D, pc);
         default: return nullptr;
     }
 }
 
 template <int D>
 static void launch_init_d(const InitArgs& a, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.rows_owned + kAisBlock - 1) / kAisBlock);
+    const unsigned grid = (unsigned)((a.rows_owned + kInitBlock - 1) / kInitBlock);
     if (grid == 0) return;
-    hipLaunchKernelGGL((ais_init_kernel<D>), dim3(grid), dim3(kAisBlock), 0, s, a);
+    hipLaunchKernelGGL((ais_init_kernel<D>), dim3(grid), dim3(kInitBlock), 0, s, a);
 }
 
 template <int... Ds>
@@ -80,9 +81,12 @@ struct kabc_ais {
     double* d_lp[2];
     double* d_ll[2];
     DevCounters* d_counters;
+    unsigned long long* d_slots;  // [kCounterSlots][8]
+    PriorDev* d_prior;            // [KABC_MAX_DIM] prepared components
     uint64_t seed, t;
     int32_t rank, world;
     AisLaunchFn launch;
+    double box_lp;
     bool initialised;
     // trace staging
     double* d_trace;
@@ -140,7 +144,14 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         set_error("DeviceCost id %d does not accept D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
     }
-    AisLaunchFn fn = find_ais_kernel(m->cost.id, m->D);
+    bool simple = true, isbox = true;
+    for (int k = 0; k < m->D; ++k) {
+        simple = simple && prior_is_simple(m->prior[k].kind);
+        isbox = isbox && (m->prior[k].kind == KABC_PRIOR_UNIFORM ||
+                          m->prior[k].kind == KABC_PRIOR_DISCRETE_UNIFORM);
+    }
+    const int pc = isbox ? kPriorBox : simple ? kPriorSimple : kPriorGeneral;
+    AisLaunchFn fn = find_ais_kernel(m->cost.id, m->D, pc);
     if (!fn) {
         set_error("no gfx950 kernel instantiated for cost id %d, D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
@@ -159,6 +170,10 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         return KABC_ERR_INVALID_ARG;
     }
     h->launch = fn;
+    // BOX class: logpdf inside the box = c0_1 + ... + c0_D, summed left to right
+    // exactly as logpdf(d::Factored, x) does (src/priors.jl:275-281)
+    h->box_lp = h->prior.c[0].c0;
+    for (int k = 1; k < h->D; ++k) h->box_lp += h->prior.c[k].c0;
     h->N = n_total;
     h->rows[0] = (n_total + 1) / 2;
     h->rows[1] = n_total / 2;
@@ -215,15 +230,28 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     }
     KABC_HIP_CHECK(hipMalloc(&h->d_counters, sizeof(DevCounters)));
     KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
+    KABC_HIP_CHECK(hipMalloc(&h->d_prior, sizeof(PriorSet)));
+    KABC_HIP_CHECK(hipMemcpyAsync(h->d_prior, &h->prior, sizeof(PriorSet), hipMemcpyHostToDevice, s));
+    KABC_HIP_CHECK(hipMalloc(&h->d_slots, sizeof(unsigned long long) * kCounterSlots * 8));
+    KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
     KABC_HIP_CHECK(hipStreamSynchronize(s));
     *out = h;
     return KABC_OK;
 }
 
 static kabc_status_t read_counters(kabc_ais_t* h, DevCounters* c) {
+    static thread_local std::vector<unsigned long long> slots(kCounterSlots * 8);
     KABC_HIP_CHECK(hipMemcpyAsync(c, h->d_counters, sizeof(DevCounters), hipMemcpyDeviceToHost,
                                   h->ctx->stream));
+    KABC_HIP_CHECK(hipMemcpyAsync(slots.data(), h->d_slots,
+                                  sizeof(unsigned long long) * kCounterSlots * 8,
+                                  hipMemcpyDeviceToHost, h->ctx->stream));
     KABC_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+    for (int i = 0; i < kCounterSlots; ++i) {
+        c->proposals += slots[i * 8 + 0];
+        c->cost_evals += slots[i * 8 + 1];
+        c->accepted += slots[i * 8 + 2];
+    }
     return KABC_OK;
 }
 
@@ -266,6 +294,7 @@ kabc_status_t kabc_ais_init(kabc_ais_t* h, int32_t retry_sampling) {
     KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
     KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
+    KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
     for (int hf = 0; hf < 2; ++hf) {
         InitArgs a;
         std::memset(&a, 0, sizeof a);
@@ -330,6 +359,7 @@ kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntra
             a.dbg = h->d_dbg + off;
     }
     a.counters = h->d_counters;
+    a.slots = h->d_slots;
     a.cost_params = h->d_cost_params;
     a.cost_data = h->d_cost_data;
     a.cost_ndata = h->cost_ndata;
@@ -342,7 +372,13 @@ kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntra
     a.nt = ntransitions;
     a.posterior = h->posterior;
     a.eps = h->eps;
-    a.prior = h->prior;
+    a.reps = 1.0 / h->eps;
+    a.box_lp = h->box_lp;
+    a.prior = h->d_prior;
+    {
+        static const char* ab = getenv("KABC_ABLATE");
+        a.ablate = ab ? atoi(ab) : 0;
+    }
     hipStream_t s = h->ctx->stream;
     const bool timed = h->timing && (h->ev_used + 2 <= h->ev.size());
     if (timed) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
@@ -570,6 +606,8 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h) {
     if (h->d_cost_params) (void)hipFree(h->d_cost_params);
     if (h->d_cost_data) (void)hipFree(h->d_cost_data);
     if (h->d_counters) (void)hipFree(h->d_counters);
+    if (h->d_slots) (void)hipFree(h->d_slots);
+    if (h->d_prior) (void)hipFree(h->d_prior);
     if (h->d_trace) (void)hipFree(h->d_trace);
     if (h->d_dbg) (void)hipFree(h->d_dbg);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);

@@ -23,6 +23,7 @@ bool prepare_prior(const kabc_prior_t& pr, PriorDev& q) {
     for (int j = 0; j < 4; ++j) q.p[j] = pr.p[j];
     q.c0 = q.c1 = 0.0;
     const double a = pr.p[0], b = pr.p[1];
+    q.rb = 1.0 / ((pr.kind == KABC_PRIOR_EXPONENTIAL) ? a : b);
     switch (pr.kind) {
         case KABC_PRIOR_UNIFORM:
             if (!(b > a)) return false;

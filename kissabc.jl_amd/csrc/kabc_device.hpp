@@ -29,6 +29,7 @@ struct PriorDev {
     int32_t discrete;
     double p[4];
     double c0, c1;
+    double rb;  // RN(1/p[1]) (1/p[0] for Exponential), for kabc_div_rc
 };
 
 struct PriorSet {
@@ -37,61 +38,107 @@ struct PriorSet {
 
 // Distributions.logpdf(p_k, x) on the device.  Same formulas, same operation
 // order as the host-side definition pinned by tests/golden/priors_logpdf.json.
-__device__ __forceinline__ double comp_logpdf(const PriorDev& q, double x) {
-    const double a = q.p[0], b = q.p[1];
+// Two code shapes with identical results:
+//   comp_logpdf_simple : the families whose logpdf needs no transcendental per
+//       walker (Uniform, Normal, truncated Normal, DiscreteUniform, Exponential);
+//       inlined into the hot loop.
+//   comp_logpdf_general: every family; kept out of line so that D copies of
+//       log/log1p/lgamma do not bloat the kernel past the instruction cache.
+__device__ __forceinline__ double comp_logpdf_simple(const PriorDev& q, double x) {
+    const double a = q.p[0], b = q.p[1], rb = q.rb;
     switch (q.kind) {
         case KABC_PRIOR_UNIFORM: return (x >= a && x <= b) ? q.c0 : -KABC_INF;
         case KABC_PRIOR_NORMAL: {
-            const double z = (x - a) / b;
+            const double z = kabc_div_rc(x - a, b, rb);
             return -(z * z + KABC_LOG_2PI) / 2.0 - q.c0;
         }
         case KABC_PRIOR_TRUNCNORMAL: {
             if (!(x >= q.p[2] && x <= q.p[3])) return -KABC_INF;
-            const double z = (x - a) / b;
+            const double z = kabc_div_rc(x - a, b, rb);
             return -(z * z + KABC_LOG_2PI) / 2.0 - q.c0 - q.c1;
+        }
+        case KABC_PRIOR_DISCRETE_UNIFORM:
+            return (x >= a && x <= b && x == kabc_rint(x)) ? q.c0 : -KABC_INF;
+        case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -q.c0 - kabc_div_rc(x, a, rb) : -KABC_INF;
+        default: return KABC_NAN;
+    }
+}
+
+static __device__ __noinline__ double comp_logpdf_general(int kind, double a, double b, double p2,
+                                                          double p3, double c0, double c1, double rb,
+                                                          double x) {
+    switch (kind) {
+        case KABC_PRIOR_UNIFORM: return (x >= a && x <= b) ? c0 : -KABC_INF;
+        case KABC_PRIOR_NORMAL: {
+            const double z = kabc_div_rc(x - a, b, rb);
+            return -(z * z + KABC_LOG_2PI) / 2.0 - c0;
+        }
+        case KABC_PRIOR_TRUNCNORMAL: {
+            if (!(x >= p2 && x <= p3)) return -KABC_INF;
+            const double z = kabc_div_rc(x - a, b, rb);
+            return -(z * z + KABC_LOG_2PI) / 2.0 - c0 - c1;
         }
         case KABC_PRIOR_BETA: {
             if (!(x >= 0.0 && x <= 1.0)) return -KABC_INF;
             const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log(x);
             const double t2 = (b == 1.0) ? 0.0 : (b - 1.0) * kabc_log1p(-x);
-            return t1 + t2 - q.c0;
+            return t1 + t2 - c0;
         }
         case KABC_PRIOR_DISCRETE_UNIFORM:
-            return (x >= a && x <= b && x == kabc_rint(x)) ? q.c0 : -KABC_INF;
+            return (x >= a && x <= b && x == kabc_rint(x)) ? c0 : -KABC_INF;
         case KABC_PRIOR_NEGBINOMIAL: {
             if (!(x >= 0.0) || x != kabc_rint(x)) return -KABC_INF;
-            return q.c0 + x * q.c1 + kabc_lgamma(x + a) - kabc_lgamma(x + 1.0);
+            return c0 + x * c1 + kabc_lgamma(x + a) - kabc_lgamma(x + 1.0);
         }
-        case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -q.c0 - x / a : -KABC_INF;
+        case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -c0 - kabc_div_rc(x, a, rb) : -KABC_INF;
         case KABC_PRIOR_GAMMA: {
             if (!(x >= 0.0)) return -KABC_INF;
             const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log(x);
-            return t1 - x / b - q.c0;
+            return t1 - kabc_div_rc(x, b, rb) - c0;
         }
         case KABC_PRIOR_LOGNORMAL: {
             if (!(x > 0.0)) return -KABC_INF;
             const double lx = kabc_log(x);
-            const double z = (lx - a) / b;
-            return -(z * z + KABC_LOG_2PI) / 2.0 - q.c0 - lx;
+            const double z = kabc_div_rc(lx - a, b, rb);
+            return -(z * z + KABC_LOG_2PI) / 2.0 - c0 - lx;
         }
         default: return KABC_NAN;
     }
 }
 
+__device__ __forceinline__ double comp_logpdf(const PriorDev& q, double x) {
+    return comp_logpdf_general(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
+}
+
+// host-side classification used to pick the kernel variant
+inline bool prior_is_simple(int kind) {
+    return kind == KABC_PRIOR_UNIFORM || kind == KABC_PRIOR_NORMAL ||
+           kind == KABC_PRIOR_TRUNCNORMAL || kind == KABC_PRIOR_DISCRETE_UNIFORM ||
+           kind == KABC_PRIOR_EXPONENTIAL;
+}
+
 // push_p (src/types.jl:109-114) followed by logpdf(d::Factored, x) = left-to-right
 // sum over components (src/priors.jl:275-281).  xp receives push_p(x).
-template <int D>
-__device__ __forceinline__ double factored_logpdf_push(const PriorSet& P, const double* x,
-                                                       double* xp) {
+// P: the prepared components (in LDS on the hot path).
+template <int D, bool SIMPLE = false>
+__device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restrict__ P,
+                                                       const double* x, double* xp) {
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        const double v = P.c[k].discrete ? kabc_rint(x[k]) : x[k];
+        __builtin_amdgcn_sched_barrier(0);
+        const PriorDev& q = P[k];
+        const double v = q.discrete ? kabc_rint(x[k]) : x[k];
         xp[k] = v;
-        const double l = comp_logpdf(P.c[k], v);
+        const double l = SIMPLE ? comp_logpdf_simple(q, v) : comp_logpdf(q, v);
         s = (k == 0) ? l : s + l;
     }
     return s;
+}
+template <int D, bool SIMPLE = false>
+__device__ __forceinline__ double factored_logpdf_push(const PriorSet& P, const double* x,
+                                                       double* xp) {
+    return factored_logpdf_push<D, SIMPLE>(P.c, x, xp);
 }
 
 // compile-time cost dispatch on the DeviceCost id (formulas: include/kabc_costs.h)

@@ -100,6 +100,7 @@ typedef struct prep {
     int32_t discrete;
     double p[4];
     double c0, c1;
+    double rb; /* RN(1 / p[1]) (or 1/p[0] for Exponential) for kabc_div_rc */
 } prep_t;
 
 static double std_normal_cdf(double z) { return 0.5 * erfc(-z * M_SQRT1_2); }
@@ -112,6 +113,7 @@ static int prepare_prior(const kabc_prior_t* pr, prep_t* q) {
     memcpy(q->p, pr->p, sizeof q->p);
     q->c0 = q->c1 = 0.0;
     const double a = pr->p[0], b = pr->p[1];
+    q->rb = 1.0 / ((pr->kind == KABC_PRIOR_EXPONENTIAL) ? a : b);
     switch (pr->kind) {
         case KABC_PRIOR_UNIFORM:
             if (!(b > a)) return 0;
@@ -163,12 +165,12 @@ static double comp_logpdf(const prep_t* q, double x) {
     switch (q->kind) {
         case KABC_PRIOR_UNIFORM: return (x >= a && x <= b) ? q->c0 : -KABC_INF;
         case KABC_PRIOR_NORMAL: {
-            double z = (x - a) / b;
+            double z = kabc_div_rc(x - a, b, q->rb);
             return -(z * z + KABC_LOG_2PI) / 2.0 - q->c0;
         }
         case KABC_PRIOR_TRUNCNORMAL: {
             if (!(x >= q->p[2] && x <= q->p[3])) return -KABC_INF;
-            double z = (x - a) / b;
+            double z = kabc_div_rc(x - a, b, q->rb);
             return -(z * z + KABC_LOG_2PI) / 2.0 - q->c0 - q->c1;
         }
         case KABC_PRIOR_BETA: {
@@ -183,16 +185,16 @@ static double comp_logpdf(const prep_t* q, double x) {
             if (!(x >= 0.0) || x != kabc_rint(x)) return -KABC_INF;
             return q->c0 + x * q->c1 + kabc_lgamma(x + a) - kabc_lgamma(x + 1.0);
         }
-        case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -q->c0 - x / a : -KABC_INF;
+        case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -q->c0 - kabc_div_rc(x, a, q->rb) : -KABC_INF;
         case KABC_PRIOR_GAMMA: {
             if (!(x >= 0.0)) return -KABC_INF;
             double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log(x);
-            return t1 - x / b - q->c0;
+            return t1 - kabc_div_rc(x, b, q->rb) - q->c0;
         }
         case KABC_PRIOR_LOGNORMAL: {
             if (!(x > 0.0)) return -KABC_INF;
             double lx = kabc_log(x);
-            double z = (lx - a) / b;
+            double z = kabc_div_rc(lx - a, b, q->rb);
             return -(z * z + KABC_LOG_2PI) / 2.0 - q->c0 - lx;
         }
         default: return KABC_NAN;
@@ -313,7 +315,7 @@ static ld_t loglike(orc_ais_t* h, const double* xp, uint32_t walker, uint64_t t,
         r.ll = r.lp;
         if (kabc_isfinite(r.lp)) {
             double c = orc_cost_eval(&h->cost, h->D, xp, h->seed, walker, t, dom);
-            double q = c / h->eps;
+            double q = kabc_div_rc(c, h->eps, 1.0 / h->eps);
             r.ll = -0.5 * (q * q); /* -0.5 * abs2(cost/scale) */
             *cost_evaluated = 1;
         }
@@ -487,7 +489,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
             double Wk = (xa[k] - xb[k]) * gamma;
             double s = kabc_fabs(xa[k] - xb[k]) + kabc_fabs(xi[k] - xb[k]) +
                        kabc_fabs(xa[k] - xi[k]);
-            double Tk = gamma * s / 300.0 * z[1 + k];
+            double Tk = kabc_div_rc(gamma * s, 300.0, 1.0 / 300.0) * z[1 + k];
             y[k] = xi[k] + Wk + Tk; /* op(+, p[i], W, T) = foldl */
         }
         corr = 0.0;
@@ -505,7 +507,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
             kabc_normal_pair(Bn.lo, Bn.hi, &z[2 * j], &z[2 * j + 1]);
         }
         for (int k = 0; k < D; ++k) {
-            double Xs = (xa[k] + (xb[k] + xc[k])) / 3.0;
+            double Xs = kabc_div_rc(xa[k] + (xb[k] + xc[k]), 3.0, 1.0 / 3.0);
             double Wk = z[0] * (xa[k] - Xs) + z[1] * (xb[k] - Xs) + z[2] * (xc[k] - Xs);
             y[k] = xi[k] + Wk;
         }
