@@ -87,6 +87,9 @@ void orc_math_vec(int32_t fn, int64_t n, const double* x, double* out) {
         }
     }
 }
+void orc_div_rc_vec(int64_t n, const double* x, const double* c, double* out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = kabc_div_rc(x[i], c[i], 1.0 / c[i]);
+}
 void orc_normal_pairs(int64_t n, const uint64_t* r, double* out) {
     for (int64_t i = 0; i < n; ++i)
         kabc_normal_pair(r[2 * i], r[2 * i + 1], &out[2 * i], &out[2 * i + 1]);

@@ -51,6 +51,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 /* math-contract probes (vectorised wrappers over include/kabc_math.h) */
 void orc_math_vec(int32_t fn, int64_t n, const double* x, double* out);
 void orc_normal_pairs(int64_t n, const uint64_t* r, double* out);
+void orc_div_rc_vec(int64_t n, const double* x, const double* c, double* out);
 
 /* Factored surface: src/priors.jl:263-294, src/types.jl:109-114 */
 int32_t orc_factored_logpdf(const kabc_prior_t* prior, int32_t D, int64_t n, const double* x,

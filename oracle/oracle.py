@@ -49,6 +49,7 @@ def load():
                                          C.POINTER(C.c_uint32)]),
             "orc_math_vec": (None, [C.c_int32, C.c_int64, dp, dp]),
             "orc_normal_pairs": (None, [C.c_int64, C.POINTER(C.c_uint64), dp]),
+            "orc_div_rc_vec": (None, [C.c_int64, dp, dp, dp]),
             "orc_factored_logpdf": (C.c_int32, [C.POINTER(cd.Prior), C.c_int32, C.c_int64, dp, dp]),
             "orc_factored_pdf": (C.c_int32, [C.POINTER(cd.Prior), C.c_int32, C.c_int64, dp, dp]),
             "orc_push_p": (C.c_int32, [C.POINTER(cd.Prior), C.c_int32, C.c_int64, dp, dp]),
@@ -98,6 +99,14 @@ def math_vec(name, x):
     out = np.empty(x.size * (2 if name == "sincos2pi" else 1))
     load().orc_math_vec(MATH_FN[name], x.size, _dp(x), _dp(out))
     return out.reshape(-1, 2) if name == "sincos2pi" else out
+
+
+def div_rc(x, c):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    c = np.ascontiguousarray(np.broadcast_to(c, x.shape), dtype=np.float64)
+    out = np.empty_like(x)
+    load().orc_div_rc_vec(x.size, _dp(x), _dp(c), _dp(out))
+    return out
 
 
 def philox(ctr, key):

@@ -107,3 +107,20 @@ def test_cdf_g_inv_closed_forms(orc):
         assert orc.cdf_g_inv(1.0, a) == pytest.approx(a, rel=4e-16)
     z = np.array([orc.cdf_g_inv(u, 3.0) for u in rng.random(1000)])
     assert z.min() >= 1 / 3 - 1e-15 and z.max() <= 3 + 1e-15
+
+
+def test_div_rc_equals_ieee_division(orc):
+    """kabc_div_rc(x, c, RN(1/c)) (Markstein: 1 mul + 2 fma) must equal the correctly
+    rounded IEEE quotient x / c: the contract uses it for `/ 300`, `/ 3`
+    (src/transition.jl:13,35), `cost / scale` (src/types.jl:137) and (x - mu) / sigma."""
+    n = 4_000_000
+    x = np.ldexp(rng.random(n) + 0.5, rng.integers(-300, 300, n)) * rng.choice([-1.0, 1.0], n)
+    for c in (3.0, 300.0, 0.1, 0.005, 0.001, 1.0, 5.0, 0.2, 0.5, 0.01 / np.sqrt(2), 12.0):
+        assert np.array_equal(orc.div_rc(x, c), x / c), c
+    c = np.ldexp(rng.random(n) + 0.5, rng.integers(-100, 100, n))
+    got, ref = orc.div_rc(x, c), x / c
+    bad = np.flatnonzero(got != ref)
+    # Markstein's theorem leaves room for rare 1-ulp misses for arbitrary c; none of the
+    # constants the path divides by may miss, and random divisors must agree to <= 1 ulp
+    assert bad.size <= n * 1e-3
+    assert ulp_diff(got, ref).max() <= 1.0

@@ -1,0 +1,127 @@
+"""CPU, world_size = 2 over gloo: the multi-GPU driver's exchange logic
+(kissabc_jl_amd.sharded.ShardedAIS: row ownership, one all-gather per
+half-generation, counter stride) with the CPU oracle standing in for the
+per-rank HIP engine.  The sharded trajectory must equal the single-process
+trajectory BIT FOR BIT -- draws are keyed by global walker id."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleEngine:
+    """Test stand-in for sharded.HipEngine: same interface, CPU oracle compute."""
+    inplace_gather = False
+
+    def __init__(self, model, n_total, seed, rank, world):
+        from oracle import oracle as orc
+        self.o = orc.OracleAIS(model, n_total, seed=seed)
+        self.N, self.D = n_total, len(model)
+        n0, n1 = (n_total + 1) // 2, n_total // 2
+        self.n0 = n0
+        self.half = [torch.zeros((n0, self.D), dtype=torch.float64),
+                     torch.zeros((n1, self.D), dtype=torch.float64)]
+        self.rows = [(rank * (n0 // world), (rank + 1) * (n0 // world)),
+                     (rank * (n1 // world), (rank + 1) * (n1 // world))]
+
+    def _pull(self):     # oracle state -> the torch half buffers (own rows only matter)
+        x, self.lp, self.ll, self.t = self.o.state()
+        for h, off in ((0, 0), (1, self.n0)):
+            lo, hi = self.rows[h]
+            self.half[h][lo:hi] = torch.from_numpy(x[off + lo:off + hi])
+
+    def _push(self):     # gathered torch halves -> oracle positions
+        x = torch.cat(self.half, 0).numpy()
+        _, lp, ll, t = self.o.state()
+        self.o.set_state(x, lp, ll, t)
+
+    def init(self, retry_sampling):
+        self.o.init(retry_sampling)   # every rank draws all walkers identically
+        self._pull()
+
+    def half_generation(self, half, nt):
+        self._push()
+        lo, hi = self.rows[half]
+        self.o.half_generation(half, nt, lo, hi)
+        self._pull()
+
+    def end_generation(self, nt):
+        self.o.end_generation(nt)
+
+    def stats(self):
+        return self.o.stats()
+
+
+def _model(k):
+    U = k.Factored(*[k.Uniform(-5, 5)] * 8)
+    return k.ApproxKernelizedPosterior(U, k.costs.Rosenbrock(), 1.0)
+
+
+def _worker(rank, world, port, N, nt, gens, seed, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import kissabc_jl_amd as k
+    from kissabc_jl_amd.sharded import ShardedAIS
+    model = _model(k)
+    eng = OracleEngine(model, N, seed, rank, world)
+    sh = ShardedAIS(model, N, seed=seed, engine=eng).init()
+    sh.advance(gens, nt)
+    pos = sh.positions().numpy()
+    # log-densities live on the owner only: gather them for the comparison
+    lp = torch.zeros(N, dtype=torch.float64)
+    n0 = (N + 1) // 2
+    for h, off in ((0, 0), (1, n0)):
+        lo, hi = eng.rows[h]
+        lp[off + lo:off + hi] = torch.from_numpy(eng.lp[off + lo:off + hi])
+    dist.all_reduce(lp)
+    st = sh.global_stats()
+    if rank == 0:
+        np.savez(out_path, pos=pos, lp=lp.numpy(), proposals=st["proposals"],
+                 accepted=st["accepted"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world", [2])
+def test_sharded_equals_single_process(tmp_path, orc, k, world):
+    N, nt, gens, seed = 512, 3, 4, 21
+    out = str(tmp_path / "sharded.npz")
+    mp.spawn(_worker, args=(world, _free_port(), N, nt, gens, seed, out), nprocs=world, join=True)
+    got = np.load(out)
+    o = orc.OracleAIS(_model(k), N, seed=seed).init()
+    o.generations_sync(gens, nt, collect=False)
+    x, lp, ll, t = o.state()
+    assert np.array_equal(got["pos"], x)
+    assert np.array_equal(got["lp"], lp)
+    st = o.stats()
+    # every rank runs init for all walkers in the stand-in, but only its rows afterwards
+    assert int(got["proposals"]) == st["proposals"] == N * nt * gens
+    assert int(got["accepted"]) == st["accepted"]
+
+
+def test_sharded_requires_divisible_ensemble(k):
+    from kissabc_jl_amd.sharded import ShardedAIS
+
+    class E:
+        half = rows = None
+    with pytest.raises(ValueError):
+        # single process => world 1 => needs N % 2 == 0
+        ShardedAIS(_model(k), 513, engine=E())
