@@ -124,6 +124,13 @@ def main():
         rows = WALKERS_PER_GPU // 2
         alg_bytes_launch = rows * nt * bytes_per_eval
         achieved = alg_bytes_launch / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        # HBM bytes per launch from PMC counters are collected in separate rocprofv3
+        # passes (FETCH_SIZE / WRITE_SIZE cannot share a pass); the committed summary
+        # of that run is reported here when it was taken on this very workload.
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if nt == NT and os.path.exists(tf):
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         out = {
             "metric": "walker proposal+cost evals/sec at N=65536 walkers, D=8",
             "value": proposals / el, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
@@ -139,7 +146,7 @@ def main():
             "cost_evals_per_s": cost_evals / el,
             "accept_rate": (st1["accepted"] - st0["accepted"]) / max(1, proposals),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "ais_half_kernel<8, rosenbrock>",
                          "kernel_avg_ms": kms, "kernel_launches_timed": nl,
                          "algorithmic_bytes_per_launch": alg_bytes_launch},
