@@ -41,6 +41,9 @@ typedef struct kabc_u128 {
 
 KABC_HD kabc_u128_t kabc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                        uint32_t k0, uint32_t k1) {
+#if defined(__clang__)
+#pragma unroll
+#endif
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)KABC_PHILOX_M0 * (uint64_t)c0;
         uint64_t p1 = (uint64_t)KABC_PHILOX_M1 * (uint64_t)c2;

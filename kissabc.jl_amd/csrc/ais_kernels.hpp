@@ -146,11 +146,19 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
             hi[k] = B.hi[k];
         }
         bool in = true;
+        if (B.dmask == 0u) {  // wave-uniform: all components continuous, push_p = identity
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const double v = ((B.dmask >> k) & 1u) ? kabc_rint(y[k]) : y[k];
-            yp[k] = v;
-            in = in && (v >= lo[k]) && (v <= hi[k]);
+            for (int k = 0; k < D; ++k) {
+                yp[k] = y[k];
+                in = in && (y[k] >= lo[k]) && (y[k] <= hi[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                const double v = ((B.dmask >> k) & 1u) ? kabc_rint(y[k]) : y[k];
+                yp[k] = v;
+                in = in && (v >= lo[k]) && (v <= hi[k]);
+            }
         }
         lp = in ? B.lp : -KABC_INF;
     } else {
@@ -226,7 +234,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     wave_lds_fence();
     // -- phase B2: partner rows b (and c) for DE / walk lanes, dense
 #pragma unroll 1
-    for (int e = lane; e < nB; e += kWave) {
+    for (int e = lane; e < ((A.ablate & 32) ? 0 : nB); e += kWave) {
         const int l = listB[e];
         const uint32_t al = R.mva[si][l] & 0x3fffffffu;
         const kabc_u128_t B2 =
@@ -251,7 +259,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     }
     // -- phase N: Box-Muller blocks, dense
 #pragma unroll 1
-    for (int e = lane; e < nN; e += kWave) {
+    for (int e = lane; e < ((A.ablate & 8) ? 0 : nN); e += kWave) {
         const int ent = listN[e];
         const int l = ent >> 4, j = ent & 15;
         const kabc_u128_t Bn = kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 3u + (uint32_t)j,
@@ -264,6 +272,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     }
     wave_lds_fence();
     // -- phase C: gamma = 2.38/sqrt(2D) * exp(0.1 randn)   (src/transition.jl:3)
+    if (A.ablate & 16) return;
     if (move == 2) {
         const double z0 = R.zs[si][0][lane];
         R.zs[si][0][lane] = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp(z0 * 0.1);
@@ -304,7 +313,7 @@ ais_half_kernel(const AisArgs A) {
     const int64_t row = A.row_first + r;
     double x[D];
     double lp = 0.0, ll = 0.0;
-    unsigned long long n_eval = 0, n_acc = 0;
+    unsigned int n_eval = 0, n_acc = 0;
     int err = 0;
     if (active) {
         load_row<D>(A.x_act + row * D, x);
@@ -346,14 +355,16 @@ ais_half_kernel(const AisArgs A) {
             // CONSUMER
             const ChunkRec<D>& R = rec[(A.ablate & 2) ? 0 : (c & 1)];
             const int ns = (A.nt - s0 < kChunk) ? (A.nt - s0) : kChunk;
-            // partner rows: pa/pb serve this sub-step, na/nb are the next one's, in
+            // partner rows: (pa, pb) serve this sub-step, (na, nb) are the next one's, in
             // flight while this one computes.  Both rows are fetched for every lane
             // whatever its move (bb defaults to a): no divergence around the loads.
-            double pa[D], pb[D], na[D], nb[D];
-            load_row<D>(A.x_comp + (int64_t)(R.mva[0][lane] & 0x3fffffffu) * D, pa);
-            load_row<D>(A.x_comp + (int64_t)R.bb[0][lane] * D, pb);
-#pragma unroll 1
-            for (int si = 0; si < ns && !err; ++si) {
+            // The sub-step body is instantiated twice with the two register sets
+            // swapped, so no row is ever copied.
+            double r0a[D], r0b[D], r1a[D], r1b[D];
+            load_row<D>(A.x_comp + (int64_t)(R.mva[0][lane] & 0x3fffffffu) * D, r0a);
+            load_row<D>(A.x_comp + (int64_t)R.bb[0][lane] * D, r0b);
+            auto substep = [&](const int si, const double (&pa)[D], const double (&pb)[D],
+                               double (&na)[D], double (&nb)[D]) __attribute__((always_inline)) {
                 const uint64_t t = A.t0 + (uint64_t)(s0 + si);
                 // (1) every LDS word of this sub-step in one batch, plus the partner
                 //     ids of the next one
@@ -440,11 +451,11 @@ ais_half_kernel(const AisArgs A) {
                     d[4] = move == 3u ? (int32_t)R.cc[si][lane] : -1;
                     d[5] = ev ? 1 : 0;
                 }
-#pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    pa[k] = na[k];
-                    pb[k] = nb[k];
-                }
+            };
+#pragma unroll 1
+            for (int si = 0; si < ns && !err; si += 2) {
+                substep(si, r0a, r0b, r1a, r1b);
+                if (si + 1 < ns && !err) substep(si + 1, r1a, r1b, r0a, r0b);
             }
         }
         __syncthreads();
