@@ -2,6 +2,7 @@
 // driven from the host, one ε-iteration = one select kernel + 1..(1+mcmc_retrys)
 // propose/accept kernels; the host reads one small control record per pass.
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #define KABC_SMC_SINGLE_UNIT 1
@@ -10,7 +11,7 @@
 
 namespace kabc {
 
-#define KABC_DECL_COST(id) SmcLaunchFn find_smc_kernel_cost_##id(int D);
+#define KABC_DECL_COST(id) SmcLaunchFn find_smc_kernel_cost_##id(int D, bool simple);
 KABC_DECL_COST(1)
 KABC_DECL_COST(2)
 KABC_DECL_COST(3)
@@ -23,19 +24,19 @@ KABC_DECL_COST(9)
 KABC_DECL_COST(10)
 KABC_DECL_COST(11)
 
-SmcLaunchFn find_smc_kernel(int cost_id, int D) {
+SmcLaunchFn find_smc_kernel(int cost_id, int D, bool simple) {
     switch (cost_id) {
-        case 1: return find_smc_kernel_cost_1(D);
-        case 2: return find_smc_kernel_cost_2(D);
-        case 3: return find_smc_kernel_cost_3(D);
-        case 4: return find_smc_kernel_cost_4(D);
-        case 5: return find_smc_kernel_cost_5(D);
-        case 6: return find_smc_kernel_cost_6(D);
-        case 7: return find_smc_kernel_cost_7(D);
-        case 8: return find_smc_kernel_cost_8(D);
-        case 9: return find_smc_kernel_cost_9(D);
-        case 10: return find_smc_kernel_cost_10(D);
-        case 11: return find_smc_kernel_cost_11(D);
+        case 1: return find_smc_kernel_cost_1(D, simple);
+        case 2: return find_smc_kernel_cost_2(D, simple);
+        case 3: return find_smc_kernel_cost_3(D, simple);
+        case 4: return find_smc_kernel_cost_4(D, simple);
+        case 5: return find_smc_kernel_cost_5(D, simple);
+        case 6: return find_smc_kernel_cost_6(D, simple);
+        case 7: return find_smc_kernel_cost_7(D, simple);
+        case 8: return find_smc_kernel_cost_8(D, simple);
+        case 9: return find_smc_kernel_cost_9(D, simple);
+        case 10: return find_smc_kernel_cost_10(D, simple);
+        case 11: return find_smc_kernel_cost_11(D, simple);
         default: return nullptr;
     }
 }
@@ -125,7 +126,9 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         set_error("DeviceCost id %d does not accept D = %d", cost->id, D);
         return KABC_ERR_UNSUPPORTED;
     }
-    SmcLaunchFn mcmc = find_smc_kernel(cost->id, D);
+    bool simple = true;
+    for (int k = 0; k < D; ++k) simple = simple && prior_is_simple(prior[k].kind);
+    SmcLaunchFn mcmc = find_smc_kernel(cost->id, D, simple);
     if (!mcmc) {
         set_error("no gfx950 kernel instantiated for cost id %d, D = %d", cost->id, D);
         return KABC_ERR_UNSUPPORTED;
@@ -145,10 +148,14 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     DevBufs bufs;
-    double *th[2], *X[2], *lp[2], *d_params = nullptr, *d_data = nullptr, *d_out = nullptr;
+    double *th[2], *X[2], *lp[2], *d_params = nullptr, *d_data = nullptr, *d_out = nullptr,
+           *d_Xout = nullptr;
     uint8_t* alive;
     int32_t *ridx, *cidx;
     SmcCtrl* ctrl;
+    unsigned long long* slots;
+    kabc_smc_iter_t* d_log = nullptr;
+    const int64_t log_cap = res->iter_log ? res->iter_log_cap : 0;
     for (int b = 0; b < 2; ++b) {
         KABC_HIP_CHECK(bufs.alloc(&th[b], (size_t)N * D));
         KABC_HIP_CHECK(bufs.alloc(&X[b], (size_t)N));
@@ -158,8 +165,12 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     KABC_HIP_CHECK(bufs.alloc(&ridx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&ctrl, 1));
+    KABC_HIP_CHECK(bufs.alloc(&slots, (size_t)kSmcSlots * 8));
     KABC_HIP_CHECK(bufs.alloc(&d_out, (size_t)N * D));
+    KABC_HIP_CHECK(bufs.alloc(&d_Xout, (size_t)N));
+    if (log_cap > 0) KABC_HIP_CHECK(bufs.alloc(&d_log, (size_t)log_cap));
     KABC_HIP_CHECK(hipMemsetAsync(ctrl, 0, sizeof(SmcCtrl), s));
+    KABC_HIP_CHECK(hipMemsetAsync(slots, 0, sizeof(unsigned long long) * kSmcSlots * 8, s));
     if (cost->nparams > 0) {
         KABC_HIP_CHECK(bufs.alloc(&d_params, (size_t)cost->nparams));
         KABC_HIP_CHECK(hipMemcpyAsync(d_params, cost->params, sizeof(double) * cost->nparams,
@@ -174,7 +185,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     KABC_HIP_CHECK(hipEventCreate(&ev0));
     KABC_HIP_CHECK(hipEventCreate(&ev1));
     double mcmc_ms = 0.0;
-    int64_t mcmc_launches = 0;
+    int64_t mcmc_timed = 0;
 
     // :119-125
     {
@@ -196,104 +207,107 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         launch_smc_init(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
         KABC_HIP_CHECK(hipGetLastError());
     }
-    int cur = 0;
-    double eps = INFINITY;
-    int64_t iteration = 0;
-    uint64_t pass = 0;
-    const int64_t max_it = o->max_iterations > 0 ? o->max_iterations : 100000;
+    SmcSelectArgs sa;
+    sa.Xbuf[0] = X[0];
+    sa.Xbuf[1] = X[1];
+    sa.alive = alive;
+    sa.ridx = ridx;
+    sa.cidx = cidx;
+    sa.ctrl = ctrl;
+    sa.N = N;
+    sa.alpha = alpha;
+    sa.min_r_ess = min_r_ess;
+    sa.stamps = nullptr;
+    if (getenv("KABC_SMC_STAMPS")) {
+        KABC_HIP_CHECK(bufs.alloc(&sa.stamps, 8));
+        KABC_HIP_CHECK(hipMemsetAsync(sa.stamps, 0, 64, s));
+    }
+    SmcMcmcArgs ma;
+    std::memset(&ma, 0, sizeof ma);
+    for (int b = 0; b < 2; ++b) {
+        ma.theta[b] = th[b];
+        ma.X[b] = X[b];
+        ma.lpi[b] = lp[b];
+    }
+    ma.alive = alive;
+    ma.ridx = ridx;
+    ma.ctrl = ctrl;
+    ma.slots = slots;
+    ma.cost_params = d_params;
+    ma.cost_data = d_data;
+    ma.cost_ndata = cost->ndata;
+    ma.N = N;
+    ma.seed = o->seed;
+    ma.max_stretch = o->max_stretch;
+    ma.prior = P;
+    SmcLoopParams lpz;
+    lpz.mcmc_tol = o->mcmc_tol;
+    lpz.epstol = o->epstol;
+    lpz.r_epstol = r_epstol;
+    lpz.max_iterations = o->max_iterations > 0 ? o->max_iterations : 100000;
+
+    // The ε-loop is decided on the device (smc_pass_end_kernel / smc_iter_end_kernel);
+    // the host enqueues kBatch iterations and then reads the 128-byte control block
+    // once.  Kernels enqueued past the end of the loop are no-ops.
+    const int R = 1 + o->mcmc_retrys;
+    const int kGroup = 4;                        // retry passes enqueued between host checks
+    const int kBatch = (R <= kGroup) ? 16 : 1;   // iterations per host sync
     SmcCtrl hc;
     std::memset(&hc, 0, sizeof hc);
     kabc_status_t rc = KABC_OK;
+    bool first = true;
     while (true) {
-        ++iteration;
-        const double epsv = eps;
-        // Step 1 + 2 (decision and index) on the device
-        SmcSelectArgs sa;
-        sa.X = X[cur];
-        sa.alive = alive;
-        sa.ridx = ridx;
-        sa.cidx = cidx;
-        sa.ctrl = ctrl;
-        sa.N = N;
-        sa.alpha = alpha;
-        sa.min_r_ess = min_r_ess;
-        hipLaunchKernelGGL(smc_select_kernel, dim3(1), dim3(kSelBlock), 0, s, sa);
+        for (int it = 0; it < kBatch; ++it) {
+            hipLaunchKernelGGL(smc_select_kernel, dim3(1), dim3(kSelBlock), 0, s, sa);
+            for (int r0 = 0; r0 < R; r0 += kGroup) {
+                const int r1 = (r0 + kGroup < R) ? r0 + kGroup : R;
+                for (int r = r0; r < r1; ++r) {
+                    const bool timed = (it == 0 && r == 0);
+                    if (timed) KABC_HIP_CHECK(hipEventRecord(ev0, s));
+                    mcmc(ma, s);
+                    if (timed) KABC_HIP_CHECK(hipEventRecord(ev1, s));
+                    hipLaunchKernelGGL(smc_pass_end_kernel, dim3(1), dim3(kSmcSlots), 0, s, ctrl,
+                                       slots, N, o->mcmc_tol);
+                }
+                if (r1 < R) {  // many retries allowed: look before enqueueing more
+                    KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+                    KABC_HIP_CHECK(hipStreamSynchronize(s));
+                    if (hc.done || !hc.pass_open) break;
+                }
+            }
+            hipLaunchKernelGGL(smc_iter_end_kernel, dim3(1), dim3(1), 0, s, ctrl, d_log, log_cap, N,
+                               lpz);
+        }
         KABC_HIP_CHECK(hipGetLastError());
-        // Step 3
-        int passes = 0;
-        for (int r = 1; r <= 1 + o->mcmc_retrys; ++r) {
-            ++pass;
-            ++passes;
-            SmcMcmcArgs ma;
-            std::memset(&ma, 0, sizeof ma);
-            ma.theta_src = th[cur];
-            ma.X_src = X[cur];
-            ma.lpi_src = lp[cur];
-            ma.theta_dst = th[1 - cur];
-            ma.X_dst = X[1 - cur];
-            ma.lpi_dst = lp[1 - cur];
-            ma.alive = alive;
-            ma.ridx = (r == 1) ? ridx : nullptr;
-            ma.ctrl = ctrl;
-            ma.cost_params = d_params;
-            ma.cost_data = d_data;
-            ma.cost_ndata = cost->ndata;
-            ma.N = N;
-            ma.seed = o->seed;
-            ma.pass = pass;
-            ma.max_stretch = o->max_stretch;
-            ma.prior = P;
-            KABC_HIP_CHECK(hipEventRecord(ev0, s));
-            mcmc(ma, s);
-            KABC_HIP_CHECK(hipEventRecord(ev1, s));
-            KABC_HIP_CHECK(hipGetLastError());
-            cur = 1 - cur;
-            KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
-            KABC_HIP_CHECK(hipStreamSynchronize(s));
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
-                mcmc_ms += ms;
-                ++mcmc_launches;
-            }
-            if (hc.error) break;
-            if ((double)hc.accepted >= o->mcmc_tol * (double)N) break;  // :192
+        KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+        KABC_HIP_CHECK(hipStreamSynchronize(s));
+        float ms = 0.f;
+        if ((first || !hc.done) && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+            mcmc_ms += ms;
+            ++mcmc_timed;
         }
-        if (hc.error) {
-            if (hc.error == 1) {
-                set_error("quantiles are undefined in presence of NaNs");
-                rc = KABC_ERR_NAN_COST;
-            } else {
-                set_error("collection must be non-empty");
-                rc = KABC_ERR_INVALID_STATE;
-            }
-            break;
+        first = false;
+        if (hc.done) break;
+    }
+    if (hc.error) {
+        if (hc.error == 1) {
+            set_error("quantiles are undefined in presence of NaNs");
+            rc = KABC_ERR_NAN_COST;
+        } else {
+            set_error("collection must be non-empty");
+            rc = KABC_ERR_INVALID_STATE;
         }
-        eps = hc.eps;
-        if (o->verbose)
-            fprintf(stderr, "(iteration, ϵ, ESS) = (%lld, %.17g, %lld)\n", (long long)iteration,
-                    eps, (long long)hc.ess);
-        if (res->iter_log && iteration <= res->iter_log_cap) {
-            kabc_smc_iter_t* L = &res->iter_log[iteration - 1];
-            L->eps = eps;
-            L->ess = hc.ess;
-            L->accepted = (int64_t)hc.accepted;
-            L->resampled = hc.resampled;
-            L->flag = hc.flag;
-            L->mcmc_passes = passes;
-            L->reserved = 0;
-        }
-        // :194-198
-        const double acc = (double)hc.accepted;
-        if (2.0 * std::fabs(epsv - eps) < r_epstol * (std::fabs(epsv) + std::fabs(eps)) ||
-            eps <= o->epstol || acc < o->mcmc_tol * (double)N)
-            break;
-        if (iteration >= max_it) break;
     }
     if (rc == KABC_OK) {
         // :200-205
         SmcFinalArgs fa;
-        fa.theta = th[cur];
+        for (int b = 0; b < 2; ++b) {
+            fa.theta[b] = th[b];
+            fa.X[b] = X[b];
+        }
+        fa.ctrl = ctrl;
         fa.out = d_out;
+        fa.Xout = d_Xout;
         fa.N = N;
         fa.D = D;
         fa.prior = P;
@@ -304,18 +318,33 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
             KABC_HIP_CHECK(hipMemcpyAsync(res->theta, d_out, sizeof(double) * N * D,
                                           hipMemcpyDeviceToHost, s));
         if (res->cost)
-            KABC_HIP_CHECK(hipMemcpyAsync(res->cost, X[cur], sizeof(double) * N,
+            KABC_HIP_CHECK(hipMemcpyAsync(res->cost, d_Xout, sizeof(double) * N,
                                           hipMemcpyDeviceToHost, s));
         if (res->alive)
             KABC_HIP_CHECK(hipMemcpyAsync(res->alive, alive, (size_t)N, hipMemcpyDeviceToHost, s));
+        const int64_t nlog = hc.iteration < log_cap ? hc.iteration : log_cap;
+        if (nlog > 0)
+            KABC_HIP_CHECK(hipMemcpyAsync(res->iter_log, d_log, sizeof(kabc_smc_iter_t) * nlog,
+                                          hipMemcpyDeviceToHost, s));
         KABC_HIP_CHECK(hipStreamSynchronize(s));
-        res->eps = eps;
-        res->iterations = iteration;
+        if (o->verbose)  // @show iteration, ϵ, ESS  (src/smc.jl:143)
+            for (int64_t i = 0; i < nlog; ++i)
+                fprintf(stderr, "(iteration, ϵ, ESS) = (%lld, %.17g, %lld)\n", (long long)(i + 1),
+                        res->iter_log[i].eps, (long long)res->iter_log[i].ess);
+        res->eps = hc.eps;
+        res->iterations = hc.iteration;
         res->n_alive = hc.n_alive;
         res->cost_evals = hc.cost_evals;
         res->proposals = hc.proposals;
-        res->kernel_ms_mcmc = mcmc_launches ? mcmc_ms / (double)mcmc_launches : 0.0;
-        res->mcmc_launches = mcmc_launches;
+        res->kernel_ms_mcmc = mcmc_timed ? mcmc_ms / (double)mcmc_timed : 0.0;
+        res->mcmc_launches = (int64_t)hc.pass;
+    }
+    if (sa.stamps) {
+        unsigned long long st[8];
+        if (hipMemcpy(st, sa.stamps, 64, hipMemcpyDeviceToHost) == hipSuccess && st[7])
+            fprintf(stderr, "[kabc smc select stamps, cycles/call @100MHz-ticks] stats %.0f narrow %.0f list %.0f eps %.0f tiles %.0f write %.0f (calls %llu)\n",
+                    (double)st[0] / st[7], (double)st[1] / st[7], (double)st[2] / st[7], (double)st[3] / st[7],
+                    (double)st[4] / st[7], (double)st[5] / st[7], st[7]);
     }
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);

@@ -8,29 +8,31 @@
 
 namespace kabc {
 
-template <int D, int COST>
+template <int D, int COST, bool SIMPLE>
 static void launch_mcmc(const SmcMcmcArgs& a, hipStream_t s) {
     const unsigned grid = (unsigned)((a.N + kSmcBlock - 1) / kSmcBlock);
     if (grid == 0) return;
-    hipLaunchKernelGGL((smc_mcmc_kernel<D, COST>), dim3(grid), dim3(kSmcBlock), 0, s, a);
+    hipLaunchKernelGGL((smc_mcmc_kernel<D, COST, SIMPLE>), dim3(grid), dim3(kSmcBlock), 0, s, a);
 }
 
-template <int COST, int D>
+template <int COST, int D, bool SIMPLE>
 static SmcLaunchFn pick() {
-    if constexpr (cost_dim_ok_c(COST, D)) return &launch_mcmc<D, COST>;
+    if constexpr (cost_dim_ok_c(COST, D)) return &launch_mcmc<D, COST, SIMPLE>;
     else return nullptr;
 }
 
 template <int COST, int... Ds>
-static SmcLaunchFn table(int D, std::integer_sequence<int, Ds...>) {
-    SmcLaunchFn fns[] = {pick<COST, Ds + 1>()...};
-    return (D >= 1 && D <= (int)sizeof...(Ds)) ? fns[D - 1] : nullptr;
+static SmcLaunchFn table(int D, bool simple, std::integer_sequence<int, Ds...>) {
+    SmcLaunchFn fs[] = {pick<COST, Ds + 1, true>()...};
+    SmcLaunchFn fg[] = {pick<COST, Ds + 1, false>()...};
+    if (D < 1 || D > (int)sizeof...(Ds)) return nullptr;
+    return simple ? fs[D - 1] : fg[D - 1];
 }
 
 #define KABC_CAT2(a, b) a##b
 #define KABC_CAT(a, b) KABC_CAT2(a, b)
-SmcLaunchFn KABC_CAT(find_smc_kernel_cost_, KABC_INST_COST)(int D) {
-    return table<KABC_INST_COST>(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+SmcLaunchFn KABC_CAT(find_smc_kernel_cost_, KABC_INST_COST)(int D, bool simple) {
+    return table<KABC_INST_COST>(D, simple, std::make_integer_sequence<int, KABC_MAX_DIM>{});
 }
 
 }  // namespace kabc

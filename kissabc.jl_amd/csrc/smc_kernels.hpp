@@ -16,18 +16,34 @@
 
 namespace kabc {
 
+// Device-resident loop state of smc().  The ε-iteration is controlled ON THE DEVICE
+// (stop tests, retry break, buffer flip) so that the host can enqueue several
+// iterations without reading anything back; kernels of an iteration that is
+// already over are no-ops.
 struct SmcCtrl {
-    double eps;
+    double eps;                     // ϵ      (src/smc.jl:134)
+    double eps_prev;                // ϵv     (:133)
     double min_alive;               // minimum(Xs[alive]) of the last select
     long long ess;                  // sum(alive) before resampling
     long long n_alive;              // sum(alive) after step 2
+    long long iteration;
     int32_t flag;
     int32_t resampled;
     int32_t error;                  // 1 NaN cost among alive, 2 no alive particle
-    int32_t pad;
-    unsigned long long accepted;    // reset by select, accumulated by the MCMC passes
+    int32_t done;                   // outer loop has terminated (:194-198) or failed
+    int32_t cur;                    // buffer set holding the current ensemble
+    int32_t use_ridx;               // next MCMC pass gathers through ridx (first of an iteration)
+    int32_t pass_open;              // retry passes of this iteration may still run (:192)
+    int32_t passes;                 // passes executed in this iteration
+    unsigned long long pass;        // global pass counter = transition counter of the streams
+    unsigned long long accepted;    // accumulated in this iteration
     unsigned long long cost_evals;  // cumulative
     unsigned long long proposals;   // cumulative
+};
+
+struct SmcLoopParams {
+    double mcmc_tol, epstol, r_epstol;
+    long long max_iterations;
 };
 
 struct SmcInitArgs {
@@ -47,7 +63,7 @@ struct SmcInitArgs {
 };
 
 struct SmcSelectArgs {
-    const double* X;
+    const double* Xbuf[2];
     uint8_t* alive;
     int32_t* ridx;   // out: source row of particle i for the next MCMC pass
     int32_t* cidx;   // scratch: compacted alive indices
@@ -55,37 +71,39 @@ struct SmcSelectArgs {
     int64_t N;
     double alpha;
     double min_r_ess;
+    unsigned long long* stamps;  // diagnostic (KABC_SMC_STAMPS): per-phase s_memtime sums [8]
 };
 
 struct SmcMcmcArgs {
-    const double* theta_src;
-    const double* X_src;
-    const double* lpi_src;
-    double* theta_dst;
-    double* X_dst;
-    double* lpi_dst;
+    double* theta[2];     // double-buffered ensemble; ctrl->cur selects the source
+    double* X[2];
+    double* lpi[2];
     const uint8_t* alive;
-    const int32_t* ridx;  // NULL = identity
+    const int32_t* ridx;  // used when ctrl->use_ridx
     SmcCtrl* ctrl;
+    unsigned long long* slots;  // [kSmcSlots][8]: accepted, cost_evals, proposals
     const double* cost_params;
     const double* cost_data;
     int64_t cost_ndata;
     int64_t N;
     uint64_t seed;
-    uint64_t pass;
     double max_stretch;
     PriorSet prior;
 };
 
 struct SmcFinalArgs {
-    const double* theta;
+    const double* theta[2];
+    const double* X[2];
+    const SmcCtrl* ctrl;
     double* out;
+    double* Xout;
     int64_t N;
     int32_t D;
     PriorSet prior;
 };
 
 constexpr int kSmcBlock = 64;
+constexpr int kSmcSlots = 256;
 constexpr int kSelBlock = 1024;
 
 // order-preserving map double -> u64 (total order with -0 < +0, NaNs at the ends)
@@ -117,10 +135,11 @@ __global__ void __launch_bounds__(kSmcBlock) smc_init_kernel(const SmcInitArgs A
     A.lpi[i] = lp;
     A.alive[i] = 1;
     if (i == 0) {
-        A.ctrl->cost_evals = (unsigned long long)A.N;
-        A.ctrl->proposals = 0;
-        A.ctrl->accepted = 0;
-        A.ctrl->error = 0;
+        SmcCtrl c = {};
+        c.eps = KABC_INF;       // ϵ = Inf  (src/smc.jl:127)
+        c.eps_prev = KABC_INF;
+        c.cost_evals = (unsigned long long)A.N;
+        *A.ctrl = c;
     }
 }
 
@@ -150,39 +169,90 @@ __device__ __forceinline__ uint64_t block_min_u64(uint64_t v, uint64_t* sh) {
     return t;
 }
 
+// visit (i, key) of every alive particle; four independent (alive, X) load pairs are
+// issued per thread and iteration so that L2 latency overlaps (one dependent pair
+// per iteration made every pass over N cost ~13 us on the single workgroup)
+template <class F>
+__device__ __forceinline__ void for_each_alive(const uint8_t* __restrict__ alive,
+                                               const double* __restrict__ X, int64_t N, int tid,
+                                               F&& f) {
+    constexpr int U = 4;
+    for (int64_t i0 = tid; i0 < N; i0 += (int64_t)U * kSelBlock) {
+        uint8_t al[U];
+        double xv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * kSelBlock;
+            al[u] = (i < N) ? alive[i] : (uint8_t)0;
+            xv[u] = (i < N) ? X[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (al[u]) f(i0 + (int64_t)u * kSelBlock, xv[u]);
+    }
+}
+
+constexpr int kSelBins = 1024;   // histogram bins per narrowing round
+constexpr int kSelCand = 4096;   // candidate keys sorted in LDS
+
+// ε-selection, alive mask, ESS, resample decision and index -- one workgroup.
+//
+// quantile: the two bracketing order statistics of the alive costs are found by
+// NARROWING on the order-preserving u64 keys: a 1024-bin histogram of
+// (key - klo) >> shift over the current key range [klo, khi] (bins are spread over
+// the range actually occupied, so LDS atomics do not pile onto one bin the way a
+// fixed leading-byte radix pass does), then the bin holding the target rank
+// becomes the new range, until at most 4096 candidates remain; those are
+// bitonic-sorted in LDS.  Typically: stats pass + 1 histogram pass + 1 collect pass.
 __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectArgs A) {
-    __shared__ unsigned int hist[256];
+    __shared__ unsigned int hist[kSelBins];
+    __shared__ uint64_t cand[kSelCand];
     __shared__ long long sh_ll[kSelBlock / kWave];
     __shared__ uint64_t sh_u[kSelBlock / kWave];
-    __shared__ uint64_t s_prefix;
-    __shared__ long long s_k;
+    __shared__ unsigned int s_wcnt[kSelBlock / kWave];
+    __shared__ uint64_t s_klo, s_khi, s_keya, s_keyb;
+    __shared__ long long s_kt, s_nrange;
+    __shared__ unsigned int s_ncand;
+    __shared__ int s_state;  // 0 narrowing, 1 collect+sort, 2 a known (all keys of range equal)
     __shared__ double s_eps;
-    __shared__ int s_flag, s_resample;
-    __shared__ long long s_scan[kSelBlock / kWave];
+    __shared__ int s_flag, s_needmin;
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
     const int64_t N = A.N;
-
-    // (a) n = count(alive), mn = minimum(Xs[alive]), NaN check
-    long long cnt = 0, nanc = 0;
-    uint64_t kmin = ~0ull;
-    for (int64_t i = tid; i < N; i += kSelBlock) {
-        if (A.alive[i]) {
-            const double x = A.X[i];
-            ++cnt;
-            if (x != x) ++nanc;
-            const uint64_t k = key_of(x);
-            kmin = k < kmin ? k : kmin;
-        }
+    if (A.ctrl->done) return;  // uniform: the loop ended in an earlier iteration
+    unsigned long long t_prev = A.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+#define KABC_STAMP(slot)                                                   \
+    if (A.stamps && tid == 0) {                                            \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();     \
+        A.stamps[slot] += t_now - t_prev;                                  \
+        t_prev = t_now;                                                    \
     }
+    const double* __restrict__ X = A.Xbuf[A.ctrl->cur];
+    const int64_t ntile = (N + kSelBlock - 1) / kSelBlock;
+
+    // (a) n = count(alive), NaN check, key range of the alive costs
+    long long cnt = 0, nanc = 0;
+    uint64_t kmin = ~0ull, kmaxn = ~0ull;  // kmaxn = ~max
+    for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+        ++cnt;
+        if (x != x) ++nanc;
+        const uint64_t k = key_of(x);
+        kmin = k < kmin ? k : kmin;
+        kmaxn = ~k < kmaxn ? ~k : kmaxn;
+    });
     const long long n = block_sum_ll(cnt, sh_ll);
     const long long nn = block_sum_ll(nanc, sh_ll);
     kmin = block_min_u64(kmin, sh_u);
+    const uint64_t kmax = ~block_min_u64(kmaxn, sh_u);
     if (n == 0 || nn > 0) {
-        if (tid == 0) A.ctrl->error = (nn > 0) ? 1 : 2;
+        if (tid == 0) {
+            A.ctrl->error = (nn > 0) ? 1 : 2;
+            A.ctrl->done = 1;
+        }
         return;
     }
-    const double mn = val_of(kmin);
+    const double mn = val_of(kmin);  // minimum(Xs[alive])
+    KABC_STAMP(0)
 
     // (b) ranks of the two bracketing order statistics (Statistics.quantile, type 7)
     const double aleph = (double)n * A.alpha + (1.0 - A.alpha);
@@ -193,53 +263,172 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     double g = aleph - (double)j;
     g = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);
 
-    // radix select of rank j-1 (0-based) over the alive keys, 8 bits per pass
+    // (c) narrowing for the key of rank j-1 (0-based) inside [klo, khi]
     if (tid == 0) {
-        s_prefix = 0;
-        s_k = j - 1;
+        s_klo = kmin;
+        s_khi = kmax;
+        s_kt = j - 1;
+        s_nrange = n;
+        s_state = (kmin == kmax) ? 2 : (n <= kSelCand ? 1 : 0);
     }
-    uint64_t mask = 0;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int round = 0; round < 12 && s_state == 0; ++round) {
+        const uint64_t klo = s_klo, khi = s_khi;
+        const uint64_t span = khi - klo;  // > 0
+        const int bits = 64 - __clzll((long long)span);
+        const int shift = bits > 10 ? bits - 10 : 0;
+        for (int b = tid; b < kSelBins; b += kSelBlock) hist[b] = 0;
         __syncthreads();
-        const uint64_t prefix = s_prefix;
-        for (int64_t i = tid; i < N; i += kSelBlock) {
-            if (A.alive[i]) {
-                const uint64_t k = key_of(A.X[i]);
-                if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)((k >> shift) & 0xff)], 1u);
-            }
+        for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+            const uint64_t k = key_of(x);
+            if (k >= klo && k <= khi) atomicAdd(&hist[(unsigned)((k - klo) >> shift)], 1u);
+        });
+        __syncthreads();
+        // parallel search of the bin holding rank kt: inclusive scan of 1024 bins
+        const unsigned c = hist[tid];
+        unsigned incl = c;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
+        }
+        if (lane == kWave - 1) s_wcnt[wid] = incl;
+        __syncthreads();
+        unsigned woff = 0;
+        for (int w = 0; w < wid; ++w) woff += s_wcnt[w];
+        const long long before = (long long)woff + incl - c, kt = s_kt;
+        __syncthreads();
+        if (c > 0 && kt >= before && kt < before + (long long)c) {  // exactly one thread
+            const uint64_t nlo = klo + ((uint64_t)tid << shift);
+            uint64_t nhi = nlo + ((1ull << shift) - 1ull);
+            if (nhi > khi || nhi < nlo) nhi = khi;
+            s_klo = nlo;
+            s_khi = nhi;
+            s_kt = kt - before;
+            s_nrange = c;
+            s_state = (shift == 0) ? 2 : (c <= (unsigned)kSelCand ? 1 : 0);
         }
         __syncthreads();
+    }
+    KABC_STAMP(1)
+    if (s_state == 0) {  // cannot happen: 12 rounds x 10 bits > 64 bits
         if (tid == 0) {
-            long long k = s_k;
-            int bin = 0;
-            for (; bin < 256; ++bin) {
-                const long long c = hist[bin];
-                if (k < c) break;
-                k -= c;
-            }
-            s_k = k;
-            s_prefix = prefix | ((uint64_t)bin << shift);
+            A.ctrl->error = 2;
+            A.ctrl->done = 1;
         }
-        mask |= (0xffull << shift);
+        return;
+    }
+    if (s_state == 1) {
+        // collect the <= 4096 keys of the range into LDS, keep narrowing ON THE LIST
+        // (4 keys per thread per round) until <= 64 keys remain, then rank those
+        // inside one wavefront.
+        if (tid == 0) s_ncand = 0;
         __syncthreads();
-    }
-    const uint64_t key_a = s_prefix;
-    // count(keys <= key_a) and min(keys > key_a)
-    long long cle = 0;
-    uint64_t kgt = ~0ull;
-    for (int64_t i = tid; i < N; i += kSelBlock) {
-        if (A.alive[i]) {
-            const uint64_t k = key_of(A.X[i]);
-            if (k <= key_a) ++cle;
-            else kgt = k < kgt ? k : kgt;
+        {
+            const uint64_t klo = s_klo, khi = s_khi;
+            for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+                const uint64_t k = key_of(x);
+                if (k >= klo && k <= khi) cand[atomicAdd(&s_ncand, 1u)] = k;
+            });
+        }
+        __syncthreads();
+        const unsigned nc = s_ncand;
+        if (tid == 0) s_state = (s_nrange <= kWave) ? 3 : 0;
+        __syncthreads();
+        for (int round = 0; round < 12 && s_state == 0; ++round) {
+            const uint64_t klo = s_klo, khi = s_khi;
+            const uint64_t span = khi - klo;
+            if (span == 0) {  // all remaining keys equal
+                if (tid == 0) s_state = 2;
+                __syncthreads();
+                break;
+            }
+            const int bits = 64 - __clzll((long long)span);
+            const int shift = bits > 10 ? bits - 10 : 0;
+            for (int b = tid; b < kSelBins; b += kSelBlock) hist[b] = 0;
+            __syncthreads();
+            for (unsigned i = tid; i < nc; i += kSelBlock) {
+                const uint64_t k = cand[i];
+                if (k >= klo && k <= khi) atomicAdd(&hist[(unsigned)((k - klo) >> shift)], 1u);
+            }
+            __syncthreads();
+            const unsigned c = hist[tid];
+            unsigned incl = c;
+            for (int off = 1; off < kWave; off <<= 1) {
+                const unsigned o = __shfl_up(incl, off, kWave);
+                if (lane >= off) incl += o;
+            }
+            if (lane == kWave - 1) s_wcnt[wid] = incl;
+            __syncthreads();
+            unsigned woff = 0;
+            for (int w = 0; w < wid; ++w) woff += s_wcnt[w];
+            const long long before = (long long)woff + incl - c, kt = s_kt;
+            __syncthreads();
+            if (c > 0 && kt >= before && kt < before + (long long)c) {
+                const uint64_t nlo = klo + ((uint64_t)tid << shift);
+                uint64_t nhi = nlo + ((1ull << shift) - 1ull);
+                if (nhi > khi || nhi < nlo) nhi = khi;
+                s_klo = nlo;
+                s_khi = nhi;
+                s_kt = kt - before;
+                s_nrange = c;
+                s_state = (shift == 0) ? 2 : (c <= (unsigned)kWave ? 3 : 0);
+            }
+            __syncthreads();
+        }
+        if (s_state == 3) {
+            // <= 64 keys left in [klo, khi]: wave 0 gathers them (one per lane) and each
+            // lane counts how many precede it -> ranks without sorting
+            if (tid == 0) s_ncand = 0;
+            __syncthreads();
+            const uint64_t klo = s_klo, khi = s_khi;
+            for (unsigned i = tid; i < nc; i += kSelBlock) {
+                const uint64_t k = cand[i];
+                if (k >= klo && k <= khi) {
+                    const unsigned pos = atomicAdd(&s_ncand, 1u);
+                    sh_u[pos % (kSelBlock / kWave)] = 0;  // (keeps sh_u initialised)
+                    reinterpret_cast<uint64_t*>(hist)[pos] = k;  // hist is free now: 64 x u64
+                }
+            }
+            __syncthreads();
+            if (wid == 0) {
+                const unsigned m = s_ncand;  // == s_nrange
+                const uint64_t mine = (lane < (int)m) ? reinterpret_cast<uint64_t*>(hist)[lane] : ~0ull;
+                unsigned rank = 0;
+                for (unsigned q = 0; q < m; ++q) {
+                    const uint64_t other = __shfl(mine, (int)q, kWave);
+                    rank += (other < mine || (other == mine && q < (unsigned)lane)) ? 1u : 0u;
+                }
+                const long long kt = s_kt;
+                if (lane < (int)m && rank == (unsigned)kt) s_keya = mine;
+                if (lane < (int)m && rank == (unsigned)kt + 1u) s_keyb = mine;
+                if (lane == 0) s_needmin = (kt + 1 < (long long)m) ? 0 : 1;
+            }
+            __syncthreads();
+            if (tid == 0 && s_needmin) s_keyb = ~0ull;
         }
     }
-    const long long n_le = block_sum_ll(cle, sh_ll);
-    kgt = block_min_u64(kgt, sh_u);
+    KABC_STAMP(2)
+    if (s_state == 2 && tid == 0) {  // every key of the range equals klo
+        s_keya = s_klo;
+        s_needmin = (s_kt + 1 < s_nrange) ? 0 : 1;
+        s_keyb = s_needmin ? ~0ull : s_klo;
+    }
+    __syncthreads();
+    if (s_needmin && n > 1) {
+        // rank j is the smallest alive key above the final range
+        const uint64_t khi = s_khi;
+        uint64_t kgt = ~0ull;
+        for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+            const uint64_t k = key_of(x);
+            if (k > khi) kgt = k < kgt ? k : kgt;
+        });
+        kgt = block_min_u64(kgt, sh_u);
+        if (tid == 0) s_keyb = kgt;
+    }
+    __syncthreads();
     if (tid == 0) {
-        const double a = val_of(key_a);
-        const double b = (n == 1 || n_le >= j + 1) ? a : val_of(kgt);
+        const double a = val_of(s_keya);
+        const double b = (n == 1) ? a : val_of(s_keyb);
         double eps;
         if (kabc_isfinite(a) && kabc_isfinite(b)) eps = a + g * (b - a);
         else eps = (1.0 - g) * a + g * b;
@@ -249,66 +438,89 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     __syncthreads();
     const double eps = s_eps;
     const int flag = s_flag;
+    KABC_STAMP(3)
 
-    // (d) new alive mask over ALL particles, ESS, compaction offsets.
-    // contiguous chunk per thread so that the compacted order is ascending in i.
-    const int64_t chunk = (N + kSelBlock - 1) / kSelBlock;
-    const int64_t i0 = (int64_t)tid * chunk;
-    const int64_t i1 = (i0 + chunk < N) ? i0 + chunk : N;
-    long long mine = 0;
-    for (int64_t i = i0; i < i1; ++i) {
-        const double x = A.X[i];
-        const bool al = flag ? (x <= eps) : (x < eps);
-        mine += al ? 1 : 0;
+    // (d) new alive mask over ALL particles, ESS, compaction of the alive indices in
+    //     ascending order: coalesced tiles of 1024 with ballot + mbcnt
+    // four tiles of 1024 per round: the 4 x 16 per-wave counts form one 64-entry
+    // vector that every wave scans with shuffles (tile-major = ascending index)
+    __shared__ unsigned int s_cnt4[4 * (kSelBlock / kWave)];
+    long long base = 0;
+    for (int64_t tile0 = 0; tile0 < ntile; tile0 += 4) {
+        bool al[4];
+        unsigned long long bm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = (tile0 + u) * kSelBlock + tid;
+            double x = 0.0;
+            const bool in = i < N;
+            if (in) x = X[i];
+            al[u] = in && (flag ? (x <= eps) : (x < eps));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            bm[u] = __ballot(al[u]);
+            if (lane == 0) s_cnt4[u * (kSelBlock / kWave) + wid] = (unsigned)__popcll(bm[u]);
+        }
+        __syncthreads();
+        const unsigned c = s_cnt4[lane];  // entry `lane` of the 64-vector
+        unsigned incl = c;
+        for (int off = 1; off < kWave; off <<= 1) {
+            const unsigned o = __shfl_up(incl, off, kWave);
+            if (lane >= off) incl += o;
+        }
+        const unsigned excl = incl - c;
+        const unsigned tot = (unsigned)__shfl((int)incl, kWave - 1, kWave);
+        const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned woff = (unsigned)__shfl((int)excl, u * (kSelBlock / kWave) + wid, kWave);
+            if (al[u])
+                A.cidx[base + woff + __popcll(bm[u] & below)] =
+                    (int32_t)((tile0 + u) * kSelBlock + tid);
+        }
+        base += tot;
+        __syncthreads();
     }
-    // exclusive scan of `mine` over the block
-    long long incl = mine;
-    for (int off = 1; off < kWave; off <<= 1) {
-        const long long o = __shfl_up(incl, off, kWave);
-        if ((tid & 63) >= off) incl += o;
-    }
-    if ((tid & 63) == 63) s_scan[tid >> 6] = incl;
-    __syncthreads();
-    long long wave_off = 0, total = 0;
-    for (int w = 0; w < kSelBlock / kWave; ++w) {
-        if (w < (tid >> 6)) wave_off += s_scan[w];
-        total += s_scan[w];
-    }
-    const long long excl = wave_off + incl - mine;
-    const long long ESS = total;
-    if (tid == 0) {
-        // Step 2 decision: α*ESS <= nparticles*min_r_ess  (src/smc.jl:145)
-        s_resample = (A.alpha * (double)ESS <= (double)N * A.min_r_ess) ? 1 : 0;
-    }
-    __syncthreads();
-    const int resample = s_resample;
+    const long long ESS = base;
+    KABC_STAMP(4)
+    // Step 2 decision: α*ESS <= nparticles*min_r_ess  (src/smc.jl:145)
+    const int resample = (A.alpha * (double)ESS <= (double)N * A.min_r_ess) ? 1 : 0;
     if (resample && ESS == 0) {
-        if (tid == 0) A.ctrl->error = 2;
+        if (tid == 0) {
+            A.ctrl->error = 2;
+            A.ctrl->done = 1;
+        }
         return;
     }
+    __threadfence_block();
+    __syncthreads();
     if (resample) {
-        long long o = excl;
-        for (int64_t i = i0; i < i1; ++i) {
-            const double x = A.X[i];
-            const bool al = flag ? (x <= eps) : (x < eps);
-            if (al) A.cidx[o++] = (int32_t)i;
-        }
-        __threadfence_block();
-        __syncthreads();
         // idx = repeat(idxalive, ceil(N/m))[1:N]  (src/smc.jl:146-147)
+        const unsigned e = (unsigned)ESS;
+        unsigned rmod = (unsigned)tid % e;
+        const unsigned step = (unsigned)kSelBlock % e;
         for (int64_t jdx = tid; jdx < N; jdx += kSelBlock) {
-            A.ridx[jdx] = A.cidx[jdx % ESS];
+            A.ridx[jdx] = A.cidx[rmod];
             A.alive[jdx] = 1;
+            rmod += step;
+            if (rmod >= e) rmod -= e;
         }
     } else {
-        for (int64_t i = i0; i < i1; ++i) {
-            const double x = A.X[i];
-            const bool al = flag ? (x <= eps) : (x < eps);
-            A.alive[i] = al ? 1 : 0;
-            A.ridx[i] = (int32_t)i;
+        for (int64_t tile = 0; tile < ntile; ++tile) {
+            const int64_t i = tile * kSelBlock + tid;
+            if (i < N) {
+                const double x = X[i];
+                A.alive[i] = (flag ? (x <= eps) : (x < eps)) ? 1 : 0;
+                A.ridx[i] = (int32_t)i;
+            }
         }
     }
+    KABC_STAMP(5)
     if (tid == 0) {
+        if (A.stamps) A.stamps[7] += 1;
+        A.ctrl->iteration += 1;
+        A.ctrl->eps_prev = A.ctrl->eps;  // ϵv = ϵ
         A.ctrl->eps = eps;
         A.ctrl->min_alive = mn;
         A.ctrl->ess = ESS;
@@ -316,27 +528,36 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         A.ctrl->flag = flag;
         A.ctrl->resampled = resample;
         A.ctrl->accepted = 0;
+        A.ctrl->passes = 0;
+        A.ctrl->pass_open = 1;
+        A.ctrl->use_ridx = 1;
     }
 }
-
 #endif  // KABC_SMC_SINGLE_UNIT
 
-template <int D, int COST>
+template <int D, int COST, bool SIMPLE>
 __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A) {
     const int64_t i = (int64_t)blockIdx.x * kSmcBlock + threadIdx.x;
     unsigned long long n_eval = 0, n_acc = 0, n_prop = 0;
+    if (A.ctrl->done || !A.ctrl->pass_open) return;  // uniform no-op
+    const int cur = A.ctrl->cur;
+    const bool gather = A.ctrl->use_ridx != 0;
+    const uint64_t pass = A.ctrl->pass + 1u;
+    const double* __restrict__ theta_src = A.theta[cur];
+    const double* __restrict__ X_src = A.X[cur];
+    const double* __restrict__ lpi_src = A.lpi[cur];
     if (i < A.N) {
-        const int64_t si = A.ridx ? A.ridx[i] : i;
+        const int64_t si = gather ? A.ridx[i] : i;
         double th[D];
-        load_row<D>(A.theta_src + si * D, th);
-        double Xi = A.X_src[si];
-        double lpi = A.lpi_src[si];
+        load_row<D>(theta_src + si * D, th);
+        double Xi = X_src[si];
+        double lpi = lpi_src[si];
         if (A.alive[i]) {
             const uint64_t N = (uint64_t)A.N;
             const uint32_t w = (uint32_t)i;
-            const kabc_u128_t B0 = kabc_stream_block(A.seed, w, A.pass, 0u, KABC_DOM_SMC_MOVE);
-            const kabc_u128_t B1 = kabc_stream_block(A.seed, w, A.pass, 1u, KABC_DOM_SMC_MOVE);
-            const kabc_u128_t B2 = kabc_stream_block(A.seed, w, A.pass, 2u, KABC_DOM_SMC_MOVE);
+            const kabc_u128_t B0 = kabc_stream_block(A.seed, w, pass, 0u, KABC_DOM_SMC_MOVE);
+            const kabc_u128_t B1 = kabc_stream_block(A.seed, w, pass, 1u, KABC_DOM_SMC_MOVE);
+            const kabc_u128_t B2 = kabc_stream_block(A.seed, w, pass, 2u, KABC_DOM_SMC_MOVE);
             // while a==i ... ; while b==i || b==a ...  (src/smc.jl:163-164)
             int64_t a = (int64_t)kabc_index(kabc_lo64(B0), N - 1u);
             a += (a >= i);
@@ -347,11 +568,11 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
             double z0, z1;
             kabc_normal_pair(kabc_lo64(B1), kabc_hi64(B1), &z0, &z1);
             const double s = A.max_stretch * z0 / kabc_sqrt((double)D);
-            const int64_t sa = A.ridx ? A.ridx[a] : a;
-            const int64_t sb = A.ridx ? A.ridx[b] : b;
+            const int64_t sa = gather ? A.ridx[a] : a;
+            const int64_t sb = gather ? A.ridx[b] : b;
             double ta[D], tb[D], prop[D], xp[D];
-            load_row<D>(A.theta_src + sa * D, ta);
-            load_row<D>(A.theta_src + sb * D, tb);
+            load_row<D>(theta_src + sa * D, ta);
+            load_row<D>(theta_src + sb * D, tb);
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 const double W = (tb[k] - ta[k]) * s;
@@ -359,12 +580,12 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
             }
             const double lprob = kabc_log(kabc_u01(kabc_lo64(B2)));
             n_prop = 1;
-            const double lpp = factored_logpdf_push<D>(A.prior, prop, xp);
+            const double lpp = factored_logpdf_push<D, SIMPLE>(A.prior, prop, xp);
             if (!(lpp < 0.0 && !kabc_isfinite(lpp))) {  // :173
                 double lM = lpp - lpi + 0.0;
                 if (!(lM < 0.0)) lM = (lM != lM) ? lM : 0.0;
                 if (lprob < lM) {
-                    kabc_cost_rng_t rng = {A.seed, A.pass, w, KABC_DOM_SMC_COST, 0u};
+                    kabc_cost_rng_t rng = {A.seed, pass, w, KABC_DOM_SMC_COST, 0u};
                     const double Xp =
                         eval_cost<COST, D>(xp, A.cost_params, A.cost_data, A.cost_ndata, &rng);
                     n_eval = 1;
@@ -380,15 +601,18 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
                 }
             }
         }
-        store_row<D>(A.theta_dst + i * D, th);
-        A.X_dst[i] = Xi;
-        A.lpi_dst[i] = lpi;
+        store_row<D>(A.theta[1 - cur] + i * D, th);
+        A.X[1 - cur][i] = Xi;
+        A.lpi[1 - cur][i] = lpi;
     }
+    // one counter line per workgroup (mod kSmcSlots): same-line atomics from 512
+    // workgroups cost ~20 us per launch
     const unsigned long long se = wave_sum(n_eval), sa = wave_sum(n_acc), sp = wave_sum(n_prop);
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        if (sa) atomicAdd(&A.ctrl->accepted, sa);
-        if (se) atomicAdd(&A.ctrl->cost_evals, se);
-        if (sp) atomicAdd(&A.ctrl->proposals, sp);
+        unsigned long long* sl = A.slots + (size_t)(blockIdx.x & (kSmcSlots - 1)) * 8;
+        if (sa) atomicAdd(&sl[0], sa);
+        if (se) atomicAdd(&sl[1], se);
+        if (sp) atomicAdd(&sl[2], sp);
     }
 }
 
@@ -396,15 +620,72 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
 __global__ void __launch_bounds__(256) smc_finalize_kernel(const SmcFinalArgs A) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= A.N) return;
+    const int cur = A.ctrl->cur;
     for (int k = 0; k < A.D; ++k) {
-        const double v = A.theta[i * A.D + k];
+        const double v = A.theta[cur][i * A.D + k];
         A.out[i * A.D + k] = A.prior.c[k].discrete ? kabc_rint(v) : v;
     }
+    A.Xout[i] = A.X[cur][i];
+}
+
+// after every MCMC pass: fold the per-workgroup counter lines, flip the buffers,
+// apply `accepted[] >= mcmc_tol * nparticles && break` (src/smc.jl:192)
+__global__ void __launch_bounds__(kSmcSlots) smc_pass_end_kernel(SmcCtrl* ctrl,
+                                                                 unsigned long long* slots,
+                                                                 int64_t N, double mcmc_tol) {
+    __shared__ unsigned long long sh[3][kSmcSlots / kWave];
+    if (ctrl->done || !ctrl->pass_open) return;
+    const int tid = threadIdx.x;
+    unsigned long long v[3];
+    for (int j = 0; j < 3; ++j) {
+        v[j] = wave_sum(slots[(size_t)tid * 8 + j]);
+        slots[(size_t)tid * 8 + j] = 0;
+    }
+    if ((tid & (kWave - 1)) == 0)
+        for (int j = 0; j < 3; ++j) sh[j][tid >> 6] = v[j];
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long t[3] = {0, 0, 0};
+        for (int w = 0; w < kSmcSlots / kWave; ++w)
+            for (int j = 0; j < 3; ++j) t[j] += sh[j][w];
+        ctrl->accepted += t[0];
+        ctrl->cost_evals += t[1];
+        ctrl->proposals += t[2];
+        ctrl->pass += 1;
+        ctrl->passes += 1;
+        ctrl->cur ^= 1;
+        ctrl->use_ridx = 0;
+        if ((double)ctrl->accepted >= mcmc_tol * (double)N) ctrl->pass_open = 0;
+    }
+}
+
+// end of an ε-iteration: log it and apply the stop tests of src/smc.jl:194-198
+__global__ void smc_iter_end_kernel(SmcCtrl* ctrl, kabc_smc_iter_t* log, int64_t log_cap,
+                                    int64_t N, SmcLoopParams P) {
+    if (ctrl->done) return;
+    ctrl->pass_open = 0;
+    const long long it = ctrl->iteration;
+    const double eps = ctrl->eps, epsv = ctrl->eps_prev;
+    if (log && it <= log_cap) {
+        kabc_smc_iter_t L;
+        L.eps = eps;
+        L.ess = ctrl->ess;
+        L.accepted = (int64_t)ctrl->accepted;
+        L.resampled = ctrl->resampled;
+        L.flag = ctrl->flag;
+        L.mcmc_passes = ctrl->passes;
+        L.reserved = 0;
+        log[it - 1] = L;
+    }
+    const double acc = (double)ctrl->accepted;
+    if (2.0 * kabc_fabs(epsv - eps) < P.r_epstol * (kabc_fabs(epsv) + kabc_fabs(eps)) ||
+        eps <= P.epstol || acc < P.mcmc_tol * (double)N || it >= P.max_iterations)
+        ctrl->done = 1;
 }
 
 #endif  // KABC_SMC_SINGLE_UNIT
 
 using SmcLaunchFn = void (*)(const SmcMcmcArgs&, hipStream_t);
-SmcLaunchFn find_smc_kernel(int cost_id, int D);
+SmcLaunchFn find_smc_kernel(int cost_id, int D, bool simple_prior);
 
 }  // namespace kabc
