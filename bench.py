@@ -93,6 +93,7 @@ def main():
     ens = sh.engine.ens
 
     def sync():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)

@@ -23,9 +23,25 @@ class KabcError(RuntimeError):
         self.status = status
 
 
+def _preload_torch_hip():
+    """PyTorch wheels bundle their own ROCm runtime (libamdhip64 & co).  If this
+    library pulls in the system libamdhip64 first, a later `import torch` binds to a
+    mixed set of ROCm libraries and reports "No HIP GPUs are available".  Loading
+    torch first makes both use torch's copy (same soname).  Only done when torch is
+    installed; the C ABI itself never needs torch."""
+    import importlib.util
+    import sys
+    if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+
+
 def load():
     global _lib
     if _lib is None:
+        _preload_torch_hip()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "

@@ -16,6 +16,8 @@ torch is plumbing here: device buffers for the two global halves (so that the
 collective and the kernels see the same memory), the current HIP stream, and
 torch.distributed.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -25,17 +27,25 @@ from .api import AisEnsemble
 
 class HipEngine:
     """Per-rank compute: the gfx950 kernels updating this rank's rows in place
-    inside torch-owned global half buffers."""
+    inside torch-owned global half buffers.
 
-    def __init__(self, model, n_total, seed, rank, world, device):
+    Stream discipline: the engine owns ONE explicit (non-default) torch stream; the
+    kernels are enqueued on it through the C ABI and the collectives are issued
+    while it is torch's current stream, so c10d orders RCCL against the kernels.
+    (torch's default stream has handle 0, which the C ABI reads as "create a
+    private stream" -- never pass it.)"""
+
+    def __init__(self, model, n_total, seed, rank, world, device, half_buffers=None):
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         D = len(model)
         n0, n1 = (n_total + 1) // 2, n_total // 2
-        self.half = [torch.zeros((n0, D), dtype=torch.float64, device=self.device),
-                     torch.zeros((n1, D), dtype=torch.float64, device=self.device)]
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx = _lib.Context(self.device.index or 0, stream)
+        self.stream = torch.cuda.Stream(self.device)
+        with torch.cuda.stream(self.stream):
+            self.half = half_buffers or [
+                torch.zeros((n0, D), dtype=torch.float64, device=self.device),
+                torch.zeros((n1, D), dtype=torch.float64, device=self.device)]
+        self.ctx = _lib.Context(self.device.index or 0, self.stream.cuda_stream)
         self.ens = AisEnsemble(model, n_total, seed=seed, ctx=self.ctx,
                                sharded=(rank, world, self.half[0].data_ptr(),
                                         self.half[1].data_ptr()))
@@ -54,7 +64,11 @@ class HipEngine:
     def stats(self):
         return self.ens.stats()
 
-    inplace_gather = True
+    def synchronize(self):
+        self.stream.synchronize()
+
+    inplace_gather = False   # a 2 MiB staging copy is cheaper than the risk of an
+    # overlapping-buffer check in the collective
 
 
 class ShardedAIS:
@@ -71,15 +85,20 @@ class ShardedAIS:
         self.N, self.D = int(n_total), len(model)
         self.engine = engine or HipEngine(model, n_total, seed, self.rank, self.world, device)
 
+    def _stream_ctx(self):
+        st = getattr(self.engine, "stream", None)
+        return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+
     def _gather(self, half):
         if self.world == 1:
             return
-        buf = self.engine.half[half]
-        lo, hi = self.engine.rows[half]
-        own = buf[lo:hi]
-        if not getattr(self.engine, "inplace_gather", False):
-            own = own.clone()
-        dist.all_gather_into_tensor(buf, own, group=self.group)
+        with self._stream_ctx():
+            buf = self.engine.half[half]
+            lo, hi = self.engine.rows[half]
+            own = buf[lo:hi]
+            if not getattr(self.engine, "inplace_gather", False):
+                own = own.clone()
+            dist.all_gather_into_tensor(buf, own, group=self.group)
 
     def init(self, retry_sampling=100):
         self.engine.init(retry_sampling)
@@ -99,12 +118,21 @@ class ShardedAIS:
 
     def positions(self):
         """[N][D] positions in walker-id order (identical on every rank)."""
-        return torch.cat([self.engine.half[0], self.engine.half[1]], dim=0)
+        with self._stream_ctx():
+            out = torch.cat([self.engine.half[0], self.engine.half[1]], dim=0)
+        self.synchronize()
+        return out
+
+    def synchronize(self):
+        sync = getattr(self.engine, "synchronize", None)
+        if sync:
+            sync()
 
     def global_stats(self):
         st = self.engine.stats()
-        t = torch.tensor([st["proposals"], st["cost_evals"], st["accepted"]], dtype=torch.int64,
-                         device=self.engine.half[0].device)
-        if self.world > 1:
-            dist.all_reduce(t, group=self.group)
+        with self._stream_ctx():
+            t = torch.tensor([st["proposals"], st["cost_evals"], st["accepted"]],
+                             dtype=torch.int64, device=self.engine.half[0].device)
+            if self.world > 1:
+                dist.all_reduce(t, group=self.group)
         return dict(zip(("proposals", "cost_evals", "accepted"), (int(v) for v in t.tolist())))

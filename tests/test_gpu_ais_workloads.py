@@ -101,3 +101,42 @@ def test_sharded_driver_world1_on_gpu(k, orc, gpu_ctx):
     o.generations_sync(3, 7, collect=False)
     assert np.array_equal(pos, o.state()[0])
     assert sh.global_stats() == o.stats()
+
+
+def test_two_ranks_emulated_on_one_gpu(k, orc, gpu_ctx):
+    """The sharded kernel path for rank > 0 (row offsets, global walker ids, partner
+    draws over the GLOBAL complementary half): two world-2 handles share the same
+    global half buffers on one GPU, so no collective is needed; the result must
+    equal the single-process oracle bit for bit."""
+    import torch
+    from kissabc_jl_amd.sharded import HipEngine
+    U8 = k.Factored(*[k.Uniform(-5, 5)] * 8)
+    model = k.ApproxKernelizedPosterior(U8, k.costs.Rosenbrock(), 1.0)
+    N, nt, gens, seed = 2048, 5, 3, 17
+    dev = torch.device("cuda", 0)
+    e0 = HipEngine(model, N, seed, 0, 2, dev)
+    e1 = HipEngine(model, N, seed, 1, 2, dev, half_buffers=e0.half)
+    for e in (e0, e1):
+        e.init(100)
+        e.synchronize()
+    for _ in range(gens):
+        for half in (0, 1):
+            for e in (e0, e1):
+                e.half_generation(half, nt)
+                e.synchronize()
+        for e in (e0, e1):
+            e.end_generation(nt)
+    pos = torch.cat(e0.half, 0).cpu().numpy()
+    o = orc.OracleAIS(model, N, seed=seed).init()
+    o.generations_sync(gens, nt, collect=False)
+    xo, lpo, llo, _ = o.state()
+    assert np.array_equal(pos, xo)
+    # log-densities live with the owner: rank r owns rows [r*512, (r+1)*512) of each half
+    x0, lp0, ll0, _ = e0.ens.state()
+    x1, lp1, ll1, _ = e1.ens.state()
+    q = N // 4
+    lp = np.concatenate([lp0[:q], lp1[:q], lp0[q:], lp1[q:]])
+    ll = np.concatenate([ll0[:q], ll1[:q], ll0[q:], ll1[q:]])
+    assert np.array_equal(lp, lpo) and np.array_equal(ll, llo)
+    s0, s1 = e0.stats(), e1.stats()
+    assert {kk: s0[kk] + s1[kk] for kk in s0} == o.stats()
