@@ -68,6 +68,21 @@ KABC_HD double kabc_div_rc(double x, double c, double rc) {
     return kabc_fma(r, rc, q);
 }
 
+/* fma(a, b, C) with a compile-time constant C.  On gfx950 hipcc materialises every
+ * 64-bit literal of a Horner step into a VGPR pair (two v_mov_b32) because it
+ * selects the accumulating v_fmac form: 3 VALU per coefficient.  Pinning the
+ * constant to an SGPR pair (two SALU s_mov_b32, issued beside the vector pipe)
+ * makes it 1 VALU.  Same correctly rounded fma either way. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double kabc_fma_c(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+#else
+KABC_HD double kabc_fma_c(double a, double b, double c) { return kabc_fma(a, b, c); }
+#endif
+
 #define KABC_LN2_HI 0x1.62e42fee00000p-1
 #define KABC_LN2_LO 0x1.a39ef35793c76p-33
 #define KABC_INV_LN2 0x1.71547652b82fep+0
@@ -80,13 +95,13 @@ KABC_HD double kabc_div_rc(double x, double c, double rc) {
 /* R(z)/z for log, Chebyshev fit on z in [0, ((sqrt2-1)/(sqrt2+1))^2] */
 KABC_HD double kabc__log_poly(double z) {
     double r = 0x1.0c04595972ab8p-3;
-    r = kabc_fma(r, z, 0x1.0fbe83c2cbcf3p-3);
-    r = kabc_fma(r, z, 0x1.3b1c360763b8ap-3);
-    r = kabc_fma(r, z, 0x1.745cf901605f7p-3);
-    r = kabc_fma(r, z, 0x1.c71c720160b47p-3);
-    r = kabc_fma(r, z, 0x1.2492492476c87p-2);
-    r = kabc_fma(r, z, 0x1.9999999999a38p-2);
-    r = kabc_fma(r, z, 0x1.5555555555555p-1);
+    r = kabc_fma_c(r, z, 0x1.0fbe83c2cbcf3p-3);
+    r = kabc_fma_c(r, z, 0x1.3b1c360763b8ap-3);
+    r = kabc_fma_c(r, z, 0x1.745cf901605f7p-3);
+    r = kabc_fma_c(r, z, 0x1.c71c720160b47p-3);
+    r = kabc_fma_c(r, z, 0x1.2492492476c87p-2);
+    r = kabc_fma_c(r, z, 0x1.9999999999a38p-2);
+    r = kabc_fma_c(r, z, 0x1.5555555555555p-1);
     return r * z;
 }
 
@@ -115,6 +130,25 @@ KABC_HD double kabc_log(double x) {
     double z = s * s;
     double R = kabc__log_poly(z);
     double dk = (double)k;
+    return s * (hfsq + R) + dk * KABC_LN2_LO - hfsq + f + dk * KABC_LN2_HI;
+}
+
+/* kabc_log restricted to positive NORMAL finite x (every argument the walker
+ * update produces: u01 variates, the stretch factor Z, Gamma/Poisson internals);
+ * bit-identical to kabc_log there, without the zero/negative/subnormal/inf tests. */
+KABC_HD double kabc_log_pn(double x) {
+    const uint64_t ix = kabc_bits(x);
+    uint32_t hx = (uint32_t)(ix >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    x = kabc_from_bits(((uint64_t)hx << 32) | (ix & 0xffffffffULL));
+    const double f = x - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double R = kabc__log_poly(z);
+    const double dk = (double)k;
     return s * (hfsq + R) + dk * KABC_LN2_LO - hfsq + f + dk * KABC_LN2_HI;
 }
 
@@ -157,19 +191,19 @@ KABC_HD double kabc_exp(double x) {
     double r = kabc_fma(-kf, KABC_LN2_LO, hi);
     /* Taylor sum_{j<=13} r^j / j!, |r| <= ln2/2 */
     double p = 0x1.6124613a86d09p-33;
-    p = kabc_fma(p, r, 0x1.1eed8eff8d898p-29);
-    p = kabc_fma(p, r, 0x1.ae64567f544e4p-26);
-    p = kabc_fma(p, r, 0x1.27e4fb7789f5cp-22);
-    p = kabc_fma(p, r, 0x1.71de3a556c734p-19);
-    p = kabc_fma(p, r, 0x1.a01a01a01a01ap-16);
-    p = kabc_fma(p, r, 0x1.a01a01a01a01ap-13);
-    p = kabc_fma(p, r, 0x1.6c16c16c16c17p-10);
-    p = kabc_fma(p, r, 0x1.1111111111111p-7);
-    p = kabc_fma(p, r, 0x1.5555555555555p-5);
-    p = kabc_fma(p, r, 0x1.5555555555555p-3);
-    p = kabc_fma(p, r, 0.5);
-    p = kabc_fma(p, r, 1.0);
-    p = kabc_fma(p, r, 1.0);
+    p = kabc_fma_c(p, r, 0x1.1eed8eff8d898p-29);
+    p = kabc_fma_c(p, r, 0x1.ae64567f544e4p-26);
+    p = kabc_fma_c(p, r, 0x1.27e4fb7789f5cp-22);
+    p = kabc_fma_c(p, r, 0x1.71de3a556c734p-19);
+    p = kabc_fma_c(p, r, 0x1.a01a01a01a01ap-16);
+    p = kabc_fma_c(p, r, 0x1.a01a01a01a01ap-13);
+    p = kabc_fma_c(p, r, 0x1.6c16c16c16c17p-10);
+    p = kabc_fma_c(p, r, 0x1.1111111111111p-7);
+    p = kabc_fma_c(p, r, 0x1.5555555555555p-5);
+    p = kabc_fma_c(p, r, 0x1.5555555555555p-3);
+    p = kabc_fma_c(p, r, 0.5);
+    p = kabc_fma_c(p, r, 1.0);
+    p = kabc_fma_c(p, r, 1.0);
     if (k > 1022) return p * 0x1p1022 * kabc__pow2i(k - 1022);
     if (k < -1021) return p * 0x1p-1021 * kabc__pow2i(k + 1021);
     return p * kabc__pow2i(k);
@@ -182,22 +216,22 @@ KABC_HD void kabc_sincos2pi(double u, double* sn, double* cs) {
     double x = (t - j) * KABC_PIO2; /* |x| <= pi/4 */
     double w = x * x;
     double sp = 0x1.952c77030ad4ap-49;
-    sp = kabc_fma(sp, w, -0x1.ae7f3e733b81fp-41);
-    sp = kabc_fma(sp, w, 0x1.6124613a86d09p-33);
-    sp = kabc_fma(sp, w, -0x1.ae64567f544e4p-26);
-    sp = kabc_fma(sp, w, 0x1.71de3a556c734p-19);
-    sp = kabc_fma(sp, w, -0x1.a01a01a01a01ap-13);
-    sp = kabc_fma(sp, w, 0x1.1111111111111p-7);
-    sp = kabc_fma(sp, w, -0x1.5555555555555p-3);
+    sp = kabc_fma_c(sp, w, -0x1.ae7f3e733b81fp-41);
+    sp = kabc_fma_c(sp, w, 0x1.6124613a86d09p-33);
+    sp = kabc_fma_c(sp, w, -0x1.ae64567f544e4p-26);
+    sp = kabc_fma_c(sp, w, 0x1.71de3a556c734p-19);
+    sp = kabc_fma_c(sp, w, -0x1.a01a01a01a01ap-13);
+    sp = kabc_fma_c(sp, w, 0x1.1111111111111p-7);
+    sp = kabc_fma_c(sp, w, -0x1.5555555555555p-3);
     double s = kabc_fma(sp * w, x, x);
     double cp = 0x1.ae7f3e733b81fp-45;
-    cp = kabc_fma(cp, w, -0x1.93974a8c07c9dp-37);
-    cp = kabc_fma(cp, w, 0x1.1eed8eff8d898p-29);
-    cp = kabc_fma(cp, w, -0x1.27e4fb7789f5cp-22);
-    cp = kabc_fma(cp, w, 0x1.a01a01a01a01ap-16);
-    cp = kabc_fma(cp, w, -0x1.6c16c16c16c17p-10);
-    cp = kabc_fma(cp, w, 0x1.5555555555555p-5);
-    cp = kabc_fma(cp, w, -0.5);
+    cp = kabc_fma_c(cp, w, -0x1.93974a8c07c9dp-37);
+    cp = kabc_fma_c(cp, w, 0x1.1eed8eff8d898p-29);
+    cp = kabc_fma_c(cp, w, -0x1.27e4fb7789f5cp-22);
+    cp = kabc_fma_c(cp, w, 0x1.a01a01a01a01ap-16);
+    cp = kabc_fma_c(cp, w, -0x1.6c16c16c16c17p-10);
+    cp = kabc_fma_c(cp, w, 0x1.5555555555555p-5);
+    cp = kabc_fma_c(cp, w, -0.5);
     double c = kabc_fma(cp, w, 1.0);
     int q = ((int)j) & 3;
     double ss = (q & 1) ? c : s;
@@ -224,13 +258,13 @@ KABC_HD double kabc_lgamma(double x) {
     double iy = 1.0 / y;
     double w = iy * iy;
     double st = -0x1.e4286cb0f5398p-6;
-    st = kabc_fma(st, w, 0x1.a41a41a41a41ap-8);
-    st = kabc_fma(st, w, -0x1.f6ab0d9993c7dp-10);
-    st = kabc_fma(st, w, 0x1.b951e2b18ff23p-11);
-    st = kabc_fma(st, w, -0x1.3813813813814p-11);
-    st = kabc_fma(st, w, 0x1.a01a01a01a01ap-11);
-    st = kabc_fma(st, w, -0x1.6c16c16c16c17p-9);
-    st = kabc_fma(st, w, 0x1.5555555555555p-4);
+    st = kabc_fma_c(st, w, 0x1.a41a41a41a41ap-8);
+    st = kabc_fma_c(st, w, -0x1.f6ab0d9993c7dp-10);
+    st = kabc_fma_c(st, w, 0x1.b951e2b18ff23p-11);
+    st = kabc_fma_c(st, w, -0x1.3813813813814p-11);
+    st = kabc_fma_c(st, w, 0x1.a01a01a01a01ap-11);
+    st = kabc_fma_c(st, w, -0x1.6c16c16c16c17p-9);
+    st = kabc_fma_c(st, w, 0x1.5555555555555p-4);
     double ly = kabc_log(y);
     double r = (y - 0.5) * ly - y + KABC_HALF_LOG_2PI + st * iy;
     return (p == 1.0) ? r : r - kabc_log(p);
@@ -253,7 +287,7 @@ KABC_HD uint64_t kabc_index(uint64_t r, uint64_t n) {
 KABC_HD void kabc_normal_pair(uint64_t r0, uint64_t r1, double* z0, double* z1) {
     double u1 = kabc_u01(r0);
     double u2 = kabc_u01(r1);
-    double rad = kabc_sqrt(-2.0 * kabc_log(u1));
+    double rad = kabc_sqrt(-2.0 * kabc_log_pn(u1));
     double s, c;
     kabc_sincos2pi(u2, &s, &c);
     *z0 = rad * c;

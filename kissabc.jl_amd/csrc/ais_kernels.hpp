@@ -205,7 +205,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         const uint32_t m7 = (uint32_t)(((uint64_t)B0.w[2] * 7u) >> 32);  // rand((1,1,1,1,2,2,3))
         move = (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
         a = (uint32_t)kabc_index(kabc_lo64(B0), nc);
-        R.logu[si][lane] = kabc_log(kabc_u01(kabc_lo64(B1)));
+        R.logu[si][lane] = kabc_log_pn(kabc_u01(kabc_lo64(B1)));
         if (move == 1) {
             // Z = cdf_g_inv(rand(rng), 3.0); correction (D-1) log Z
             const double sq3 = kabc_sqrt(3.0), isq3 = kabc_sqrt(1.0 / 3.0);
@@ -213,7 +213,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
             const double tz = u * (sq3 - isq3) + isq3;
             const double Z = tz * tz;
             R.zs[si][0][lane] = Z;
-            R.zs[si][1][lane] = (double)(D - 1) * kabc_log(Z);
+            R.zs[si][1][lane] = (double)(D - 1) * kabc_log_pn(Z);
         }
     }
     R.mva[si][lane] = ((uint32_t)move << 30) | a;

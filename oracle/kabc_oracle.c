@@ -83,6 +83,7 @@ void orc_math_vec(int32_t fn, int64_t n, const double* x, double* out) {
             } break;
             case 5: out[i] = kabc_sqrt(x[i]); break;
             case 6: out[i] = kabc_rint(x[i]); break;
+            case 7: out[i] = kabc_log_pn(x[i]); break;
             default: out[i] = KABC_NAN;
         }
     }
@@ -476,7 +477,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
             double W = (xi[k] - xa[k]) * Z; /* op(*, op(-, p[i], p[a]), Z) */
             y[k] = xa[k] + W;               /* op(+, p[a], W)              */
         }
-        corr = (double)(D - 1) * kabc_log(Z);
+        corr = (double)(D - 1) * kabc_log_pn(Z);
     } else if (move == 2) {
         /* de_propose :2-22 */
         blk_t B2 = stream(h->seed, w, t, 2, KABC_DOM_AIS_MOVE);
@@ -530,7 +531,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
     if (!kabc_isfinite(corr)) return -1; /* "ld_correction is invalid" */
     if (!is_valid(h, old)) return -2;    /* "starting sample invalid." */
     if (is_valid(h, nw)) {
-        double e = -kabc_log(kabc_u01(B1.lo)); /* randexp(rng) */
+        double e = -kabc_log_pn(kabc_u01(B1.lo)); /* randexp(rng) */
         if (h->posterior == KABC_POSTERIOR_KERNELIZED) {
             double lW = corr + (nw.lp + nw.ll) - (old.lp + old.ll);
             acc = (-e <= lW);

@@ -91,7 +91,7 @@ def _dp(a):
     return a.ctypes.data_as(cd.c_double_p)
 
 
-MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6}
+MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6, "log_pn": 7}
 
 
 def math_vec(name, x):

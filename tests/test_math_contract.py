@@ -53,6 +53,13 @@ def test_log_exp_log1p_within_1ulp_of_libm(orc):
     assert ulp_diff(orc.math_vec("log1p", z), np.log1p(z)).max() <= 1.0
 
 
+def test_log_pn_is_log_on_positive_normals(orc):
+    x = np.ldexp(rng.random(300000) + 0.5, rng.integers(-1020, 1020, 300000))
+    assert np.array_equal(orc.math_vec("log_pn", x), orc.math_vec("log", x))
+    u = (rng.integers(0, 2 ** 52, 300000).astype(np.float64) + 0.5) * 2.0 ** -52
+    assert np.array_equal(orc.math_vec("log_pn", u), orc.math_vec("log", u))
+
+
 def test_math_special_values(orc):
     with np.errstate(all="ignore"):
         x = np.array([0.0, -0.0, -1.0, np.inf, np.nan, 5e-324, 1.0, 2.2250738585072014e-308])
