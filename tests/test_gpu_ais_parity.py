@@ -9,7 +9,32 @@ pytestmark = pytest.mark.gpu
 def _models(k):
     U8 = k.Factored(*[k.Uniform(-5, 5)] * 8)
     N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    rng = np.random.default_rng(7)
+    H16 = k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 14)
+    socks = k.Factored(k.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), k.Beta(15, 2))
+    mixed = k.Factored(k.Gamma(2.5, 0.7), k.LogNormal(0.3, 0.6), k.Exponential(2.0),
+                       k.DiscreteUniform(1, 10), k.TruncatedNormal(0, 1, -1, 2))
     return {
+        # every prior class x posterior kind x deterministic / stochastic cost, D = 1 .. 16
+        "d1_dirac_kernelized": (k.ApproxKernelizedPosterior(k.Normal(1, 0.2), k.costs.DiracSq(1.5),
+                                                            0.001), 12),
+        "d1_mixture_threshold": (k.ApproxPosterior(k.Uniform(-10, 10), k.costs.Mixture(0.0), 0.5), 50),
+        "d2_readme_sim": (k.ApproxKernelizedPosterior(
+            k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100)),
+            k.costs.NormalMeanStdSim(200, 2.0, 0.04), 0.005), 10),
+        "d2_discrete_threshold": (k.ApproxPosterior(
+            k.Factored(k.Normal(1, 0.5), k.DiscreteUniform(1, 10)), k.costs.NoisyQuadDU(5.5), 0.5), 100),
+        "d2_general_negbin_beta": (k.ApproxKernelizedPosterior(socks, k.costs.GaussDist([40.0, 0.8]),
+                                                               3.0), 200),
+        "d5_general_mixed": (k.ApproxKernelizedPosterior(mixed, k.costs.NormShell(3.0), 0.5), 333),
+        "d16_hier_sim": (k.ApproxKernelizedPosterior(H16, k.costs.HierGaussSim(rng.normal(size=14)),
+                                                     0.3), 640),
+        "d16_box": (k.ApproxKernelizedPosterior(k.Factored(*[k.Uniform(-3, 3)] * 16),
+                                                k.costs.Rosenbrock(), 2.0), 130),
+        "d2_wiener": (k.ApproxPosterior(k.Factored(k.Uniform(0, 1), k.Uniform(0, 4)),
+                                        k.costs.WienerRms(np.sqrt(0.25 * np.arange(31.0) ** 2
+                                                                  + 4.0 * np.arange(31.0))), 0.5), 50),
+        "d2_banana_inf": (k.ApproxKernelizedPosterior(N2, k.costs.NoisyBanana(0.5), 5.0), 64),
         "C3_rosenbrock_d8": (k.ApproxKernelizedPosterior(U8, k.costs.Rosenbrock(), 1.0), 2048),
         "C2_gauss_d2": (k.ApproxKernelizedPosterior(N2, k.costs.GaussDist([1.0, -0.5]), 0.1), 4096),
         "threshold_d2": (k.ApproxPosterior(N2, k.costs.GaussDist([1.0, -0.5]), 0.5), 1000),
@@ -19,10 +44,15 @@ def _models(k):
     }
 
 
-@pytest.mark.parametrize("name", ["C3_rosenbrock_d8", "C2_gauss_d2", "threshold_d2", "odd_N_d3"])
+NAMES = ["C3_rosenbrock_d8", "C2_gauss_d2", "threshold_d2", "odd_N_d3", "d1_dirac_kernelized",
+         "d1_mixture_threshold", "d2_readme_sim", "d2_discrete_threshold", "d2_general_negbin_beta",
+         "d5_general_mixed", "d16_hier_sim", "d16_box", "d2_wiener", "d2_banana_inf"]
+
+
+@pytest.mark.parametrize("name", NAMES)
 def test_ais_generation_bit_exact(k, orc, gpu_ctx, name):
     model, N = _models(k)[name]
-    nt, gens, seed = 5, 4, 11
+    nt, gens, seed = (1 if name == "d1_dirac_kernelized" else 5), 4, 11
     ens = k.AisEnsemble(model, N, seed=seed).init()
     o = orc.OracleAIS(model, N, seed=seed).init()
     # init parity (step(init), src/KissABC.jl:35-64)
