@@ -119,6 +119,14 @@ kabc_status_t kabc_factored_rand(kabc_ctx_t* ctx, const kabc_prior_t* prior, int
                                  uint64_t seed, uint32_t domain, int64_t first_walker, int64_t n,
                                  uint64_t attempt, double* out);
 
+/* ---- user DeviceCost plugins ------------------------------------------------
+ * Replaces "cost is an arbitrary closure" (src/types.jl:124,137; src/smc.jl:94) for
+ * costs that can be written as a C function (signature: include/kabc_costs.h,
+ * KABC_COST_USER).  `path` is a shared library built from the user's snippet +
+ * kissabc.jl_amd/csrc/user_plugin.inc with hipcc --offload-arch=gfx950; on success
+ * *out_cost_id (>= 100) is the id to put into kabc_cost_t.id. */
+kabc_status_t kabc_register_cost_plugin(const char* path, int32_t* out_cost_id);
+
 /* ---- AIS: sample(model, AIS(N), Ns; ntransitions, discard_initial, retry_sampling)
  *
  * Ensemble layout.  Walker ids g = 0..N-1.  Half 0 = ids [0, N0), half 1 = ids

@@ -30,7 +30,13 @@ enum {
     KABC_COST_MIXTURE = 9,            /* test/runtests.jl:145-146: |mu + rand((0.1 randn, randn)) - target| */
     KABC_COST_NOISY_BANANA = 10,      /* test/runtests.jl:242,248: noisy Rosenbrock, optional Inf   */
     KABC_COST_WIENER_RMS = 11,        /* test/runtests.jl:116-126: drifted Wiener RMS curve         */
-    KABC_COST__COUNT = 12
+    KABC_COST__COUNT = 12,
+    /* ids >= KABC_COST_USER are user DeviceCosts compiled at run time from a C snippet
+     * (kabc_register_cost_plugin, include/kabc.h).  The snippet defines
+     *   KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
+     *                                 const double* data, int64_t ndata, kabc_cost_rng_t* rng);
+     * and may use everything in kabc_math.h / kabc_philox.h. */
+    KABC_COST_USER = 100
 };
 
 /* does the cost consume random numbers? (host-side bookkeeping only) */
@@ -181,7 +187,11 @@ KABC_HD double kabc_cost_eval(int id, const double* x, int D, const double* para
         case KABC_COST_MIXTURE: return kabc_cost_mixture(x, params, rng);
         case KABC_COST_NOISY_BANANA: return kabc_cost_noisy_banana(x, params, rng);
         case KABC_COST_WIENER_RMS: return kabc_cost_wiener_rms(x, data, ndata, rng);
-        default: return KABC_NAN;
+        default:
+#ifdef KABC_USER_COST_DEFINED
+            if (id >= KABC_COST_USER) return kabc_user_cost(x, D, params, data, ndata, rng);
+#endif
+            return KABC_NAN;
     }
 }
 
@@ -199,7 +209,7 @@ KABC_HD int kabc_cost_dim_ok(int id, int D) {
         case KABC_COST_MIXTURE: return D == 1;
         case KABC_COST_NOISY_BANANA: return D == 2;
         case KABC_COST_WIENER_RMS: return D == 2;
-        default: return 0;
+        default: return 0; /* user costs: decided by the plugin registry */
     }
 }
 

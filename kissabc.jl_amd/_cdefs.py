@@ -83,6 +83,7 @@ PROTOTYPES = {
                                        c_double_p]),
     "kabc_factored_rand": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.c_uint64, C.c_uint32,
                                      C.c_int64, C.c_int64, C.c_uint64, c_double_p]),
+    "kabc_register_cost_plugin": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "kabc_ais_create": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_uint64, C.POINTER(VP)]),
     "kabc_ais_create_sharded": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_int32, C.c_int32,
                                           C.c_uint64, VP, VP, C.POINTER(VP)]),

@@ -6,6 +6,7 @@
 
 #include "ais_kernels.hpp"
 #include "host_common.hpp"
+#include "plugin_registry.hpp"
 
 namespace kabc {
 
@@ -35,7 +36,10 @@ AisLaunchFn find_ais_kernel(int cost_id, int D, int pc) {
         case 9: return find_ais_kernel_cost_9(D, pc);
         case 10: return find_ais_kernel_cost_10(D, pc);
         case 11: return find_ais_kernel_cost_11(D, pc);
-        default: return nullptr;
+        default: {
+            const CostPlugin* p = find_plugin(cost_id);
+            return p ? (AisLaunchFn)p->ais(D, pc) : nullptr;
+        }
     }
 }
 
@@ -55,6 +59,11 @@ static void launch_init_table(int D, const InitArgs& a, hipStream_t s,
 }
 
 void launch_ais_init(int D, const InitArgs& a, hipStream_t s) {
+    if (const CostPlugin* p = find_plugin(a.cost_id)) {
+        using Fn = void (*)(const InitArgs&, hipStream_t);
+        if (Fn f = (Fn)p->ais_init(D)) f(a, s);
+        return;
+    }
     launch_init_table(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
 }
 
@@ -140,7 +149,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
                   (long long)n_total, world);
         return KABC_ERR_INVALID_ARG;
     }
-    if (!kabc_cost_dim_ok(m->cost.id, m->D)) {
+    if (!cost_dim_ok_rt(m->cost.id, m->D)) {
         set_error("DeviceCost id %d does not accept D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
     }

@@ -7,6 +7,7 @@
 
 #define KABC_SMC_SINGLE_UNIT 1
 #include "host_common.hpp"
+#include "plugin_registry.hpp"
 #include "smc_kernels.hpp"
 
 namespace kabc {
@@ -37,7 +38,10 @@ SmcLaunchFn find_smc_kernel(int cost_id, int D, bool simple) {
         case 9: return find_smc_kernel_cost_9(D, simple);
         case 10: return find_smc_kernel_cost_10(D, simple);
         case 11: return find_smc_kernel_cost_11(D, simple);
-        default: return nullptr;
+        default: {
+            const CostPlugin* p = find_plugin(cost_id);
+            return p ? (SmcLaunchFn)p->smc(D, simple ? 1 : 0) : nullptr;
+        }
     }
 }
 
@@ -122,7 +126,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         set_error("invalid prior parameters");
         return KABC_ERR_INVALID_ARG;
     }
-    if (!kabc_cost_dim_ok(cost->id, D)) {
+    if (!cost_dim_ok_rt(cost->id, D)) {
         set_error("DeviceCost id %d does not accept D = %d", cost->id, D);
         return KABC_ERR_UNSUPPORTED;
     }
@@ -204,7 +208,12 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         a.cost_id = cost->id;
         a.prior = P;
         std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
-        launch_smc_init(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+        if (const CostPlugin* pl = find_plugin(cost->id)) {
+            using Fn = void (*)(const SmcInitArgs&, hipStream_t);
+            if (Fn f = (Fn)pl->smc_init(D)) f(a, s);
+        } else {
+            launch_smc_init(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+        }
         KABC_HIP_CHECK(hipGetLastError());
     }
     SmcSelectArgs sa;

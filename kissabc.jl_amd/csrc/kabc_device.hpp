@@ -157,6 +157,9 @@ __device__ __forceinline__ double eval_cost(const double* xp, const double* __re
     else if constexpr (COST == KABC_COST_MIXTURE) return kabc_cost_mixture(xp, params, rng);
     else if constexpr (COST == KABC_COST_NOISY_BANANA) return kabc_cost_noisy_banana(xp, params, rng);
     else if constexpr (COST == KABC_COST_WIENER_RMS) return kabc_cost_wiener_rms(xp, data, ndata, rng);
+#ifdef KABC_USER_COST_DEFINED
+    else if constexpr (COST == KABC_COST_USER) return kabc_user_cost(xp, D, params, data, ndata, rng);
+#endif
     else return KABC_NAN;
 }
 
@@ -209,6 +212,9 @@ constexpr bool cost_dim_ok_c(int id, int D) {
         case KABC_COST_MIXTURE: return D == 1;
         case KABC_COST_NOISY_BANANA: return D == 2;
         case KABC_COST_WIENER_RMS: return D == 2;
+#ifdef KABC_USER_DIM_OK
+        case KABC_COST_USER: return KABC_USER_DIM_OK(D);
+#endif
         default: return false;
     }
 }

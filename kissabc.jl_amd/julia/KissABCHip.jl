@@ -99,6 +99,29 @@ NoisyBanana(p = 0.0) = DeviceCost(Int32(10), [Float64(p)], Float64[],
 # ... the remaining ids (hier_gauss_sim, normal_meanstd_sim, noisy_quad_du, mixture,
 # wiener_rms) follow the same pattern.
 
+"""
+    UserCost(csrc, dims; params, data, cpu)
+A DeviceCost from a C snippet defining `kabc_user_cost` (include/kabc_costs.h,
+KABC_COST_USER): compiled with hipcc for gfx950 together with csrc/user_plugin.inc and
+registered with `kabc_register_cost_plugin`.  `cpu` is the Julia closure with the same
+formula (used when the model runs through KissABC's own AIS/smc).
+"""
+function UserCost(csrc::String, dims; params = Float64[], data = Float64[], cpu = x -> NaN)
+    root = normpath(joinpath(@__DIR__, "..", ".."))
+    cond = join(("(D) == \$d" for d in dims), " || ")
+    text = "#define KABC_USER_DIM_OK(D) (\$cond)\n#include <hip/hip_runtime.h>\n" *
+           "#include \"kabc_philox.h\"\n" * csrc *
+           "\n#define KABC_USER_COST_DEFINED 1\n#include \"user_plugin.inc\"\n"
+    dir = mktempdir(); src = joinpath(dir, "user.hip"); so = joinpath(dir, "libkabc_user.so")
+    write(src, text)
+    run(`/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950
+         -I \$(joinpath(root, "include")) -I \$(joinpath(root, "kissabc.jl_amd", "csrc"))
+         -shared -o \$so \$src`)
+    id = Ref{Int32}(0)
+    check(ccall((:kabc_register_cost_plugin, libkabc), Cint, (Cstring, Ref{Int32}), so, id))
+    DeviceCost(id[], collect(Float64, params), collect(Float64, data), cpu)
+end
+
 # ---- Factored / Distributions -> kabc_prior_t --------------------------------
 lower(d::Uniform) = KabcPrior(1, 0, (d.a, d.b, 0.0, 0.0))
 lower(d::Normal) = KabcPrior(2, 0, (d.μ, d.σ, 0.0, 0.0))
@@ -217,5 +240,5 @@ function KissABC.smc(prior::Distribution, cost::DeviceCost; rng = Random.GLOBAL_
     (P = P, C = C, ϵ = r.eps)
 end
 
-export AISHip, DeviceCost, GaussDist, Rosenbrock, DiracSq, AbsDiff, NormShell, NoisyBanana
+export AISHip, DeviceCost, UserCost, GaussDist, Rosenbrock, DiracSq, AbsDiff, NormShell, NoisyBanana
 end # module

@@ -270,9 +270,27 @@ int32_t orc_factored_rand(const kabc_prior_t* prior, int32_t D, uint64_t seed, u
     return KABC_OK;
 }
 
+/* user DeviceCosts (ids >= KABC_COST_USER): the same C snippet the device plugin is
+ * built from, compiled with gcc by oracle.py and registered here */
+typedef double (*orc_user_cost_fn)(const double*, int, const double*, const double*, int64_t,
+                                   kabc_cost_rng_t*);
+static orc_user_cost_fn g_user_cost[64];
+int32_t orc_register_user_cost(int32_t id, void* fn) {
+    if (id < KABC_COST_USER || id >= KABC_COST_USER + 64) return fail(KABC_ERR_INVALID_ARG, "bad user cost id");
+    g_user_cost[id - KABC_COST_USER] = (orc_user_cost_fn)fn;
+    return KABC_OK;
+}
+static int cost_dim_ok_any(int id, int D) {
+    if (id >= KABC_COST_USER) return id < KABC_COST_USER + 64 && g_user_cost[id - KABC_COST_USER] != 0;
+    return kabc_cost_dim_ok(id, D);
+}
+
 double orc_cost_eval(const kabc_cost_t* cost, int32_t D, const double* x, uint64_t seed,
                      uint32_t walker, uint64_t t, uint32_t domain) {
     kabc_cost_rng_t rng = {seed, t, walker, domain, 0};
+    if (cost->id >= KABC_COST_USER)
+        return g_user_cost[cost->id - KABC_COST_USER](x, D, cost->params, cost->data, cost->ndata,
+                                                      &rng);
     return kabc_cost_eval(cost->id, x, D, cost->params, cost->data, cost->ndata, &rng);
 }
 
@@ -348,7 +366,7 @@ int32_t orc_ais_create(const kabc_model_t* m, int64_t N, uint64_t seed, orc_ais_
                  (long long)N, m->D + 5);
         return KABC_ERR_INVALID_ARG;
     }
-    if (!kabc_cost_dim_ok(m->cost.id, m->D))
+    if (!cost_dim_ok_any(m->cost.id, m->D))
         return fail(KABC_ERR_UNSUPPORTED, "cost id / dimension not supported");
     orc_ais_t* h = (orc_ais_t*)calloc(1, sizeof *h);
     h->D = m->D;
@@ -723,7 +741,7 @@ int32_t orc_smc_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cos
     if (!(o->max_stretch > 1)) return fail(KABC_ERR_INVALID_ARG, "max_stretch must be > 1");
     prep_t q[KABC_MAX_DIM];
     if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
-    if (!kabc_cost_dim_ok(cost->id, D))
+    if (!cost_dim_ok_any(cost->id, D))
         return fail(KABC_ERR_UNSUPPORTED, "cost id / dimension not supported");
     {
         double mn = alpha < min_r_ess ? alpha : min_r_ess;

@@ -58,6 +58,7 @@ def load():
             "orc_cost_eval": (C.c_double, [C.POINTER(cd.Cost), C.c_int32, dp, C.c_uint64,
                                            C.c_uint32, C.c_uint64, C.c_uint32]),
             "orc_cdf_g_inv": (C.c_double, [C.c_double, C.c_double]),
+            "orc_register_user_cost": (C.c_int32, [C.c_int32, C.c_void_p]),
             "orc_ais_create": (C.c_int32, [C.POINTER(cd.Model), C.c_int64, C.c_uint64,
                                            C.POINTER(VP)]),
             "orc_ais_init": (C.c_int32, [VP, C.c_int32]),
@@ -163,6 +164,34 @@ def cost_eval(cost, x, seed=0, walker=0, t=0, domain=cd.DOM_AIS_COST):
     x = np.ascontiguousarray(x, dtype=np.float64)
     cc = cost.to_c()
     return load().orc_cost_eval(C.byref(cc), x.size, _dp(x), seed, walker, t, domain)
+
+
+_user_libs = {}
+
+
+def register_user_cost(cost):
+    """Compile the C snippet of a kissabc_jl_amd.costs.UserCost with gcc and register
+    it under the same id, so that the oracle evaluates the same user function."""
+    import hashlib
+    text = ('#include "kabc_philox.h"\n' + cost.source +
+            "\ndouble orc_user_cost_entry(const double* x, int D, const double* params, "
+            "const double* data, int64_t ndata, kabc_cost_rng_t* rng) {\n"
+            "    return kabc_user_cost(x, D, params, data, ndata, rng);\n}\n")
+    tag = hashlib.sha1(text.encode()).hexdigest()[:16]
+    bdir = os.path.join(_HERE, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    so = os.path.join(bdir, f"libuser_{tag}.so")
+    if not os.path.exists(so):
+        src = os.path.join(bdir, f"user_{tag}.c")
+        with open(src, "w") as f:
+            f.write(text)
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-ffp-contract=off", "-mfma",
+                               "-I", os.path.join(os.path.dirname(_HERE), "include"), "-shared",
+                               "-o", so, src, "-lm"])
+    lib = _user_libs.get(so) or C.CDLL(so)
+    _user_libs[so] = lib
+    fn = C.cast(lib.orc_user_cost_entry, C.c_void_p)
+    _check(load().orc_register_user_cost(cost.id, fn))
 
 
 def cdf_g_inv(u, a):
