@@ -108,15 +108,15 @@ formula (used when the model runs through KissABC's own AIS/smc).
 """
 function UserCost(csrc::String, dims; params = Float64[], data = Float64[], cpu = x -> NaN)
     root = normpath(joinpath(@__DIR__, "..", ".."))
-    cond = join(("(D) == \$d" for d in dims), " || ")
-    text = "#define KABC_USER_DIM_OK(D) (\$cond)\n#include <hip/hip_runtime.h>\n" *
+    cond = join(("(D) == $d" for d in dims), " || ")
+    text = "#define KABC_USER_DIM_OK(D) ($cond)\n#include <hip/hip_runtime.h>\n" *
            "#include \"kabc_philox.h\"\n" * csrc *
            "\n#define KABC_USER_COST_DEFINED 1\n#include \"user_plugin.inc\"\n"
     dir = mktempdir(); src = joinpath(dir, "user.hip"); so = joinpath(dir, "libkabc_user.so")
     write(src, text)
     run(`/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950
-         -I \$(joinpath(root, "include")) -I \$(joinpath(root, "kissabc.jl_amd", "csrc"))
-         -shared -o \$so \$src`)
+         -I $(joinpath(root, "include")) -I $(joinpath(root, "kissabc.jl_amd", "csrc"))
+         -shared -o $so $src`)
     id = Ref{Int32}(0)
     check(ccall((:kabc_register_cost_plugin, libkabc), Cint, (Cstring, Ref{Int32}), so, id))
     DeviceCost(id[], collect(Float64, params), collect(Float64, data), cpu)
