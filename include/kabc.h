@@ -72,7 +72,11 @@ typedef struct kabc_cost {
 
 typedef enum kabc_posterior_kind {
     KABC_POSTERIOR_KERNELIZED = 1, /* ApproxKernelizedPosterior, src/types.jl:122-157; eps = scale   */
-    KABC_POSTERIOR_THRESHOLD = 2   /* ApproxPosterior,           src/types.jl:158-186; eps = maxcost */
+    KABC_POSTERIOR_THRESHOLD = 2,  /* ApproxPosterior,           src/types.jl:158-186; eps = maxcost */
+    /* CommonLogDensity(nparameters, sample_init, lπ), src/types.jl:187-210: plain MCMC on a
+     * log-density.  `cost` IS lπ (returns the log-density), `prior` describes sample_init
+     * (used only by step(init)); no push_p, no prior term, eps unused. */
+    KABC_POSTERIOR_COMMON = 3
 } kabc_posterior_kind_t;
 
 /* ApproxKernelizedPosterior(prior, cost, scale) / ApproxPosterior(prior, cost, maxcost) */

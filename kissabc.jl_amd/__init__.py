@@ -7,7 +7,8 @@ module kissabc_jl_amd.py registers this package under that name).
 from . import costs
 from ._cdefs import KABC_MAX_DIM
 from ._lib import Context, KabcError, LIB_PATH, default_context
-from .api import (AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, MCMCThreads,
+from .api import (AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity,
+                  MCMCThreads,
                   Particles, sample, smc)
 from .costs import DeviceCost
 from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, LogNormal,
@@ -15,7 +16,8 @@ from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma,
                             truncated)
 
 __all__ = [
-    "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "MCMCThreads",
+    "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "CommonLogDensity",
+    "MCMCThreads",
     "Particles", "sample", "smc", "DeviceCost", "costs", "Factored", "Uniform", "Normal",
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
     "Exponential", "Gamma", "LogNormal", "Context", "KabcError", "default_context", "LIB_PATH",

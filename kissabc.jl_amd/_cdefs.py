@@ -15,7 +15,7 @@ KABC_OK, KABC_ERR_INVALID_ARG, KABC_ERR_RETRY_EXHAUSTED, KABC_ERR_INVALID_STATE,
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_BETA, PRIOR_DISCRETE_UNIFORM, \
     PRIOR_NEGBINOMIAL, PRIOR_EXPONENTIAL, PRIOR_GAMMA, PRIOR_LOGNORMAL = range(1, 10)
 
-POSTERIOR_KERNELIZED, POSTERIOR_THRESHOLD = 1, 2
+POSTERIOR_KERNELIZED, POSTERIOR_THRESHOLD, POSTERIOR_COMMON = 1, 2, 3
 
 # DeviceCost ids (include/kabc_costs.h)
 COST_GAUSS_DIST, COST_ROSENBROCK, COST_HIER_GAUSS_SIM, COST_NORMAL_MEANSTD_SIM, COST_DIRAC_SQ, \

@@ -95,6 +95,24 @@ class ApproxPosterior(_ApproxModel):
         return self.eps
 
 
+class CommonLogDensity(_ApproxModel):
+    """CommonLogDensity(nparameters, sample_init, lπ) -- src/types.jl:187-210, 233-243:
+    classical MCMC on a log-density.  On the device path `lπ` is a DeviceCost that
+    RETURNS THE LOG-DENSITY (built-in or costs.UserCost) and `sample_init` is a
+    Factored / univariate distribution the initial walkers are drawn from
+    (the reference takes an arbitrary `rng -> sample` closure)."""
+    posterior = cd.POSTERIOR_COMMON
+
+    def __init__(self, nparameters, sample_init, lpi):
+        super().__init__(sample_init, lpi, 1.0)
+        if len(self.prior) != int(nparameters):
+            raise ValueError("nparameters must equal the length of sample_init")
+
+    @property
+    def lπ(self):
+        return self.cost
+
+
 class AIS:
     """AIS(nparticles) -- src/KissABC.jl:21-23"""
 

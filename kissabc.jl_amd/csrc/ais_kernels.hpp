@@ -111,8 +111,9 @@ struct ChunkRec {
 template <int POSTERIOR_RUNTIME = 0>
 __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
     // is_valid_logdensity: src/types.jl:142 and :175-176
-    return posterior == KABC_POSTERIOR_KERNELIZED ? kabc_isfinite(lp + ll)
-                                                  : (kabc_isfinite(ll) && kabc_isfinite(lp));
+    // (CommonLogDensity, :203: isfinite(ld), held as lp = 0, ll = lπ)
+    return posterior != KABC_POSTERIOR_THRESHOLD ? kabc_isfinite(lp + ll)
+                                                 : (kabc_isfinite(ll) && kabc_isfinite(lp));
 }
 
 // Prior classes (chosen on the host, identical results):
@@ -138,6 +139,14 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
                                         int64_t ndata, kabc_cost_rng_t* rng, double& lp,
                                         double& ll, bool& ev) {
     double yp[D];
+    if (posterior == KABC_POSTERIOR_COMMON) {
+        // loglike(density::CommonLogDensity, sample) = lπ(sample.x)  src/types.jl:199-201;
+        // push_p is the identity for a plain AbstractDensity (:109)
+        lp = 0.0;
+        ev = true;
+        ll = eval_cost<COST, D>(y, cost_params, cost_data, ndata, rng);
+        return;
+    }
     if constexpr (PC == kPriorBox) {
         double lo[D], hi[D];
 #pragma unroll
@@ -428,6 +437,9 @@ ais_half_kernel(const AisArgs A) {
                     if (A.posterior == KABC_POSTERIOR_KERNELIZED) {
                         const double lW = corr + (nlp + nll) - (lp + ll);
                         acc = (-e <= lW);
+                    } else if (A.posterior == KABC_POSTERIOR_COMMON) {
+                        const double lW = corr + nll - ll;  // src/types.jl:209
+                        acc = (-e <= lW);
                     } else {
                         const double lW = corr + nlp - lp;
                         const double mx = (A.eps > ll) ? A.eps : ll;
@@ -470,7 +482,8 @@ ais_half_kernel(const AisArgs A) {
                 double xp[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k)
-                    xp[k] = sprior[k].discrete ? kabc_rint(x[k]) : x[k];
+                    xp[k] = (sprior[k].discrete && A.posterior != KABC_POSTERIOR_COMMON)
+                                ? kabc_rint(x[k]) : x[k];
                 store_row<D>(A.trace + r * D, xp);
             }
         }
@@ -506,7 +519,10 @@ __global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) 
         }
         lp = factored_logpdf_push<D>(A.prior, x, xp);
         kabc_cost_rng_t rng = {A.seed, attempt, w, KABC_DOM_AIS_INIT_COST, 0u};
-        if (A.posterior == KABC_POSTERIOR_KERNELIZED) {
+        if (A.posterior == KABC_POSTERIOR_COMMON) {
+            lp = 0.0;
+            ll = kabc_cost_eval(A.cost_id, x, D, A.cost_params, A.cost_data, A.cost_ndata, &rng);
+        } else if (A.posterior == KABC_POSTERIOR_KERNELIZED) {
             ll = lp;
             if (kabc_isfinite(lp)) {
                 const double c = kabc_cost_eval(A.cost_id, xp, D, A.cost_params, A.cost_data,

@@ -140,7 +140,8 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         set_error("nparticles must be < 2^31");
         return KABC_ERR_INVALID_ARG;
     }
-    if (m->posterior != KABC_POSTERIOR_KERNELIZED && m->posterior != KABC_POSTERIOR_THRESHOLD) {
+    if (m->posterior != KABC_POSTERIOR_KERNELIZED && m->posterior != KABC_POSTERIOR_THRESHOLD &&
+        m->posterior != KABC_POSTERIOR_COMMON) {
         set_error("unknown posterior kind %d", m->posterior);
         return KABC_ERR_INVALID_ARG;
     }
@@ -381,7 +382,7 @@ kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntra
     a.nt = ntransitions;
     a.posterior = h->posterior;
     a.eps = h->eps;
-    a.reps = 1.0 / h->eps;
+    a.reps = (h->posterior == KABC_POSTERIOR_COMMON) ? 1.0 : 1.0 / h->eps;
     a.box_lp = h->box_lp;
     a.prior = h->d_prior;
     {

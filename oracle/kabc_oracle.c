@@ -331,6 +331,12 @@ typedef struct ld {
 static ld_t loglike(orc_ais_t* h, const double* xp, uint32_t walker, uint64_t t, uint32_t dom,
                     int* cost_evaluated) {
     ld_t r;
+    if (h->posterior == KABC_POSTERIOR_COMMON) { /* loglike = lπ(sample.x), src/types.jl:199-201 */
+        r.lp = 0.0;
+        r.ll = orc_cost_eval(&h->cost, h->D, xp, h->seed, walker, t, dom);
+        *cost_evaluated = 1;
+        return r;
+    }
     r.lp = factored_logpdf(h->q, h->D, xp);
     *cost_evaluated = 0;
     if (h->posterior == KABC_POSTERIOR_KERNELIZED) {
@@ -351,9 +357,16 @@ static ld_t loglike(orc_ais_t* h, const double* xp, uint32_t walker, uint64_t t,
     return r;
 }
 
+/* push_p(density, p): ABC posteriors project through the prior (src/types.jl:110),
+ * a plain AbstractDensity (CommonLogDensity) is the identity (:109) */
+static void model_push_p(const orc_ais_t* h, const double* x, double* out) {
+    if (h->posterior == KABC_POSTERIOR_COMMON) memcpy(out, x, sizeof(double) * h->D);
+    else push_p(h->q, h->D, x, out);
+}
+
 /* is_valid_logdensity: src/types.jl:142 (isfinite(sum(ld))), :175-176 */
 static int is_valid(const orc_ais_t* h, ld_t v) {
-    if (h->posterior == KABC_POSTERIOR_KERNELIZED) return kabc_isfinite(v.lp + v.ll);
+    if (h->posterior != KABC_POSTERIOR_THRESHOLD) return kabc_isfinite(v.lp + v.ll); /* :142, :203 */
     return kabc_isfinite(v.ll) && kabc_isfinite(v.lp);
 }
 
@@ -415,13 +428,13 @@ int32_t orc_ais_init(orc_ais_t* h, int32_t retry_sampling) {
         uint64_t attempt = 0;
         int ev;
         factored_rand(h->prior, D, h->seed, (uint32_t)i, attempt, KABC_DOM_AIS_INIT, h->x + i * D);
-        push_p(h->q, D, h->x + i * D, xp);
+        model_push_p(h, h->x + i * D, xp);
         ld_t v = loglike(h, xp, (uint32_t)i, attempt, KABC_DOM_AIS_INIT_COST, &ev);
         while (!is_valid(h, v)) { /* :54-60 */
             ++attempt;
             factored_rand(h->prior, D, h->seed, (uint32_t)i, attempt, KABC_DOM_AIS_INIT,
                           h->x + i * D);
-            push_p(h->q, D, h->x + i * D, xp);
+            model_push_p(h, h->x + i * D, xp);
             v = loglike(h, xp, (uint32_t)i, attempt, KABC_DOM_AIS_INIT_COST, &ev);
             retrys -= 1;
             if (retrys < 0)
@@ -538,7 +551,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
 
     /* ld = loglike(density, push_p(density, p))  (:75) */
     int ev;
-    push_p(h->q, D, y, yp);
+    model_push_p(h, y, yp);
     ld_t nw = loglike(h, yp, w, t, KABC_DOM_AIS_COST, &ev);
     ld_t old = {h->lp[i], h->ll[i]};
     h->st.proposals += 1;
@@ -552,6 +565,9 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
         double e = -kabc_log_pn(kabc_u01(B1.lo)); /* randexp(rng) */
         if (h->posterior == KABC_POSTERIOR_KERNELIZED) {
             double lW = corr + (nw.lp + nw.ll) - (old.lp + old.ll);
+            acc = (-e <= lW);
+        } else if (h->posterior == KABC_POSTERIOR_COMMON) {
+            double lW = corr + nw.ll - old.ll; /* src/types.jl:209 */
             acc = (-e <= lW);
         } else {
             double lW = corr + nw.lp - old.lp;
@@ -593,7 +609,7 @@ int32_t orc_ais_steps_serial(orc_ais_t* h, int64_t nsteps, int32_t ntransitions,
             int rc = transition(h, i, h->tc[i]++, &ps, NULL);
             if (rc < 0) return transition_error(rc);
         }
-        if (out) push_p(h->q, D, h->x + i * D, out + s * D); /* :78 */
+        if (out) model_push_p(h, h->x + i * D, out + s * D); /* :78 */
         h->cursor = (i + 1) % h->N;                           /* :79 */
     }
     return KABC_OK;
@@ -650,7 +666,7 @@ int32_t orc_ais_generations_sync(orc_ais_t* h, int64_t ngen, int32_t ntransition
         orc_ais_end_generation(h, ntransitions);
         if (out)
             for (int64_t i = 0; i < h->N; ++i)
-                push_p(h->q, D, h->x + i * D, out + (g * h->N + i) * D);
+                model_push_p(h, h->x + i * D, out + (g * h->N + i) * D);
     }
     return KABC_OK;
 }

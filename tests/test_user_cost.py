@@ -97,3 +97,63 @@ def test_user_stochastic_simulator_bit_exact_vs_oracle(k, orc, gpu_ctx):
     r = k.smc(prior, user, nparticles=800, alpha=0.9, epstol=0.3, seed=8, return_array=True)
     o = orc.smc(prior, user, nparticles=800, alpha=0.9, epstol=0.3, seed=8)
     assert np.array_equal(r.info["theta_all"], o["theta_all"]) and r.eps == o["eps"]
+
+
+# ---- CommonLogDensity (src/types.jl:187-210) with user log-densities ---------------
+BANANA_LPI = """
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
+                              const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
+    double a = x[0] - x[1] * x[1], b = x[1] - 1.0;      /* test/runtests.jl:204 */
+    return -100.0 * a * a - b * b;
+}
+"""
+DISC_LPI = """
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
+                              const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
+    double s = x[0] * x[0] + x[1] * x[1];                /* test/runtests.jl:225 */
+    return (s <= params[0]) ? 0.0 : -KABC_INF;
+}
+"""
+
+
+def test_common_log_density_on_oracle(k, orc):
+    from kissabc_jl_amd.costs import DeviceCost
+    lpi = DeviceCost(100 + 62, name="banana")
+    lpi.source = BANANA_LPI
+    orc.register_user_cost(lpi)
+    D = k.CommonLogDensity(2, k.Factored(k.Normal(0, 1), k.Normal(0, 1)), lpi)
+    assert len(D) == 2                                    # test/runtests.jl:206
+    o = orc.OracleAIS(D, 50, seed=1).init()
+    x, lp, ll, _ = o.state()
+    assert np.all(lp == 0.0)
+    a = x[:, 0] - x[:, 1] ** 2
+    assert np.allclose(ll, -100 * a * a - (x[:, 1] - 1) ** 2, rtol=1e-14)
+    o.generations_sync(40, 100, collect=False)
+    s = o.generations_sync(20, 100).reshape(-1, 2)
+    lp_s = -100 * (s[:, 0] - s[:, 1] ** 2) ** 2 - (s[:, 1] - 1) ** 2
+    assert np.quantile(lp_s, 0.97) > -0.69                # test/runtests.jl:217
+    # documented output of the docstring example (src/KissABC.jl:151): 1.43 ± 1.4, 0.99 ± 0.67
+    assert abs(s[:, 0].mean() - 1.43) < 0.35 and abs(s[:, 1].mean() - 0.99) < 0.2
+
+
+@pytest.mark.gpu
+def test_common_log_density_gpu_parity_and_reference_tests(k, orc, gpu_ctx):
+    banana = k.costs.UserCost(BANANA_LPI, dims=[2], name="banana")
+    orc.register_user_cost(banana)
+    D = k.CommonLogDensity(2, k.Factored(k.Normal(0, 1), k.Normal(0, 1)), banana)
+    got = k.AisEnsemble(D, 50, seed=1).init().advance(5, 20, collect=True)
+    assert np.array_equal(got, orc.OracleAIS(D, 50, seed=1).init().generations_sync(5, 20))
+    res = k.sample(D, k.AIS(50), 1000, ntransitions=100, discard_initial=2000, seed=1,
+                   return_array=True)
+    lp = -100 * (res[:, 0] - res[:, 1] ** 2) ** 2 - (res[:, 1] - 1) ** 2
+    assert np.quantile(lp, 0.97) > -0.69                  # test/runtests.jl:217
+    # "Handling of ∞ costs", test/runtests.jl:221-238
+    disc = k.costs.UserCost(DISC_LPI, dims=[2], params=[1.0], name="disc")
+    init = k.Factored(k.Uniform(-1, 1), k.Uniform(0, 1))
+    res = k.sample(k.CommonLogDensity(2, init, disc), k.AIS(50), 1000, ntransitions=100,
+                   discard_initial=5000, seed=2, return_array=True)
+    assert np.all((res ** 2).sum(1) <= 1.0)
+    never = k.costs.UserCost(DISC_LPI, dims=[2], params=[-1.0], name="never")   # lπ = -Inf
+    with pytest.raises(k.KabcError) as e:
+        k.sample(k.CommonLogDensity(2, init, never), k.AIS(50), 10)
+    assert "Prior leads to ∞ costs too often" in str(e.value)
