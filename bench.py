@@ -131,7 +131,9 @@ def main():
         sh.generation(nt)
     sync()
     st0 = sh.global_stats()
-    ens.set_timing(2 * args.steps)
+    # hipEvent pairs on the kernel's stream, one pair per 8 consecutive half-generation
+    # launches (a pair per launch adds ~3 us of marker overhead to every figure)
+    ens.set_timing(2 * args.steps, stride=8)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):

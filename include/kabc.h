@@ -204,6 +204,9 @@ int64_t kabc_ais_owned(const kabc_ais_t* h, int32_t half);
  * kernels with a hipEvent pair on the context stream (0 disables).
  * kabc_ais_kernel_ms returns their average device time in ms and rewinds. */
 kabc_status_t kabc_ais_set_timing(kabc_ais_t* h, int32_t max_launches);
+/* one event pair brackets `stride` consecutive launches and the elapsed time is divided
+ * by `stride` (a pair per launch adds ~3 us of marker overhead to each figure); default 1 */
+kabc_status_t kabc_ais_set_timing_stride(kabc_ais_t* h, int32_t stride);
 double kabc_ais_kernel_ms(kabc_ais_t* h, int64_t* nlaunches);
 /* Test hook: record (move, accepted, a, b, c, cost_evaluated) as 6 int32 per
  * walker and sub-step of the NEXT generation ([N_owned][ntransitions][6], walker-id

@@ -198,8 +198,9 @@ class AisEnsemble:
         _lib.check(_lib.load().kabc_ais_get_stats(self._h, C.byref(st)))
         return {"proposals": st.proposals, "cost_evals": st.cost_evals, "accepted": st.accepted}
 
-    def set_timing(self, max_launches):
+    def set_timing(self, max_launches, stride=1):
         _lib.check(_lib.load().kabc_ais_set_timing(self._h, int(max_launches)))
+        _lib.check(_lib.load().kabc_ais_set_timing_stride(self._h, int(stride)))
 
     def kernel_ms(self):
         n = C.c_int64()
