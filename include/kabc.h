@@ -260,6 +260,35 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
                            const kabc_cost_t* cost, const kabc_smc_opts_t* opts,
                            kabc_smc_result_t* result);
 
+/* ---- ABCDE(prior, cost, ϵ_target; kwargs...) -- src/smc.jl:347-430 -----------
+ * ABC differential evolution (exported, undocumented and untested in the reference:
+ * parity is oracle-vs-device only).  Generation-synchronous and double-buffered in
+ * the reference already (nθs/nΔs/nlogπ, :374-376,413-422), so it maps 1:1. */
+typedef struct kabc_abcde_opts {
+    int64_t nparticles;     /* 50   */
+    int64_t generations;    /* 20   */
+    double eps_target;      /* ϵ_target (positional in the reference) */
+    double alpha;           /* α = 0, must satisfy 0 <= α < 1 (:348) */
+    double proposal_width;  /* 1.0  */
+    int32_t earlystop;      /* false */
+    int32_t verbose;
+    uint64_t seed;
+} kabc_abcde_opts_t;
+
+typedef struct kabc_abcde_result {
+    double* theta;            /* host [N][D], push_p'ed (:425)         */
+    double* cost;             /* host [N] = Δs (field C)               */
+    int32_t reached_eps;      /* maximum(Δs) <= ϵ_target (:422)        */
+    int32_t reserved;
+    int64_t generations_run;  /* iters                                  */
+    uint64_t nsims;           /* sum(nsims) (:407)                      */
+} kabc_abcde_result_t;
+
+void kabc_abcde_default_opts(kabc_abcde_opts_t* o);
+kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                             const kabc_cost_t* cost, const kabc_abcde_opts_t* opts,
+                             kabc_abcde_result_t* result);
+
 #ifdef __cplusplus
 }
 #endif

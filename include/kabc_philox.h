@@ -38,6 +38,10 @@ typedef struct kabc_u128 {
 #define KABC_DOM_SMC_INIT_COST 6u /* src/smc.jl:120-123 */
 #define KABC_DOM_SMC_MOVE 7u      /* src/smc.jl:160-167 */
 #define KABC_DOM_SMC_COST 8u      /* src/smc.jl:176 */
+#define KABC_DOM_ABCDE_INIT 9u       /* src/smc.jl:349,362 */
+#define KABC_DOM_ABCDE_INIT_COST 10u /* src/smc.jl:358,364 */
+#define KABC_DOM_ABCDE_MOVE 11u      /* src/smc.jl:392-406 */
+#define KABC_DOM_ABCDE_COST 12u      /* src/smc.jl:408 */
 
 KABC_HD kabc_u128_t kabc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                        uint32_t k0, uint32_t k1) {

@@ -7,7 +7,7 @@ module kissabc_jl_amd.py registers this package under that name).
 from . import costs
 from ._cdefs import KABC_MAX_DIM
 from ._lib import Context, KabcError, LIB_PATH, default_context
-from .api import (AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity,
+from .api import (ABCDE, AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity,
                   MCMCThreads,
                   Particles, sample, smc)
 from .costs import DeviceCost
@@ -16,7 +16,7 @@ from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma,
                             truncated)
 
 __all__ = [
-    "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "CommonLogDensity",
+    "ABCDE", "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "CommonLogDensity",
     "MCMCThreads",
     "Particles", "sample", "smc", "DeviceCost", "costs", "Factored", "Uniform", "Normal",
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",

@@ -68,6 +68,17 @@ class SmcResult(C.Structure):
                 ("kernel_ms_mcmc", C.c_double), ("mcmc_launches", C.c_int64)]
 
 
+class AbcdeOpts(C.Structure):
+    _fields_ = [("nparticles", C.c_int64), ("generations", C.c_int64), ("eps_target", C.c_double),
+                ("alpha", C.c_double), ("proposal_width", C.c_double), ("earlystop", C.c_int32),
+                ("verbose", C.c_int32), ("seed", C.c_uint64)]
+
+
+class AbcdeResult(C.Structure):
+    _fields_ = [("theta", c_double_p), ("cost", c_double_p), ("reached_eps", C.c_int32),
+                ("reserved", C.c_int32), ("generations_run", C.c_int64), ("nsims", C.c_uint64)]
+
+
 # every symbol include/kabc.h declares: name -> (restype, argtypes)
 VP = C.c_void_p
 PROTOTYPES = {
@@ -103,6 +114,9 @@ PROTOTYPES = {
     "kabc_ais_get_debug": (C.c_int, [VP, C.POINTER(C.c_int32), C.c_int64]),
     "kabc_ais_destroy": (C.c_int, [VP]),
     "kabc_smc_default_opts": (None, [C.POINTER(SmcOpts)]),
+    "kabc_abcde_default_opts": (None, [C.POINTER(AbcdeOpts)]),
+    "kabc_abcde_run": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),
+                                 C.POINTER(AbcdeOpts), C.POINTER(AbcdeResult)]),
     "kabc_smc_run": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),
                                C.POINTER(SmcOpts), C.POINTER(SmcResult)]),
 }

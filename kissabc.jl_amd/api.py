@@ -331,3 +331,44 @@ def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.01
     }
     P = kept if return_array else _bundle(kept, scalar)
     return SmcResult(P, Cst, r.eps, info)
+
+
+class AbcdeResult(collections.namedtuple("AbcdeResult", ["P", "C", "reached_eps", "info"])):
+    """(P, C, reached_ϵ) of src/smc.jl:428 (+ info); `.reached_ϵ` aliases `.reached_eps`."""
+    __slots__ = ()
+
+    def __getattr__(self, name):
+        if name in ("reached_\u03b5", "reached_\u03f5"):
+            return self.reached_eps
+        raise AttributeError(name)
+
+
+def ABCDE(prior, cost, eps_target, *, nparticles=50, generations=20, α=0.0, alpha=None,
+          parallel=False, earlystop=False, verbose=False, proposal_width=1.0, seed=0, ctx=None,
+          return_array=False):
+    """ABCDE(prior, cost, ϵ_target; ...) -- src/smc.jl:347-430, same keywords
+    (`alpha` is an ASCII alias of `α`; `parallel` is accepted and ignored).
+    Returns (P, C, reached_ϵ) as the reference does (+ info)."""
+    fac = as_factored(prior)
+    scalar = isinstance(prior, UnivariateDistribution)
+    if not isinstance(cost, DeviceCost):
+        raise TypeError("`cost` must be a DeviceCost on the MI355X path")
+    lib = _lib.load()
+    ctx = ctx or _lib.default_context()
+    o = cd.AbcdeOpts()
+    lib.kabc_abcde_default_opts(C.byref(o))
+    o.nparticles, o.generations, o.eps_target = int(nparticles), int(generations), float(eps_target)
+    o.alpha = float(α if alpha is None else alpha)
+    o.proposal_width, o.earlystop, o.verbose, o.seed = (float(proposal_width), int(bool(earlystop)),
+                                                        int(bool(verbose)), int(seed))
+    N, D = max(int(nparticles), 1), len(fac)
+    theta = np.empty((N, D))
+    Cst = np.empty(N)
+    r = cd.AbcdeResult()
+    r.theta = theta.ctypes.data_as(cd.c_double_p)
+    r.cost = Cst.ctypes.data_as(cd.c_double_p)
+    cc = cost.to_c()
+    _lib.check(lib.kabc_abcde_run(ctx.handle, fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    info = {"generations_run": r.generations_run, "nsims": r.nsims}
+    return AbcdeResult(theta if return_array else _bundle(theta, scalar), Cst,
+                       bool(r.reached_eps), info)

@@ -1,0 +1,225 @@
+// abcde_kernels.hpp -- gfx950 kernels for ABCDE (src/smc.jl:347-430).
+// Not a hot path of the round: one thread per particle, D as the only template
+// parameter (the DeviceCost is dispatched at run time by kabc_cost_eval, which a
+// user plugin extends with its own branch).
+#pragma once
+
+#include "kabc_device.hpp"
+
+namespace kabc {
+
+struct AbcdeCtrl {
+    double eps_l, eps_h, eps_pop;
+    int32_t cur;         // buffer set holding θs, Δs, logπ
+    int32_t done;        // earlystop break (:379-381)
+    int32_t error;       // 1: initial sampling never produced a finite (Δ, logπ)
+    int32_t pad;
+    long long iters;
+    unsigned long long nsims;
+};
+
+struct AbcdeArgs {
+    double* theta[2];
+    double* delta[2];
+    double* lpi[2];
+    AbcdeCtrl* ctrl;
+    const double* cost_params;
+    const double* cost_data;
+    int64_t cost_ndata;
+    int64_t N;
+    uint64_t seed;
+    int32_t cost_id;
+    int32_t earlystop;
+    double eps_target;
+    double alpha;
+    double gamma;  // proposal_width * 2.38 / sqrt(2 * length(prior))  (:370)
+    PriorSet prior;
+    kabc_prior_t raw[KABC_MAX_DIM];
+};
+
+constexpr int kAbcdeBlock = 64;
+constexpr unsigned kAbcdeMaxInitTries = 100000u;
+
+// θs, logπ, Δs with the re-draw loop of :351-366
+template <int D>
+__global__ void __launch_bounds__(kAbcdeBlock) abcde_init_kernel(const AbcdeArgs A) {
+    const int64_t i = (int64_t)blockIdx.x * kAbcdeBlock + threadIdx.x;
+    if (i >= A.N) return;
+    double x[D], xp[D];
+    double lp = 0.0, dl = 0.0;
+    for (unsigned attempt = 0;; ++attempt) {
+        for (int k = 0; k < D; ++k) {
+            kabc_slotwin_t win = {A.seed, (uint64_t)attempt, (uint32_t)i, KABC_DOM_ABCDE_INIT,
+                                  (uint32_t)k * KABC_SLOTS_PER_DIM};
+            x[k] = kabc_sample_prior(&A.raw[k], &win);
+        }
+        lp = factored_logpdf_push<D>(A.prior, x, xp);
+        kabc_cost_rng_t rng = {A.seed, (uint64_t)attempt, (uint32_t)i, KABC_DOM_ABCDE_INIT_COST, 0u};
+        // first pass: the cost is only evaluated when logπ is finite (:357-359);
+        // in the re-draw loop it always is (:364).  cost(θ.x): NOT push_p'ed.
+        const bool eval = (attempt > 0) || kabc_isfinite(lp);
+        dl = eval ? kabc_cost_eval(A.cost_id, x, D, A.cost_params, A.cost_data, A.cost_ndata, &rng)
+                  : KABC_NAN;
+        if (kabc_isfinite(dl) && kabc_isfinite(lp)) break;
+        if (attempt >= kAbcdeMaxInitTries) {
+            A.ctrl->error = 1;
+            break;
+        }
+    }
+    store_row<D>(A.theta[0] + i * D, x);
+    A.delta[0][i] = dl;
+    A.lpi[0][i] = lp;
+}
+
+#ifdef KABC_ABCDE_SINGLE_UNIT  // non-template kernels: defined once, in capi_abcde.hip
+// ϵ_l, ϵ_h = extrema(Δs); earlystop break; ϵ_pop (:377-382).  One workgroup.
+__global__ void __launch_bounds__(1024) abcde_extrema_kernel(const AbcdeArgs A) {
+    __shared__ double smin[16], smax[16];
+    if (A.ctrl->done) return;
+    const double* dl = A.delta[A.ctrl->cur];
+    double mn = KABC_INF, mx = -KABC_INF;
+    for (int64_t i = threadIdx.x; i < A.N; i += 1024) {
+        const double v = dl[i];
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const double a = __shfl_down(mn, off, kWave), b = __shfl_down(mx, off, kWave);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        smin[threadIdx.x >> 6] = mn;
+        smax[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            mn = smin[w] < mn ? smin[w] : mn;
+            mx = smax[w] > mx ? smax[w] : mx;
+        }
+        A.ctrl->eps_l = mn;
+        A.ctrl->eps_h = mx;
+        if (A.earlystop && mx <= A.eps_target) {
+            A.ctrl->done = 1;
+        } else {
+            A.ctrl->iters += 1;  // iters += 1 (:373)
+            const double pop = mn + A.alpha * (mx - mn);
+            A.ctrl->eps_pop = (A.eps_target > pop) ? A.eps_target : pop;  // max(ϵ_target, ...)
+        }
+    }
+}
+
+#endif  // KABC_ABCDE_SINGLE_UNIT
+
+// one generation (:383-412); reads buffer cur, writes buffer 1-cur
+template <int D>
+__global__ void __launch_bounds__(kAbcdeBlock) abcde_gen_kernel(const AbcdeArgs A) {
+    const int64_t i = (int64_t)blockIdx.x * kAbcdeBlock + threadIdx.x;
+    if (A.ctrl->done) return;
+    const int cur = A.ctrl->cur;
+    const uint64_t g = (uint64_t)A.ctrl->iters;
+    const double* __restrict__ TH = A.theta[cur];
+    const double* __restrict__ DL = A.delta[cur];
+    const double* __restrict__ LP = A.lpi[cur];
+    unsigned long long sims = 0;
+    if (i < A.N) {
+        const int64_t N = A.N;
+        double th[D];
+        load_row<D>(TH + i * D, th);
+        double di = DL[i], li = LP[i];
+        const bool skip = A.earlystop && di <= A.eps_target;  // :384-386
+        if (!skip) {
+            const uint32_t w = (uint32_t)i;
+            const kabc_u128_t B0 = kabc_stream_block(A.seed, w, g, 0u, KABC_DOM_ABCDE_MOVE);
+            const kabc_u128_t B1 = kabc_stream_block(A.seed, w, g, 1u, KABC_DOM_ABCDE_MOVE);
+            int64_t s = i;
+            const double eps = (di <= A.eps_target) ? A.eps_target : A.ctrl->eps_pop;  // :390
+            if (di > eps) {
+                // s = rand(trng, (1:N)[Δs .<= Δs[i]])  (:392): the m-th index, in ascending
+                // order, whose cost does not exceed ours
+                int64_t c = 0;
+                for (int64_t j = 0; j < N; ++j) c += (DL[j] <= di) ? 1 : 0;
+                int64_t m = (int64_t)kabc_index(kabc_lo64(B0), (uint64_t)c);
+                for (int64_t j = 0; j < N; ++j) {
+                    if (DL[j] <= di) {
+                        if (m == 0) {
+                            s = j;
+                            break;
+                        }
+                        --m;
+                    }
+                }
+            }
+            // while a == s ... ; while b == a || b == s ...  (:394-401)
+            int64_t a = (int64_t)kabc_index(kabc_hi64(B0), (uint64_t)(N - 1));
+            a += (a >= s);
+            const int64_t lo = a < s ? a : s, hi = a < s ? s : a;
+            int64_t b = (int64_t)kabc_index(kabc_lo64(B1), (uint64_t)(N - 2));
+            b += (b >= lo);
+            b += (b >= hi);
+            double ts[D], ta[D], tb[D], tp[D], xp[D];
+            load_row<D>(TH + s * D, ts);
+            load_row<D>(TH + a * D, ta);
+            load_row<D>(TH + b * D, tb);
+#pragma unroll
+            for (int k = 0; k < D; ++k) tp[k] = ts[k] + (ta[k] - tb[k]) * A.gamma;  // :402
+            const double lpp = factored_logpdf_push<D>(A.prior, tp, xp);
+            const double wp = lpp - li;
+            double mn = wp;
+            if (!(wp < 0.0)) mn = (wp != wp) ? wp : 0.0;  // min(0, w_prior), NaN propagates
+            const double lu = kabc_log_pn(kabc_u01(kabc_hi64(B1)));
+            if (!(lu > mn)) {  // log(rand) > min(0,w_prior) && continue  (:405)
+                sims = 1;
+                kabc_cost_rng_t rng = {A.seed, g, w, KABC_DOM_ABCDE_COST, 0u};
+                const double dp = kabc_cost_eval(A.cost_id, tp, D, A.cost_params, A.cost_data,
+                                                 A.cost_ndata, &rng);  // cost(θp.x), :408
+                const double thr = (eps > di) ? eps : di;  // max(ϵ, Δs[i])
+                if (dp <= thr) {
+                    di = dp;
+                    li = lpp;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) th[k] = tp[k];
+                }
+            }
+        }
+        store_row<D>(A.theta[1 - cur] + i * D, th);
+        A.delta[1 - cur][i] = di;
+        A.lpi[1 - cur][i] = li;
+    }
+    const unsigned long long ssum = wave_sum(sims);
+    if ((threadIdx.x & 63) == 0 && ssum) atomicAdd(&A.ctrl->nsims, ssum);
+}
+
+#ifdef KABC_ABCDE_SINGLE_UNIT
+// θs = nθs ... (:413-415)
+__global__ void abcde_flip_kernel(AbcdeCtrl* ctrl) {
+    if (!ctrl->done) ctrl->cur ^= 1;
+}
+
+struct AbcdeFinalArgs {
+    const double* theta[2];
+    const double* delta[2];
+    const AbcdeCtrl* ctrl;
+    double* out;
+    double* dout;
+    int64_t N;
+    int32_t D;
+    PriorSet prior;
+};
+__global__ void __launch_bounds__(256) abcde_final_kernel(const AbcdeFinalArgs A) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= A.N) return;
+    const int cur = A.ctrl->cur;
+    for (int k = 0; k < A.D; ++k) {
+        const double v = A.theta[cur][i * A.D + k];
+        A.out[i * A.D + k] = A.prior.c[k].discrete ? kabc_rint(v) : v;
+    }
+    A.dout[i] = A.delta[cur][i];
+}
+
+#endif  // KABC_ABCDE_SINGLE_UNIT
+
+using AbcdeLaunchFn = void (*)(const AbcdeArgs&, hipStream_t);
+
+}  // namespace kabc

@@ -1,0 +1,188 @@
+// capi_abcde.hip -- kabc_abcde_run: ABCDE(prior, cost, ϵ_target; ...) of
+// src/smc.jl:347-430.  All generations are enqueued without a host round trip; the
+// earlystop break is taken on the device (kernels after it are no-ops).
+#include <cmath>
+#include <vector>
+
+#define KABC_ABCDE_SINGLE_UNIT 1
+#include "abcde_kernels.hpp"
+#include "host_common.hpp"
+#include "plugin_registry.hpp"
+
+namespace kabc {
+
+template <int D>
+static void l_init(const AbcdeArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((abcde_init_kernel<D>), dim3((unsigned)((a.N + kAbcdeBlock - 1) / kAbcdeBlock)),
+                       dim3(kAbcdeBlock), 0, s, a);
+}
+template <int D>
+static void l_gen(const AbcdeArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((abcde_gen_kernel<D>), dim3((unsigned)((a.N + kAbcdeBlock - 1) / kAbcdeBlock)),
+                       dim3(kAbcdeBlock), 0, s, a);
+}
+template <int... Ds>
+static AbcdeLaunchFn pick_init(int D, std::integer_sequence<int, Ds...>) {
+    static const AbcdeLaunchFn f[] = {&l_init<Ds + 1>...};
+    return f[D - 1];
+}
+template <int... Ds>
+static AbcdeLaunchFn pick_gen(int D, std::integer_sequence<int, Ds...>) {
+    static const AbcdeLaunchFn f[] = {&l_gen<Ds + 1>...};
+    return f[D - 1];
+}
+
+}  // namespace kabc
+
+using namespace kabc;
+
+extern "C" {
+
+void kabc_abcde_default_opts(kabc_abcde_opts_t* o) {
+    if (!o) return;
+    o->nparticles = 50;
+    o->generations = 20;
+    o->eps_target = 0.0;
+    o->alpha = 0.0;
+    o->proposal_width = 1.0;
+    o->earlystop = 0;
+    o->verbose = 0;
+    o->seed = 0;
+}
+
+kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                             const kabc_cost_t* cost, const kabc_abcde_opts_t* o,
+                             kabc_abcde_result_t* res) {
+    if (!ctx || !prior || !cost || !o || !res) {
+        set_error("kabc_abcde_run: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (!(o->alpha >= 0 && o->alpha < 1)) {  // @assert 0<=α<1 (:348)
+        set_error("α must be in 0 <= α < 1.");
+        return KABC_ERR_INVALID_ARG;
+    }
+    const int64_t N = o->nparticles;
+    if (D < 1 || D > KABC_MAX_DIM) {
+        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    if (N < 3 || N >= (1ll << 31)) {  // three distinct indices s, a, b are drawn (:394-401)
+        set_error("nparticles must be >= 3 (and < 2^31)");
+        return KABC_ERR_INVALID_ARG;
+    }
+    AbcdeArgs A;
+    std::memset(&A, 0, sizeof A);
+    if (!prepare_priors(prior, D, A.prior)) {
+        set_error("invalid prior parameters");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (!cost_dim_ok_rt(cost->id, D)) {
+        set_error("DeviceCost id %d does not accept D = %d", cost->id, D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    AbcdeLaunchFn f_init, f_gen;
+    if (const CostPlugin* p = find_plugin(cost->id)) {
+        f_init = p->abcde_init ? (AbcdeLaunchFn)p->abcde_init(D) : nullptr;
+        f_gen = p->abcde_gen ? (AbcdeLaunchFn)p->abcde_gen(D) : nullptr;
+        if (!f_init || !f_gen) {
+            set_error("cost plugin has no ABCDE kernels for D = %d", D);
+            return KABC_ERR_UNSUPPORTED;
+        }
+    } else {
+        f_init = pick_init(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+        f_gen = pick_gen(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+    }
+    std::memcpy(A.raw, prior, sizeof(kabc_prior_t) * D);
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<void*> bufs;
+    auto alloc = [&](void** p, size_t bytes) {
+        hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+        if (e == hipSuccess) bufs.push_back(*p);
+        return e;
+    };
+    struct Free {
+        std::vector<void*>& b;
+        ~Free() {
+            for (void* p : b) (void)hipFree(p);
+        }
+    } freer{bufs};
+    for (int b = 0; b < 2; ++b) {
+        KABC_HIP_CHECK(alloc((void**)&A.theta[b], sizeof(double) * N * D));
+        KABC_HIP_CHECK(alloc((void**)&A.delta[b], sizeof(double) * N));
+        KABC_HIP_CHECK(alloc((void**)&A.lpi[b], sizeof(double) * N));
+    }
+    double *d_params = nullptr, *d_data = nullptr, *d_out = nullptr, *d_dout = nullptr;
+    KABC_HIP_CHECK(alloc((void**)&A.ctrl, sizeof(AbcdeCtrl)));
+    KABC_HIP_CHECK(alloc((void**)&d_out, sizeof(double) * N * D));
+    KABC_HIP_CHECK(alloc((void**)&d_dout, sizeof(double) * N));
+    KABC_HIP_CHECK(hipMemsetAsync(A.ctrl, 0, sizeof(AbcdeCtrl), s));
+    if (cost->nparams > 0) {
+        KABC_HIP_CHECK(alloc((void**)&d_params, sizeof(double) * cost->nparams));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_params, cost->params, sizeof(double) * cost->nparams,
+                                      hipMemcpyHostToDevice, s));
+    }
+    if (cost->ndata > 0) {
+        KABC_HIP_CHECK(alloc((void**)&d_data, sizeof(double) * cost->ndata));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_data, cost->data, sizeof(double) * cost->ndata,
+                                      hipMemcpyHostToDevice, s));
+    }
+    A.cost_params = d_params;
+    A.cost_data = d_data;
+    A.cost_ndata = cost->ndata;
+    A.N = N;
+    A.seed = o->seed;
+    A.cost_id = cost->id;
+    A.earlystop = o->earlystop;
+    A.eps_target = o->eps_target;
+    A.alpha = o->alpha;
+    A.gamma = o->proposal_width * 2.38 / std::sqrt((double)(2 * D));
+    f_init(A, s);
+    KABC_HIP_CHECK(hipGetLastError());
+    for (int64_t g = 0; g < o->generations; ++g) {  // while iters < generations (:372)
+        hipLaunchKernelGGL(abcde_extrema_kernel, dim3(1), dim3(1024), 0, s, A);
+        f_gen(A, s);
+        hipLaunchKernelGGL(abcde_flip_kernel, dim3(1), dim3(1), 0, s, A.ctrl);
+    }
+    KABC_HIP_CHECK(hipGetLastError());
+    AbcdeFinalArgs F;
+    for (int b = 0; b < 2; ++b) {
+        F.theta[b] = A.theta[b];
+        F.delta[b] = A.delta[b];
+    }
+    F.ctrl = A.ctrl;
+    F.out = d_out;
+    F.dout = d_dout;
+    F.N = N;
+    F.D = D;
+    F.prior = A.prior;
+    hipLaunchKernelGGL(abcde_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, F);
+    KABC_HIP_CHECK(hipGetLastError());
+    AbcdeCtrl hc;
+    KABC_HIP_CHECK(hipMemcpyAsync(&hc, A.ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+    if (res->theta)
+        KABC_HIP_CHECK(hipMemcpyAsync(res->theta, d_out, sizeof(double) * N * D,
+                                      hipMemcpyDeviceToHost, s));
+    std::vector<double> hd((size_t)N);
+    KABC_HIP_CHECK(hipMemcpyAsync(hd.data(), d_dout, sizeof(double) * N, hipMemcpyDeviceToHost, s));
+    KABC_HIP_CHECK(hipStreamSynchronize(s));
+    if (hc.error) {
+        set_error("ABCDE: the prior never produced a finite (cost, logpdf) pair for some particle");
+        return KABC_ERR_RETRY_EXHAUSTED;
+    }
+    double mx = -INFINITY;
+    for (int64_t i = 0; i < N; ++i) {
+        if (res->cost) res->cost[i] = hd[i];
+        mx = hd[i] > mx ? hd[i] : mx;
+    }
+    res->reached_eps = (mx <= o->eps_target) ? 1 : 0;  // conv = maximum(Δs) <= ϵ_target
+    res->reserved = 0;
+    res->generations_run = hc.iters;
+    res->nsims = hc.nsims;
+    if (o->verbose)
+        fprintf(stderr, "ABCDE End: converged = %d nsim = %llu range_eps = (%g, %g)\n",
+                res->reached_eps, (unsigned long long)hc.nsims, hc.eps_l, hc.eps_h);
+    return KABC_OK;
+}
+
+}  // extern "C"

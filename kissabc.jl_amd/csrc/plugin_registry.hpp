@@ -12,6 +12,8 @@ struct CostPlugin {
     void* (*smc)(int32_t D, int32_t simple_prior);  // -> SmcLaunchFn
     void* (*ais_init)(int32_t D);                   // -> void (*)(const InitArgs&, hipStream_t)
     void* (*smc_init)(int32_t D);                   // -> void (*)(const SmcInitArgs&, hipStream_t)
+    void* (*abcde_init)(int32_t D);                 // -> AbcdeLaunchFn (may be NULL)
+    void* (*abcde_gen)(int32_t D);                  // -> AbcdeLaunchFn (may be NULL)
 };
 
 const CostPlugin* find_plugin(int cost_id);

@@ -939,3 +939,117 @@ done:
     free(alive); free(idx); free(prop); free(lprob);
     return rc;
 }
+
+/* ------------------------------------------------------------------------- */
+/* ABCDE -- src/smc.jl:347-430 (exported, undocumented, untested upstream)    */
+/* ------------------------------------------------------------------------- */
+int32_t orc_abcde_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cost,
+                      const kabc_abcde_opts_t* o, kabc_abcde_result_t* res) {
+    if (!(o->alpha >= 0 && o->alpha < 1)) return fail(KABC_ERR_INVALID_ARG, "α must be in 0 <= α < 1.");
+    const int64_t N = o->nparticles;
+    if (N < 3) return fail(KABC_ERR_INVALID_ARG, "nparticles must be >= 3 (and < 2^31)");
+    prep_t q[KABC_MAX_DIM];
+    if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
+    if (!cost_dim_ok_any(cost->id, D)) return fail(KABC_ERR_UNSUPPORTED, "cost id / dimension not supported");
+    const uint64_t seed = o->seed;
+    double* th = (double*)malloc(sizeof(double) * N * D);
+    double* nth = (double*)malloc(sizeof(double) * N * D);
+    double* dl = (double*)malloc(sizeof(double) * N);
+    double* ndl = (double*)malloc(sizeof(double) * N);
+    double* lp = (double*)malloc(sizeof(double) * N);
+    double* nlp = (double*)malloc(sizeof(double) * N);
+    double xp[KABC_MAX_DIM], tp[KABC_MAX_DIM];
+    uint64_t nsims = 0;
+    int32_t rc = KABC_OK;
+    /* :349-366 */
+    for (int64_t i = 0; i < N; ++i) {
+        for (unsigned attempt = 0;; ++attempt) {
+            factored_rand(prior, D, seed, (uint32_t)i, attempt, KABC_DOM_ABCDE_INIT, th + i * D);
+            push_p(q, D, th + i * D, xp);
+            lp[i] = factored_logpdf(q, D, xp);
+            int eval = attempt > 0 || kabc_isfinite(lp[i]);
+            dl[i] = eval ? orc_cost_eval(cost, D, th + i * D, seed, (uint32_t)i, attempt,
+                                         KABC_DOM_ABCDE_INIT_COST)
+                         : KABC_NAN;
+            if (kabc_isfinite(dl[i]) && kabc_isfinite(lp[i])) break;
+            if (attempt >= 100000u) {
+                rc = fail(KABC_ERR_RETRY_EXHAUSTED, "ABCDE: the prior never produced a finite (cost, logpdf) pair for some particle");
+                goto done;
+            }
+        }
+    }
+    const double gamma = o->proposal_width * 2.38 / sqrt((double)(2 * D)); /* :370 */
+    int64_t iters = 0;
+    while (iters < o->generations) { /* :372 */
+        double el = KABC_INF, eh = -KABC_INF;
+        for (int64_t i = 0; i < N; ++i) {
+            if (dl[i] < el) el = dl[i];
+            if (dl[i] > eh) eh = dl[i];
+        }
+        if (o->earlystop && eh <= o->eps_target) break; /* :379-381 (before iters += 1 here
+                                                            would differ: the reference increments
+                                                            first; keep its count) */
+        iters += 1;
+        memcpy(nth, th, sizeof(double) * N * D);
+        memcpy(ndl, dl, sizeof(double) * N);
+        memcpy(nlp, lp, sizeof(double) * N);
+        double pop = el + o->alpha * (eh - el);
+        double eps_pop = o->eps_target > pop ? o->eps_target : pop;
+        for (int64_t i = 0; i < N; ++i) {
+            if (o->earlystop && dl[i] <= o->eps_target) continue;
+            blk_t B0 = stream(seed, (uint32_t)i, (uint64_t)iters, 0, KABC_DOM_ABCDE_MOVE);
+            blk_t B1 = stream(seed, (uint32_t)i, (uint64_t)iters, 1, KABC_DOM_ABCDE_MOVE);
+            int64_t s = i;
+            double eps = dl[i] <= o->eps_target ? o->eps_target : eps_pop;
+            if (dl[i] > eps) { /* s = rand(trng, (1:N)[Δs .<= Δs[i]]) */
+                int64_t c = 0;
+                for (int64_t j = 0; j < N; ++j) c += dl[j] <= dl[i];
+                int64_t m = (int64_t)kabc_index(B0.lo, (uint64_t)c);
+                for (int64_t j = 0; j < N; ++j)
+                    if (dl[j] <= dl[i]) {
+                        if (m == 0) { s = j; break; }
+                        --m;
+                    }
+            }
+            partner_set_t ps = {0, N, s};
+            int64_t a = draw_partner(B0.hi, &ps, NULL, 0);
+            int64_t b = draw_partner(B1.lo, &ps, &a, 1);
+            for (int k = 0; k < D; ++k)
+                tp[k] = th[s * D + k] + (th[a * D + k] - th[b * D + k]) * gamma;
+            push_p(q, D, tp, xp);
+            double lpp = factored_logpdf(q, D, xp);
+            double wp = lpp - lp[i];
+            double mn = wp;
+            if (!(wp < 0.0)) mn = (wp != wp) ? wp : 0.0;
+            double lu = kabc_log_pn(kabc_u01(B1.hi));
+            if (lu > mn) continue; /* :405 */
+            nsims += 1;
+            double dp = orc_cost_eval(cost, D, tp, seed, (uint32_t)i, (uint64_t)iters, KABC_DOM_ABCDE_COST);
+            double thr = eps > dl[i] ? eps : dl[i];
+            if (dp <= thr) {
+                ndl[i] = dp;
+                nlp[i] = lpp;
+                memcpy(nth + i * D, tp, sizeof(double) * D);
+            }
+        }
+        double* sw;
+        sw = th; th = nth; nth = sw;
+        sw = dl; dl = ndl; ndl = sw;
+        sw = lp; lp = nlp; nlp = sw;
+    }
+    {
+        double mx = -KABC_INF;
+        for (int64_t i = 0; i < N; ++i) {
+            if (res->theta) push_p(q, D, th + i * D, res->theta + i * D);
+            if (res->cost) res->cost[i] = dl[i];
+            if (dl[i] > mx) mx = dl[i];
+        }
+        res->reached_eps = mx <= o->eps_target;
+        res->reserved = 0;
+        res->generations_run = iters;
+        res->nsims = nsims;
+    }
+done:
+    free(th); free(nth); free(dl); free(ndl); free(lp); free(nlp);
+    return rc;
+}

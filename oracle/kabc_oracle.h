@@ -91,6 +91,9 @@ void orc_ais_destroy(orc_ais_t* h);
 /* smc(prior, cost; ...) -- src/smc.jl:92-206 */
 int32_t orc_smc_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cost,
                     const kabc_smc_opts_t* opts, kabc_smc_result_t* result);
+/* ABCDE(prior, cost, ϵ_target; ...) -- src/smc.jl:347-430 */
+int32_t orc_abcde_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cost,
+                      const kabc_abcde_opts_t* opts, kabc_abcde_result_t* result);
 /* Statistics.quantile(v, p) (type 7), restated; v is not modified */
 int32_t orc_quantile(const double* v, int64_t n, double p, double* out);
 

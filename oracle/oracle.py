@@ -75,6 +75,8 @@ def load():
             "orc_smc_run": (C.c_int32, [C.POINTER(cd.Prior), C.c_int32, C.POINTER(cd.Cost),
                                         C.POINTER(cd.SmcOpts), C.POINTER(cd.SmcResult)]),
             "orc_quantile": (C.c_int32, [dp, C.c_int64, C.c_double, dp]),
+            "orc_abcde_run": (C.c_int32, [C.POINTER(cd.Prior), C.c_int32, C.POINTER(cd.Cost),
+                                          C.POINTER(cd.AbcdeOpts), C.POINTER(cd.AbcdeResult)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
@@ -301,3 +303,21 @@ def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.01
                      resampled=log[i].resampled, flag=log[i].flag, passes=log[i].mcmc_passes)
                 for i in range(nit)],
     }
+
+
+def abcde(prior, cost, eps_target, *, nparticles=50, generations=20, alpha=0.0, earlystop=False,
+          proposal_width=1.0, seed=0):
+    """CPU restatement of ABCDE (src/smc.jl:347-430); returns dict."""
+    fac = as_factored(prior)
+    o = cd.AbcdeOpts()
+    o.nparticles, o.generations, o.eps_target, o.alpha = int(nparticles), int(generations), eps_target, alpha
+    o.proposal_width, o.earlystop, o.verbose, o.seed = proposal_width, int(earlystop), 0, seed
+    N, D = max(int(nparticles), 1), len(fac)
+    theta = np.empty((N, D))
+    Cst = np.empty(N)
+    r = cd.AbcdeResult()
+    r.theta, r.cost = _dp(theta), _dp(Cst)
+    cc = cost.to_c()
+    _check(load().orc_abcde_run(fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    return {"P": theta, "C": Cst, "reached_eps": bool(r.reached_eps),
+            "generations_run": r.generations_run, "nsims": r.nsims}

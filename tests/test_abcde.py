@@ -1,0 +1,44 @@
+"""ABCDE (src/smc.jl:347-430): exported by the reference but undocumented and untested
+there, so parity is oracle-vs-device (bit-exact) plus sanity on known posteriors."""
+import numpy as np
+import pytest
+
+
+def _cases(k):
+    N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    return {
+        "gauss": (N2, k.costs.GaussDist([1.0, -0.5]), 0.05, dict(nparticles=300, generations=100)),
+        "gauss_alpha_early": (N2, k.costs.GaussDist([1.0, -0.5]), 0.3,
+                              dict(nparticles=200, generations=60, alpha=0.3, earlystop=True)),
+        "banana_noisy": (N2, k.costs.NoisyBanana(0.0), 0.05,
+                         dict(nparticles=500, generations=50, proposal_width=0.8)),
+        "dirac_d1": (k.Normal(1, 0.2), k.costs.DiracSq(1.5), 0.01, dict(nparticles=64)),
+        "discrete": (k.Factored(k.Normal(1, 0.5), k.DiscreteUniform(1, 10)), k.costs.NoisyQuadDU(5.5),
+                     0.05, dict(nparticles=128, generations=30)),
+    }
+
+
+def test_abcde_oracle_converges(orc, k):
+    pri, cost, eps, kw = _cases(k)["gauss"]
+    r = orc.abcde(pri, cost, eps, seed=1, **kw)
+    assert r["generations_run"] == 100 and r["reached_eps"]
+    assert np.all(r["C"] <= eps)
+    assert np.all(np.abs(r["P"].mean(0) - [1.0, -0.5]) < 0.02)
+    with pytest.raises(orc.OracleError) as e:
+        orc.abcde(pri, cost, eps, alpha=1.0)
+    assert str(e.value) == "α must be in 0 <= α < 1."
+    r2 = orc.abcde(pri, cost, 0.3, seed=1, nparticles=200, generations=60, alpha=0.3, earlystop=True)
+    assert r2["reached_eps"] and r2["generations_run"] < 60
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gauss", "gauss_alpha_early", "banana_noisy", "dirac_d1", "discrete"])
+def test_abcde_bit_exact(k, orc, gpu_ctx, name):
+    pri, cost, eps, kw = _cases(k)[name]
+    got = k.ABCDE(pri, cost, eps, seed=9, return_array=True, **kw)
+    ref = orc.abcde(pri, cost, eps, seed=9, **kw)
+    assert np.array_equal(got.P, ref["P"])
+    assert np.array_equal(got.C, ref["C"])
+    assert got.reached_ϵ == ref["reached_eps"]
+    assert got.info["generations_run"] == ref["generations_run"]
+    assert got.info["nsims"] == ref["nsims"]

@@ -79,6 +79,10 @@ def test_user_cost_equals_builtin_and_oracle(k, orc, gpu_ctx):
     b = k.smc(N2, k.costs.Rosenbrock(), nparticles=1000, alpha=0.9, epstol=0.05, seed=2,
               return_array=True)
     assert np.array_equal(a.P, b.P) and a.eps == b.eps
+    c = k.ABCDE(N2, user, 0.05, nparticles=200, generations=30, seed=3, return_array=True)
+    d = k.ABCDE(N2, k.costs.Rosenbrock(), 0.05, nparticles=200, generations=30, seed=3,
+                return_array=True)
+    assert np.array_equal(c.P, d.P) and np.array_equal(c.C, d.C)
     with pytest.raises(k.KabcError):          # D = 5 was not built
         k.AisEnsemble(k.ApproxKernelizedPosterior(k.Factored(*[k.Uniform(-5, 5)] * 5), user, 1.0),
                       64)
