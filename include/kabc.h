@@ -289,6 +289,40 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
                              const kabc_cost_t* cost, const kabc_abcde_opts_t* opts,
                              kabc_abcde_result_t* result);
 
+/* ---- pfilter(prior, cost, N; kwargs...) -- src/smc.jl:275-340 -----------------
+ * Rejection-refresh particle filter (exported, undocumented and untested in the
+ * reference: parity is oracle-vs-device only).  Every iteration the particles above
+ * the q-quantile of the costs are re-proposed from three distinct survivors until
+ * they pass the prior-MH test and land below ϵ. */
+typedef struct kabc_pfilter_opts {
+    int64_t nparticles;     /* N (positional in the reference); raised to ceil((4D+1)/q) if N*q <= 4D */
+    double q;               /* 0.7   */
+    double eff_tol;         /* 0.1   */
+    double epstol;          /* -Inf  */
+    double proposal_width;  /* 0.75  */
+    int64_t max_iters;      /* Inf -> pass <= 0 for "no limit" */
+    int32_t verbose;
+    int32_t reserved;
+    uint64_t seed;
+} kabc_pfilter_opts_t;
+
+typedef struct kabc_pfilter_result {
+    double* theta;      /* host [N_eff][D], push_p'ed (:334); N_eff = kabc_pfilter_nparticles() */
+    double* cost;       /* host [N_eff] (field C)                                               */
+    double eps;         /* ϵ of the last iteration                                              */
+    double eff;         /* eff of the last iteration (:327)                                     */
+    int64_t iterations;
+    uint64_t nreps;     /* total proposals                                                      */
+    uint64_t cost_evals;
+} kabc_pfilter_result_t;
+
+void kabc_pfilter_default_opts(kabc_pfilter_opts_t* o);
+/* the particle count the reference actually uses (src/smc.jl:276-279) */
+int64_t kabc_pfilter_nparticles(int64_t N, double q, int32_t D);
+kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                               const kabc_cost_t* cost, const kabc_pfilter_opts_t* opts,
+                               kabc_pfilter_result_t* result);
+
 #ifdef __cplusplus
 }
 #endif

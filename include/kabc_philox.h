@@ -42,6 +42,10 @@ typedef struct kabc_u128 {
 #define KABC_DOM_ABCDE_INIT_COST 10u /* src/smc.jl:358,364 */
 #define KABC_DOM_ABCDE_MOVE 11u      /* src/smc.jl:392-406 */
 #define KABC_DOM_ABCDE_COST 12u      /* src/smc.jl:408 */
+#define KABC_DOM_PF_INIT 13u         /* src/smc.jl:280,290 */
+#define KABC_DOM_PF_INIT_COST 14u    /* src/smc.jl:287,292 */
+#define KABC_DOM_PF_MOVE 15u         /* src/smc.jl:309-319 */
+#define KABC_DOM_PF_COST 16u         /* src/smc.jl:321 */
 
 KABC_HD kabc_u128_t kabc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                        uint32_t k0, uint32_t k1) {

@@ -8,7 +8,7 @@ from . import costs
 from ._cdefs import KABC_MAX_DIM
 from ._lib import Context, KabcError, LIB_PATH, default_context
 from .api import (ABCDE, AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity,
-                  MCMCThreads,
+                  MCMCThreads, pfilter,
                   Particles, sample, smc)
 from .costs import DeviceCost
 from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, LogNormal,
@@ -17,7 +17,7 @@ from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma,
 
 __all__ = [
     "ABCDE", "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "CommonLogDensity",
-    "MCMCThreads",
+    "MCMCThreads", "pfilter",
     "Particles", "sample", "smc", "DeviceCost", "costs", "Factored", "Uniform", "Normal",
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
     "Exponential", "Gamma", "LogNormal", "Context", "KabcError", "default_context", "LIB_PATH",

@@ -79,6 +79,18 @@ class AbcdeResult(C.Structure):
                 ("reserved", C.c_int32), ("generations_run", C.c_int64), ("nsims", C.c_uint64)]
 
 
+class PfilterOpts(C.Structure):
+    _fields_ = [("nparticles", C.c_int64), ("q", C.c_double), ("eff_tol", C.c_double),
+                ("epstol", C.c_double), ("proposal_width", C.c_double), ("max_iters", C.c_int64),
+                ("verbose", C.c_int32), ("reserved", C.c_int32), ("seed", C.c_uint64)]
+
+
+class PfilterResult(C.Structure):
+    _fields_ = [("theta", c_double_p), ("cost", c_double_p), ("eps", C.c_double),
+                ("eff", C.c_double), ("iterations", C.c_int64), ("nreps", C.c_uint64),
+                ("cost_evals", C.c_uint64)]
+
+
 # every symbol include/kabc.h declares: name -> (restype, argtypes)
 VP = C.c_void_p
 PROTOTYPES = {
@@ -117,6 +129,10 @@ PROTOTYPES = {
     "kabc_abcde_default_opts": (None, [C.POINTER(AbcdeOpts)]),
     "kabc_abcde_run": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),
                                  C.POINTER(AbcdeOpts), C.POINTER(AbcdeResult)]),
+    "kabc_pfilter_default_opts": (None, [C.POINTER(PfilterOpts)]),
+    "kabc_pfilter_nparticles": (C.c_int64, [C.c_int64, C.c_double, C.c_int32]),
+    "kabc_pfilter_run": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),
+                                   C.POINTER(PfilterOpts), C.POINTER(PfilterResult)]),
     "kabc_smc_run": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),
                                C.POINTER(SmcOpts), C.POINTER(SmcResult)]),
 }

@@ -372,3 +372,37 @@ def ABCDE(prior, cost, eps_target, *, nparticles=50, generations=20, α=0.0, alp
     info = {"generations_run": r.generations_run, "nsims": r.nsims}
     return AbcdeResult(theta if return_array else _bundle(theta, scalar), Cst,
                        bool(r.reached_eps), info)
+
+
+PfilterResult = collections.namedtuple("PfilterResult", ["P", "C", "info"])
+
+
+def pfilter(prior, cost, N, *, q=0.7, eff_tol=0.1, epstol=-math.inf, max_iters=math.inf,
+            proposal_width=0.75, verbose=False, parallel=False, seed=0, ctx=None,
+            return_array=False):
+    """pfilter(prior, cost, N; ...) -- src/smc.jl:275-340, same keywords
+    (`parallel` accepted and ignored).  Returns (P, C) as the reference does (+ info)."""
+    fac = as_factored(prior)
+    scalar = isinstance(prior, UnivariateDistribution)
+    if not isinstance(cost, DeviceCost):
+        raise TypeError("`cost` must be a DeviceCost on the MI355X path")
+    lib = _lib.load()
+    ctx = ctx or _lib.default_context()
+    o = cd.PfilterOpts()
+    lib.kabc_pfilter_default_opts(C.byref(o))
+    o.nparticles, o.q, o.eff_tol, o.epstol = int(N), float(q), float(eff_tol), float(epstol)
+    o.proposal_width, o.verbose, o.seed = float(proposal_width), int(bool(verbose)), int(seed)
+    o.max_iters = 0 if math.isinf(max_iters) else int(max_iters)
+    D = len(fac)
+    n_eff = lib.kabc_pfilter_nparticles(int(N), float(q), D)
+    theta = np.empty((n_eff, D))
+    Cst = np.empty(n_eff)
+    r = cd.PfilterResult()
+    r.theta = theta.ctypes.data_as(cd.c_double_p)
+    r.cost = Cst.ctypes.data_as(cd.c_double_p)
+    cc = cost.to_c()
+    _lib.check(lib.kabc_pfilter_run(ctx.handle, fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    info = {"eps": r.eps, "eff": r.eff, "iterations": r.iterations, "nreps": r.nreps,
+            "cost_evals": r.cost_evals, "nparticles": n_eff}
+    return PfilterResult(theta if return_array else _bundle(theta, scalar),
+                         Cst if return_array else Particles(Cst), info)

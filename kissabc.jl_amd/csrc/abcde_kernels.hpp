@@ -30,6 +30,7 @@ struct AbcdeArgs {
     uint64_t seed;
     int32_t cost_id;
     int32_t earlystop;
+    uint32_t dom_init, dom_init_cost;  // stream domains of the initial draws (ABCDE / pfilter)
     double eps_target;
     double alpha;
     double gamma;  // proposal_width * 2.38 / sqrt(2 * length(prior))  (:370)
@@ -49,12 +50,12 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_init_kernel(const AbcdeArgs
     double lp = 0.0, dl = 0.0;
     for (unsigned attempt = 0;; ++attempt) {
         for (int k = 0; k < D; ++k) {
-            kabc_slotwin_t win = {A.seed, (uint64_t)attempt, (uint32_t)i, KABC_DOM_ABCDE_INIT,
+            kabc_slotwin_t win = {A.seed, (uint64_t)attempt, (uint32_t)i, A.dom_init,
                                   (uint32_t)k * KABC_SLOTS_PER_DIM};
             x[k] = kabc_sample_prior(&A.raw[k], &win);
         }
         lp = factored_logpdf_push<D>(A.prior, x, xp);
-        kabc_cost_rng_t rng = {A.seed, (uint64_t)attempt, (uint32_t)i, KABC_DOM_ABCDE_INIT_COST, 0u};
+        kabc_cost_rng_t rng = {A.seed, (uint64_t)attempt, (uint32_t)i, A.dom_init_cost, 0u};
         // first pass: the cost is only evaluated when logπ is finite (:357-359);
         // in the re-draw loop it always is (:364).  cost(θ.x): NOT push_p'ed.
         const bool eval = (attempt > 0) || kabc_isfinite(lp);

@@ -137,6 +137,8 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     A.eps_target = o->eps_target;
     A.alpha = o->alpha;
     A.gamma = o->proposal_width * 2.38 / std::sqrt((double)(2 * D));
+    A.dom_init = KABC_DOM_ABCDE_INIT;
+    A.dom_init_cost = KABC_DOM_ABCDE_INIT_COST;
     f_init(A, s);
     KABC_HIP_CHECK(hipGetLastError());
     for (int64_t g = 0; g < o->generations; ++g) {  // while iters < generations (:372)

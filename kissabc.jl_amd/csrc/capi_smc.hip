@@ -9,6 +9,8 @@
 #include "host_common.hpp"
 #include "plugin_registry.hpp"
 #include "smc_kernels.hpp"
+#include "abcde_kernels.hpp"
+#include "pfilter_kernels.hpp"
 
 namespace kabc {
 
@@ -226,6 +228,8 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     sa.N = N;
     sa.alpha = alpha;
     sa.min_r_ess = min_r_ess;
+    sa.mode = 0;
+    sa.alive_out = alive;
     sa.stamps = nullptr;
     if (getenv("KABC_SMC_STAMPS")) {
         KABC_HIP_CHECK(bufs.alloc(&sa.stamps, 8));
@@ -358,6 +362,253 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     return rc;
+}
+
+
+// ---- pfilter(prior, cost, N; ...) -- src/smc.jl:275-340 ---------------------------
+void kabc_pfilter_default_opts(kabc_pfilter_opts_t* o) {
+    if (!o) return;
+    o->nparticles = 100;
+    o->q = 0.7;
+    o->eff_tol = 0.1;
+    o->epstol = -INFINITY;
+    o->proposal_width = 0.75;
+    o->max_iters = 0;
+    o->verbose = 0;
+    o->reserved = 0;
+    o->seed = 0;
+}
+
+int64_t kabc_pfilter_nparticles(int64_t N, double q, int32_t D) {
+    const int64_t lowN = 4 * (int64_t)D;  // :276-279
+    if ((double)N * q <= (double)lowN) N = (int64_t)std::ceil((double)(lowN + 1) / q);
+    return N;
+}
+
+}  // extern "C"
+
+namespace {
+template <int D>
+void pf_l_init(const AbcdeArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((abcde_init_kernel<D>), dim3((unsigned)((a.N + kAbcdeBlock - 1) / kAbcdeBlock)),
+                       dim3(kAbcdeBlock), 0, s, a);
+}
+template <int D>
+void pf_l_attempt(const PfArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((pf_attempt_kernel<D>), dim3((unsigned)((a.N + kPfBlock - 1) / kPfBlock)),
+                       dim3(kPfBlock), 0, s, a);
+}
+template <int... Ds>
+AbcdeLaunchFn pf_pick_init(int D, std::integer_sequence<int, Ds...>) {
+    static const AbcdeLaunchFn f[] = {&pf_l_init<Ds + 1>...};
+    return f[D - 1];
+}
+template <int... Ds>
+PfLaunchFn pf_pick_attempt(int D, std::integer_sequence<int, Ds...>) {
+    static const PfLaunchFn f[] = {&pf_l_attempt<Ds + 1>...};
+    return f[D - 1];
+}
+}  // namespace
+
+extern "C" {
+
+kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
+                               const kabc_cost_t* cost, const kabc_pfilter_opts_t* o,
+                               kabc_pfilter_result_t* res) {
+    if (!ctx || !prior || !cost || !o || !res) {
+        set_error("kabc_pfilter_run: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (D < 1 || D > KABC_MAX_DIM) {
+        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    if (!(o->q > 0 && o->q <= 1) || o->nparticles < 1) {
+        set_error("pfilter needs 0 < q <= 1 and N >= 1");
+        return KABC_ERR_INVALID_ARG;
+    }
+    PriorSet P;
+    if (!prepare_priors(prior, D, P)) {
+        set_error("invalid prior parameters");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (!cost_dim_ok_rt(cost->id, D)) {
+        set_error("DeviceCost id %d does not accept D = %d", cost->id, D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    AbcdeLaunchFn f_init;
+    PfLaunchFn f_att;
+    if (const CostPlugin* p = find_plugin(cost->id)) {
+        f_init = p->abcde_init ? (AbcdeLaunchFn)p->abcde_init(D) : nullptr;
+        f_att = p->pf_attempt ? (PfLaunchFn)p->pf_attempt(D) : nullptr;
+        if (!f_init || !f_att) {
+            set_error("cost plugin has no pfilter kernels for D = %d", D);
+            return KABC_ERR_UNSUPPORTED;
+        }
+    } else {
+        f_init = pf_pick_init(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+        f_att = pf_pick_attempt(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+    }
+    const int64_t N = kabc_pfilter_nparticles(o->nparticles, o->q, D);
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevBufs bufs;
+    double *th, *Cc, *lpi, *d_params = nullptr, *d_data = nullptr, *d_out, *d_cout;
+    uint8_t *ones, *ok, *pending;
+    int32_t *ridx, *cidx;
+    SmcCtrl* sel;
+    PfCtrl* pctrl;
+    AbcdeCtrl* actrl;
+    KABC_HIP_CHECK(bufs.alloc(&th, (size_t)N * D));
+    KABC_HIP_CHECK(bufs.alloc(&Cc, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&lpi, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&d_out, (size_t)N * D));
+    KABC_HIP_CHECK(bufs.alloc(&d_cout, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&ones, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&ok, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&pending, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&ridx, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&sel, 1));
+    KABC_HIP_CHECK(bufs.alloc(&pctrl, 1));
+    KABC_HIP_CHECK(bufs.alloc(&actrl, 1));
+    KABC_HIP_CHECK(hipMemsetAsync(ones, 1, (size_t)N, s));
+    KABC_HIP_CHECK(hipMemsetAsync(sel, 0, sizeof(SmcCtrl), s));
+    KABC_HIP_CHECK(hipMemsetAsync(pctrl, 0, sizeof(PfCtrl), s));
+    KABC_HIP_CHECK(hipMemsetAsync(actrl, 0, sizeof(AbcdeCtrl), s));
+    if (cost->nparams > 0) {
+        KABC_HIP_CHECK(bufs.alloc(&d_params, (size_t)cost->nparams));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_params, cost->params, sizeof(double) * cost->nparams,
+                                      hipMemcpyHostToDevice, s));
+    }
+    if (cost->ndata > 0) {
+        KABC_HIP_CHECK(bufs.alloc(&d_data, (size_t)cost->ndata));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_data, cost->data, sizeof(double) * cost->ndata,
+                                      hipMemcpyHostToDevice, s));
+    }
+    // :280-294 (same initial-draw loop as ABCDE, its own stream domains)
+    {
+        AbcdeArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.theta[0] = th;
+        a.delta[0] = Cc;
+        a.lpi[0] = lpi;
+        a.ctrl = actrl;
+        a.cost_params = d_params;
+        a.cost_data = d_data;
+        a.cost_ndata = cost->ndata;
+        a.N = N;
+        a.seed = o->seed;
+        a.cost_id = cost->id;
+        a.dom_init = KABC_DOM_PF_INIT;
+        a.dom_init_cost = KABC_DOM_PF_INIT_COST;
+        a.prior = P;
+        std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
+        f_init(a, s);
+        KABC_HIP_CHECK(hipGetLastError());
+        AbcdeCtrl hc;
+        KABC_HIP_CHECK(hipMemcpyAsync(&hc, actrl, sizeof hc, hipMemcpyDeviceToHost, s));
+        KABC_HIP_CHECK(hipStreamSynchronize(s));
+        if (hc.error) {
+            set_error("pfilter: the prior never produced a finite (cost, logpdf) pair for some particle");
+            return KABC_ERR_RETRY_EXHAUSTED;
+        }
+    }
+    SmcSelectArgs sa;
+    sa.Xbuf[0] = Cc;
+    sa.Xbuf[1] = Cc;
+    sa.alive = ones;
+    sa.alive_out = ok;
+    sa.ridx = ridx;
+    sa.cidx = cidx;
+    sa.ctrl = sel;
+    sa.N = N;
+    sa.alpha = o->q;
+    sa.min_r_ess = 1.0;
+    sa.stamps = nullptr;
+    sa.mode = 1;
+    PfArgs pa;
+    std::memset(&pa, 0, sizeof pa);
+    pa.theta = th;
+    pa.C = Cc;
+    pa.lpi = lpi;
+    pa.pending = pending;
+    pa.idxok = cidx;
+    pa.sel = sel;
+    pa.ctrl = pctrl;
+    pa.cost_params = d_params;
+    pa.cost_data = d_data;
+    pa.cost_ndata = cost->ndata;
+    pa.N = N;
+    pa.seed = o->seed;
+    pa.cost_id = cost->id;
+    pa.proposal_width = o->proposal_width;
+    pa.prior = P;
+    int64_t iters = 0;
+    double eps = 0.0, eff = 0.0;
+    SmcCtrl hsel;
+    PfCtrl hp;
+    std::memset(&hp, 0, sizeof hp);
+    while (true) {
+        ++iters;
+        hipLaunchKernelGGL(smc_select_kernel, dim3(1), dim3(kSelBlock), 0, s, sa);
+        hipLaunchKernelGGL(pf_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
+                           pending, ok, pctrl, sel, N);
+        pa.iteration = (uint64_t)iters;
+        uint32_t attempt = 0;
+        while (true) {
+            for (int g = 0; g < 8; ++g) {
+                pa.attempt = attempt++;
+                f_att(pa, s);
+            }
+            KABC_HIP_CHECK(hipGetLastError());
+            KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));
+            KABC_HIP_CHECK(hipMemcpyAsync(&hsel, sel, sizeof hsel, hipMemcpyDeviceToHost, s));
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+            if (hsel.error) {
+                set_error("pfilter: quantile of the costs is undefined (NaN or empty)");
+                return KABC_ERR_NAN_COST;
+            }
+            if (hp.remaining == 0) break;
+            if (attempt >= (1u << 24)) {
+                set_error("pfilter: a particle was not replaced after 2^24 proposals");
+                return KABC_ERR_RETRY_EXHAUSTED;
+            }
+        }
+        // NOTE passes enqueued after the last replacement are no-ops (nothing pending)
+        eps = hsel.eps;
+        const double nbad = (double)(N - hsel.ess);
+        eff = nbad / (double)hp.nreps;  // :327 (0/0 = NaN when nothing was bad, as in Julia)
+        if (o->verbose)
+            fprintf(stderr, "(iters, ϵ, eff) = (%lld, %.17g, %.17g)\n", (long long)iters, eps, eff);
+        if (eff < o->eff_tol) break;
+        if (eps < o->epstol) break;
+        if (o->max_iters > 0 && iters > o->max_iters) break;
+        if (!(hp.nreps > 0)) break;  // nothing left to refresh: eff is NaN forever
+    }
+    SmcFinalArgs fa;
+    fa.theta[0] = fa.theta[1] = th;
+    fa.X[0] = fa.X[1] = Cc;
+    fa.ctrl = sel;
+    fa.out = d_out;
+    fa.Xout = d_cout;
+    fa.N = N;
+    fa.D = D;
+    fa.prior = P;
+    hipLaunchKernelGGL(smc_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, fa);
+    KABC_HIP_CHECK(hipGetLastError());
+    if (res->theta)
+        KABC_HIP_CHECK(hipMemcpyAsync(res->theta, d_out, sizeof(double) * N * D,
+                                      hipMemcpyDeviceToHost, s));
+    if (res->cost)
+        KABC_HIP_CHECK(hipMemcpyAsync(res->cost, d_cout, sizeof(double) * N, hipMemcpyDeviceToHost, s));
+    KABC_HIP_CHECK(hipStreamSynchronize(s));
+    res->eps = eps;
+    res->eff = eff;
+    res->iterations = iters;
+    res->nreps = hp.total_reps;
+    res->cost_evals = hp.cost_evals;
+    return KABC_OK;
 }
 
 }  // extern "C"

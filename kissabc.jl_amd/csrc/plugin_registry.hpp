@@ -14,6 +14,7 @@ struct CostPlugin {
     void* (*smc_init)(int32_t D);                   // -> void (*)(const SmcInitArgs&, hipStream_t)
     void* (*abcde_init)(int32_t D);                 // -> AbcdeLaunchFn (may be NULL)
     void* (*abcde_gen)(int32_t D);                  // -> AbcdeLaunchFn (may be NULL)
+    void* (*pf_attempt)(int32_t D);                 // -> PfLaunchFn (may be NULL)
 };
 
 const CostPlugin* find_plugin(int cost_id);

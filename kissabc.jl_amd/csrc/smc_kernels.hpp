@@ -72,6 +72,11 @@ struct SmcSelectArgs {
     double alpha;
     double min_r_ess;
     unsigned long long* stamps;  // diagnostic (KABC_SMC_STAMPS): per-phase s_memtime sums [8]
+    // mode 1 = pfilter (src/smc.jl:298-301): ϵ = quantile(C, q) over ALL particles (the
+    // `alive` input is all ones), ok mask = !(C > ϵ) written to alive_out, idxok to
+    // cidx, count to ctrl->ess; no resampling, no ridx.  mode 0: alive_out == alive.
+    int32_t mode;
+    uint8_t* alive_out;
 };
 
 struct SmcMcmcArgs {
@@ -433,7 +438,7 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         if (kabc_isfinite(a) && kabc_isfinite(b)) eps = a + g * (b - a);
         else eps = (1.0 - g) * a + g * b;
         s_eps = eps;
-        s_flag = (eps > mn) ? 0 : 1;  // src/smc.jl:135-141
+        s_flag = (A.mode == 1) ? 1 : ((eps > mn) ? 0 : 1);  // src/smc.jl:135-141
     }
     __syncthreads();
     const double eps = s_eps;
@@ -485,7 +490,8 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     const long long ESS = base;
     KABC_STAMP(4)
     // Step 2 decision: α*ESS <= nparticles*min_r_ess  (src/smc.jl:145)
-    const int resample = (A.alpha * (double)ESS <= (double)N * A.min_r_ess) ? 1 : 0;
+    const int resample =
+        (A.mode == 0 && A.alpha * (double)ESS <= (double)N * A.min_r_ess) ? 1 : 0;
     if (resample && ESS == 0) {
         if (tid == 0) {
             A.ctrl->error = 2;
@@ -511,8 +517,8 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
             const int64_t i = tile * kSelBlock + tid;
             if (i < N) {
                 const double x = X[i];
-                A.alive[i] = (flag ? (x <= eps) : (x < eps)) ? 1 : 0;
-                A.ridx[i] = (int32_t)i;
+                A.alive_out[i] = (flag ? (x <= eps) : (x < eps)) ? 1 : 0;
+                if (A.mode == 0) A.ridx[i] = (int32_t)i;
             }
         }
     }

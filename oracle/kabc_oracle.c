@@ -1053,3 +1053,113 @@ done:
     free(th); free(nth); free(dl); free(ndl); free(lp); free(nlp);
     return rc;
 }
+
+/* ------------------------------------------------------------------------- */
+/* pfilter -- src/smc.jl:275-340 (exported, undocumented, untested upstream)  */
+/* ------------------------------------------------------------------------- */
+int64_t orc_pfilter_nparticles(int64_t N, double q, int32_t D) {
+    int64_t lowN = 4 * (int64_t)D; /* :276-279 */
+    if ((double)N * q <= (double)lowN) N = (int64_t)ceil((double)(lowN + 1) / q);
+    return N;
+}
+
+int32_t orc_pfilter_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cost,
+                        const kabc_pfilter_opts_t* o, kabc_pfilter_result_t* res) {
+    prep_t q[KABC_MAX_DIM];
+    if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
+    if (!cost_dim_ok_any(cost->id, D)) return fail(KABC_ERR_UNSUPPORTED, "cost id / dimension not supported");
+    if (!(o->q > 0 && o->q <= 1) || o->nparticles < 1)
+        return fail(KABC_ERR_INVALID_ARG, "pfilter needs 0 < q <= 1 and N >= 1");
+    const int64_t N = orc_pfilter_nparticles(o->nparticles, o->q, D);
+    const uint64_t seed = o->seed;
+    double* th = (double*)malloc(sizeof(double) * N * D);
+    double* Cc = (double*)malloc(sizeof(double) * N);
+    double* lp = (double*)malloc(sizeof(double) * N);
+    double* tmp = (double*)malloc(sizeof(double) * N);
+    int64_t* idxok = (int64_t*)malloc(sizeof(int64_t) * N);
+    uint8_t* bad = (uint8_t*)malloc(N);
+    double xp[KABC_MAX_DIM], p[KABC_MAX_DIM];
+    uint64_t total_reps = 0, cost_evals = 0;
+    int32_t rc = KABC_OK;
+    for (int64_t i = 0; i < N; ++i) { /* :280-294 */
+        for (unsigned attempt = 0;; ++attempt) {
+            factored_rand(prior, D, seed, (uint32_t)i, attempt, KABC_DOM_PF_INIT, th + i * D);
+            push_p(q, D, th + i * D, xp);
+            lp[i] = factored_logpdf(q, D, xp);
+            int eval = attempt > 0 || kabc_isfinite(lp[i]);
+            Cc[i] = eval ? orc_cost_eval(cost, D, th + i * D, seed, (uint32_t)i, attempt, KABC_DOM_PF_INIT_COST)
+                         : KABC_NAN;
+            if (kabc_isfinite(Cc[i]) && kabc_isfinite(lp[i])) break;
+            if (attempt >= 100000u) {
+                rc = fail(KABC_ERR_RETRY_EXHAUSTED, "pfilter: the prior never produced a finite (cost, logpdf) pair for some particle");
+                goto done;
+            }
+        }
+    }
+    int64_t iters = 0;
+    double eps = 0.0, eff = 0.0;
+    while (1) {
+        iters += 1;
+        memcpy(tmp, Cc, sizeof(double) * N);
+        qsort(tmp, N, sizeof(double), cmp_double);
+        quantile_sorted(tmp, N, o->q, &eps); /* ϵ = quantile(C, q) */
+        int64_t nok = 0, nbad = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            bad[i] = Cc[i] > eps;
+            if (bad[i]) ++nbad; else idxok[nok++] = i;
+        }
+        uint64_t nreps = 0;
+        for (int64_t i = 0; i < N; ++i) {
+            if (!bad[i]) continue;
+            for (uint32_t attempt = 0;; ++attempt) { /* @label resample */
+                uint64_t t = ((uint64_t)iters << 24) | attempt;
+                blk_t B0 = stream(seed, (uint32_t)i, t, 0, KABC_DOM_PF_MOVE);
+                blk_t B1 = stream(seed, (uint32_t)i, t, 1, KABC_DOM_PF_MOVE);
+                blk_t B2 = stream(seed, (uint32_t)i, t, 2, KABC_DOM_PF_MOVE);
+                partner_set_t ps = {0, nok, -1};
+                int64_t pb = draw_partner(B0.lo, &ps, NULL, 0);
+                int64_t pc = draw_partner(B0.hi, &ps, &pb, 1);
+                int64_t bc[2] = {pb, pc};
+                int64_t pd = draw_partner(B1.lo, &ps, bc, 2);
+                int64_t b = idxok[pb], c = idxok[pc], d = idxok[pd];
+                double z0, z1;
+                kabc_normal_pair(B2.lo, B2.hi, &z0, &z1);
+                double sc = z0 * o->proposal_width;
+                for (int k = 0; k < D; ++k) p[k] = th[b * D + k] + (th[d * D + k] - th[c * D + k]) * sc;
+                nreps += 1;
+                push_p(q, D, p, xp);
+                double ll = factored_logpdf(q, D, xp);
+                double wp = ll - lp[i];
+                double mn = wp;
+                if (!(wp < 0.0)) mn = (wp != wp) ? wp : 0.0;
+                double lu = kabc_log_pn(kabc_u01(B1.hi));
+                if (lu > mn) continue; /* @goto resample */
+                double Cp = orc_cost_eval(cost, D, p, seed, (uint32_t)i, t, KABC_DOM_PF_COST);
+                cost_evals += 1;
+                if (Cp > eps) continue;
+                Cc[i] = Cp;
+                memcpy(th + i * D, p, sizeof(double) * D);
+                lp[i] = ll;
+                break;
+            }
+        }
+        total_reps += nreps;
+        eff = (double)nbad / (double)nreps;
+        if (eff < o->eff_tol) break;
+        if (eps < o->epstol) break;
+        if (o->max_iters > 0 && iters > o->max_iters) break;
+        if (!(nreps > 0)) break;
+    }
+    for (int64_t i = 0; i < N; ++i) {
+        if (res->theta) push_p(q, D, th + i * D, res->theta + i * D);
+        if (res->cost) res->cost[i] = Cc[i];
+    }
+    res->eps = eps;
+    res->eff = eff;
+    res->iterations = iters;
+    res->nreps = total_reps;
+    res->cost_evals = cost_evals;
+done:
+    free(th); free(Cc); free(lp); free(tmp); free(idxok); free(bad);
+    return rc;
+}

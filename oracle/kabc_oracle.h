@@ -94,6 +94,10 @@ int32_t orc_smc_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cos
 /* ABCDE(prior, cost, ϵ_target; ...) -- src/smc.jl:347-430 */
 int32_t orc_abcde_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cost,
                       const kabc_abcde_opts_t* opts, kabc_abcde_result_t* result);
+/* pfilter(prior, cost, N; ...) -- src/smc.jl:275-340 */
+int64_t orc_pfilter_nparticles(int64_t N, double q, int32_t D);
+int32_t orc_pfilter_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cost,
+                        const kabc_pfilter_opts_t* opts, kabc_pfilter_result_t* result);
 /* Statistics.quantile(v, p) (type 7), restated; v is not modified */
 int32_t orc_quantile(const double* v, int64_t n, double p, double* out);
 

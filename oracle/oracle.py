@@ -75,6 +75,9 @@ def load():
             "orc_smc_run": (C.c_int32, [C.POINTER(cd.Prior), C.c_int32, C.POINTER(cd.Cost),
                                         C.POINTER(cd.SmcOpts), C.POINTER(cd.SmcResult)]),
             "orc_quantile": (C.c_int32, [dp, C.c_int64, C.c_double, dp]),
+            "orc_pfilter_nparticles": (C.c_int64, [C.c_int64, C.c_double, C.c_int32]),
+            "orc_pfilter_run": (C.c_int32, [C.POINTER(cd.Prior), C.c_int32, C.POINTER(cd.Cost),
+                                            C.POINTER(cd.PfilterOpts), C.POINTER(cd.PfilterResult)]),
             "orc_abcde_run": (C.c_int32, [C.POINTER(cd.Prior), C.c_int32, C.POINTER(cd.Cost),
                                           C.POINTER(cd.AbcdeOpts), C.POINTER(cd.AbcdeResult)]),
         }
@@ -321,3 +324,22 @@ def abcde(prior, cost, eps_target, *, nparticles=50, generations=20, alpha=0.0, 
     _check(load().orc_abcde_run(fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
     return {"P": theta, "C": Cst, "reached_eps": bool(r.reached_eps),
             "generations_run": r.generations_run, "nsims": r.nsims}
+
+
+def pfilter(prior, cost, N, *, q=0.7, eff_tol=0.1, epstol=-math.inf, max_iters=0,
+            proposal_width=0.75, seed=0):
+    """CPU restatement of pfilter (src/smc.jl:275-340); returns dict."""
+    fac = as_factored(prior)
+    o = cd.PfilterOpts()
+    o.nparticles, o.q, o.eff_tol, o.epstol = int(N), q, eff_tol, epstol
+    o.proposal_width, o.max_iters, o.verbose, o.seed = proposal_width, int(max_iters), 0, seed
+    D = len(fac)
+    n_eff = load().orc_pfilter_nparticles(int(N), q, D)
+    theta = np.empty((n_eff, D))
+    Cst = np.empty(n_eff)
+    r = cd.PfilterResult()
+    r.theta, r.cost = _dp(theta), _dp(Cst)
+    cc = cost.to_c()
+    _check(load().orc_pfilter_run(fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    return {"P": theta, "C": Cst, "eps": r.eps, "eff": r.eff, "iterations": r.iterations,
+            "nreps": r.nreps, "cost_evals": r.cost_evals}
