@@ -47,6 +47,15 @@ typedef struct kabc_u128 {
 #define KABC_DOM_PF_MOVE 15u         /* src/smc.jl:309-319 */
 #define KABC_DOM_PF_COST 16u         /* src/smc.jl:321 */
 
+/* a ^ b ^ c: one v_bitop3_b32 on gfx950 instead of two v_xor_b32 */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t kabc_xor3(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+}
+#else
+KABC_HD uint32_t kabc_xor3(uint32_t a, uint32_t b, uint32_t c) { return a ^ b ^ c; }
+#endif
+
 KABC_HD kabc_u128_t kabc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                        uint32_t k0, uint32_t k1) {
 #if defined(__clang__)
@@ -55,9 +64,9 @@ KABC_HD kabc_u128_t kabc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, ui
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)KABC_PHILOX_M0 * (uint64_t)c0;
         uint64_t p1 = (uint64_t)KABC_PHILOX_M1 * (uint64_t)c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n0 = kabc_xor3((uint32_t)(p1 >> 32), c1, k0);
         uint32_t n1 = (uint32_t)p1;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n2 = kabc_xor3((uint32_t)(p0 >> 32), c3, k1);
         uint32_t n3 = (uint32_t)p0;
         c0 = n0;
         c1 = n1;
