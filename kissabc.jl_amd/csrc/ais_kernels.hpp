@@ -200,7 +200,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int D>
 __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R, int si,
                                                 uint64_t t, uint32_t w_base, int n_active,
-                                                uint16_t* listN, uint8_t* listB, int lane) {
+                                                uint8_t* listB, int lane) {
     constexpr int NB = RecGeom<D>::NB;
     const uint64_t nc = (uint64_t)A.n_comp;
     const bool active = lane < n_active;
@@ -232,14 +232,13 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     const unsigned long long mDE = __ballot(move == 2), mWK = __ballot(move == 3);
     const unsigned long long mB = mDE | mWK;
     const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int nB = __popcll(mB);
-    const int nN = NB * __popcll(mDE) + 2 * __popcll(mWK);
-    if (move >= 2) {
-        listB[__popcll(mB & below)] = (uint8_t)lane;
-        const int base = NB * __popcll(mDE & below) + 2 * __popcll(mWK & below);
-        const int cnt = (move == 2) ? NB : 2;
-        for (int j = 0; j < cnt; ++j) listN[base + j] = (uint16_t)((lane << 4) | j);
-    }
+    // one lane list: DE lanes first, then walk lanes.  Work item e of the Box-Muller
+    // phase is decoded from it: e < nDE*NB -> (DE lane e / NB, block e % NB), else
+    // (walk lane (e - nDE*NB) / 2, block (e - nDE*NB) % 2).
+    const int nDE = __popcll(mDE), nB = __popcll(mB);
+    const int nN = NB * nDE + 2 * (nB - nDE);
+    if (move == 2) listB[__popcll(mDE & below)] = (uint8_t)lane;
+    if (move == 3) listB[nDE + __popcll(mWK & below)] = (uint8_t)lane;
     wave_lds_fence();
     // -- phase B2: partner rows b (and c) for DE / walk lanes, dense
 #pragma unroll 1
@@ -269,13 +268,16 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     // -- phase N: Box-Muller blocks, dense
 #pragma unroll 1
     for (int e = lane; e < ((A.ablate & 8) ? 0 : nN); e += kWave) {
-        const int ent = listN[e];
-        const int l = ent >> 4, j = ent & 15;
+        const int e2 = e - nDE * NB;
+        const bool is_de = e2 < 0;
+        const int q = is_de ? e / NB : nDE + (e2 >> 1);
+        const int j = is_de ? e - q * NB : (e2 & 1);
+        const int l = listB[q];
         const kabc_u128_t Bn = kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 3u + (uint32_t)j,
                                                  KABC_DOM_AIS_MOVE);
         double z0, z1;
         kabc_normal_pair(kabc_lo64(Bn), kabc_hi64(Bn), &z0, &z1);
-        const int lim = ((R.mva[si][l] >> 30) == 2u) ? D : 2;  // last variate index used
+        const int lim = is_de ? D : 2;  // last variate index used
         if (2 * j <= lim) R.zs[si][2 * j][l] = z0;
         if (2 * j + 1 <= lim) R.zs[si][2 * j + 1][l] = z1;
     }
@@ -301,7 +303,6 @@ template <int D, int COST, int PC>
 __global__ void __launch_bounds__(kAisBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ais_half_kernel(const AisArgs A) {
     __shared__ ChunkRec<D> rec[2];
-    __shared__ uint16_t listN[kChunk][kBatch * RecGeom<D>::NB];
     __shared__ uint8_t listB[kChunk][kBatch];
     // prepared prior components: read by the consumer with wave-uniform LDS
     // addresses (broadcast).  By-value kernel arguments made hipcc pin ~250 SGPRs
@@ -345,8 +346,8 @@ ais_half_kernel(const AisArgs A) {
     if (wave > 0) {
         const int si = wave - 1;
         if (si < A.nt && !(A.ablate & 4))
-            produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listN[si],
-                               listB[si], lane);
+            produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
+                               lane);
     }
     __syncthreads();
 
@@ -359,7 +360,7 @@ ais_half_kernel(const AisArgs A) {
             const int s = s0 + kChunk + si;
             if (s < A.nt && !(A.ablate & 2))
                 produce_substep<D>(A, rec[(c + 1) & 1], si, A.t0 + (uint64_t)s, w_base, n_active,
-                                   listN[si], listB[si], lane);
+                                   listB[si], lane);
         } else if (active && !(A.ablate & 1)) {
             // CONSUMER
             const ChunkRec<D>& R = rec[(A.ablate & 2) ? 0 : (c & 1)];
