@@ -114,9 +114,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = world > 1 or os.environ.get("KABC_FORCE_COLLECTIVE") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     model = build_model(k)
     n_total = WALKERS_PER_GPU * world
@@ -125,7 +127,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -135,8 +137,9 @@ def main():
         sync()
         s0 = sh.global_stats()
         # hipEvent pairs on the kernel's stream, one pair per 8 consecutive half-generation
-        # launches (a pair per launch adds ~3 us of marker overhead to every figure)
-        ens.set_timing(2 * steps, stride=8)
+        # launches (a pair per launch adds ~3 us of marker overhead to every figure); with
+        # collectives between the launches each launch gets its own pair instead
+        ens.set_timing(2 * steps, stride=1 if use_pg else 8)
         sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -147,7 +150,7 @@ def main():
         ens.set_timing(0)
         s1 = sh.global_stats()
         tmax = torch.tensor([el_r], dtype=torch.float64, device=dev)
-        if world > 1:
+        if use_pg:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()), kms_r, nl_r, s0, s1
 
@@ -160,6 +163,16 @@ def main():
         el2, kms2, nl2, a0, a1 = timed_region(100, k2, 2)
         alt = (el2, kms2, nl2, a1["proposals"] - a0["proposals"], k2)
 
+    # RCCL prints a version banner to the C stdout of every rank when its communicator
+    # comes up; push it out now so that the JSON below is the LAST line of the job
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if use_pg:
+        dist.barrier()
     if rank == 0:
         proposals = st1["proposals"] - st0["proposals"]
         cost_evals = st1["cost_evals"] - st0["cost_evals"]
@@ -204,8 +217,8 @@ def main():
                 "why": "README.md:57 and test/runtests.jl run AIS with ntransitions=100"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -17,6 +17,7 @@ collective and the kernels see the same memory), the current HIP stream, and
 torch.distributed.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -67,8 +68,10 @@ class HipEngine:
     def synchronize(self):
         self.stream.synchronize()
 
-    inplace_gather = False   # a 2 MiB staging copy is cheaper than the risk of an
-    # overlapping-buffer check in the collective
+    # RCCL's in-place all-gather: the send buffer is this rank's slice of the receive
+    # buffer (offset rank * count), the layout the half buffers already have -- no
+    # staging copy.  (torch's own FSDP issues all_gather_into_tensor the same way.)
+    inplace_gather = True
 
 
 class ShardedAIS:
@@ -90,7 +93,10 @@ class ShardedAIS:
         return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
 
     def _gather(self, half):
-        if self.world == 1:
+        # KABC_FORCE_COLLECTIVE=1 issues the collective at world size 1 too, so that the
+        # RCCL path can be exercised on a single-GPU box (tests/test_gpu_nccl_world1.py)
+        if self.world == 1 and not (dist.is_initialized() and
+                                    os.environ.get("KABC_FORCE_COLLECTIVE") == "1"):
             return
         with self._stream_ctx():
             buf = self.engine.half[half]
