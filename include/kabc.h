@@ -20,6 +20,7 @@
 #ifndef KABC_H
 #define KABC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -110,6 +111,15 @@ kabc_status_t kabc_ctx_create(int32_t device_id, void* stream, kabc_ctx_t** out)
 kabc_status_t kabc_ctx_destroy(kabc_ctx_t* ctx);
 kabc_status_t kabc_ctx_synchronize(kabc_ctx_t* ctx);
 
+/* Page-locked host memory for the buffers the caller hands to kabc_ais_advance
+ * (out_samples): the sample trace is then DMA'd over PCIe while the next
+ * generations compute.  Any other host pointer is accepted too (the runtime stages
+ * pageable copies, several times slower).  The reference returns its samples in
+ * GC-managed Julia arrays (src/KissABC.jl:82-94); this pair is what the host shim
+ * allocates them with. */
+kabc_status_t kabc_host_alloc(size_t bytes, void** out);
+kabc_status_t kabc_host_free(void* p);
+
 /* ---- Factored utilities (device kernels; host in, host out) ----------------
  * logpdf(d::Factored, x) for n rows x[n][D]      -- src/priors.jl:275-281
  * push_p(d::Factored, x)                          -- src/types.jl:111-114
@@ -185,7 +195,9 @@ kabc_status_t kabc_ais_end_generation(kabc_ais_t* h, int32_t ntransitions);
  * Runs ngenerations generations (single-process handles only).  out_samples, if
  * not NULL, is a HOST buffer [ngenerations][N][D] receiving push_p(walker) in
  * walker-id order after each generation: exactly the samples the reference's
- * step() emits over N*ngenerations calls.  stats (optional) accumulates. */
+ * step() emits over N*ngenerations calls.  stats (optional) accumulates.
+ * The trace is streamed out in chunks while later generations compute; hand over a
+ * kabc_host_alloc buffer for the full PCIe rate (any host pointer works). */
 kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntransitions,
                                double* out_samples, kabc_stats_t* stats);
 

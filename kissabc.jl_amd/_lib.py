@@ -94,3 +94,38 @@ def default_context(device=0):
     if ctx is None:
         ctx = _default_ctx[device] = Context(device)
     return ctx
+
+
+class _PinnedBlock:
+    """One kabc_host_alloc allocation, released when the last numpy view dies."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        check(load().kabc_host_alloc(C.c_size_t(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p.value, nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr and _lib is not None:
+                _lib.kabc_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+        self.ptr = None
+
+
+def pinned_empty(shape, dtype="float64"):
+    """numpy array over page-locked host memory (kabc_host_alloc): the destination of
+    the sample trace, so that kabc_ais_advance can DMA it while the kernels run.
+    Falls back to ordinary memory when pinning fails or KABC_PINNED_TRACE=0."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    if n == 0 or os.environ.get("KABC_PINNED_TRACE", "1") == "0":
+        return np.empty(shape, dtype=dt)
+    try:
+        blk = _PinnedBlock(n)
+    except KabcError:
+        return np.empty(shape, dtype=dt)
+    buf = (C.c_char * n).from_address(blk.ptr)
+    buf._kabc_block = blk
+    return np.frombuffer(buf, dtype=dt).reshape(shape)

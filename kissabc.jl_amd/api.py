@@ -12,6 +12,7 @@ ABI of include/kabc.h.  This file only marshals arguments and shapes results
 (bundle_samples / chainsstack, src/KissABC.jl:82-104).
 """
 import collections
+import concurrent.futures
 import ctypes as C
 import math
 
@@ -153,12 +154,17 @@ class AisEnsemble:
         return self
 
     # step(rng, model, spl, state; ntransitions) x N x ngenerations -- src/KissABC.jl:66-80
-    def advance(self, ngenerations, ntransitions=1, collect=False):
+    def advance(self, ngenerations, ntransitions=1, collect=False, out=None):
+        """`collect=True` returns the sample trace [generation][walker][D]; `out` may
+        supply its buffer (C-contiguous float64, e.g. from _lib.pinned_empty)."""
         lib = _lib.load()
-        out = None
         ptr = None
-        if collect:
-            out = np.empty((int(ngenerations), self.N, self.D))
+        if collect or out is not None:
+            shape = (int(ngenerations), self.N, self.D)
+            if out is None:
+                out = _lib.pinned_empty(shape)
+            if out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
+                raise ValueError(f"out must be a C-contiguous float64 array of shape {shape}")
             ptr = out.ctypes.data_as(cd.c_double_p)
         st = cd.Stats()
         _lib.check(lib.kabc_ais_advance(self._h, int(ngenerations), int(ntransitions), ptr,
@@ -258,14 +264,19 @@ def sample(model, spl, *args, ntransitions=1, discard_initial=0, retry_sampling=
     Ns = int(Ns)
     N = spl.nparticles
     ens = AisEnsemble(model, N, seed=seed, ctx=ctx)
+    gk = max(1, -(-Ns // N))
+    # the page-locked trace buffer is allocated on a helper thread (pinning costs
+    # ~40 us per MiB) while init and the discarded generations run on the device
+    pool = concurrent.futures.ThreadPoolExecutor(1)
+    buf = pool.submit(_lib.pinned_empty, (gk, N, len(model)))
     try:
         ens.init(retry_sampling)
         gd = -(-int(discard_initial) // N)
         if gd:
             ens.advance(gd, ntransitions)
-        gk = max(1, -(-Ns // N))
-        out = ens.advance(gk, ntransitions, collect=True).reshape(gk * N, len(model))[:Ns]
+        out = ens.advance(gk, ntransitions, out=buf.result()).reshape(gk * N, len(model))[:Ns]
     finally:
+        pool.shutdown(wait=True)
         ens.close()
     return out if return_array else _bundle(out, model.scalar)
 

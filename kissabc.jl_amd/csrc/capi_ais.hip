@@ -1,7 +1,10 @@
 // capi_ais.hip -- the AIS entry points of the C ABI (include/kabc.h):
 // AIS(N) + AISState + step(init) + step(advance) of src/KissABC.jl:21-80,
 // executed by the gfx950 kernels in ais_kernels.hpp.
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "ais_kernels.hpp"
@@ -71,6 +74,8 @@ void launch_ais_init(int D, const InitArgs& a, hipStream_t s) {
 
 using namespace kabc;
 
+static constexpr int kTraceBufs = 3;
+
 struct kabc_ais {
     kabc_ctx_t* ctx;
     int32_t D, posterior, cost_id;
@@ -97,9 +102,12 @@ struct kabc_ais {
     AisLaunchFn launch;
     double box_lp;
     bool initialised;
-    // trace staging
-    double* d_trace;
+    // sample-trace streaming: device chunks filled in rotation by the kernels and
+    // drained to the caller's buffer on a copy stream while the next chunks compute
+    double* d_trace[kTraceBufs];
     int64_t trace_cap_gens;
+    hipStream_t copy_stream;
+    hipEvent_t ev_filled[kTraceBufs];
     // debug records (tests)
     int32_t* d_dbg;
     int64_t dbg_cap;  // in int32 units
@@ -206,8 +214,12 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->seed = seed;
     h->t = 0;
     h->initialised = false;
-    h->d_trace = nullptr;
     h->trace_cap_gens = 0;
+    h->copy_stream = nullptr;
+    for (int b = 0; b < kTraceBufs; ++b) {
+        h->d_trace[b] = nullptr;
+        h->ev_filled[b] = nullptr;
+    }
     h->d_dbg = nullptr;
     h->dbg_cap = 0;
     h->timing = false;
@@ -434,35 +446,111 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
     KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
     const int64_t gen_elems = h->N * h->D;
-    int64_t chunk = 1;
-    if (out_samples) {
-        chunk = (int64_t)((256ull << 20) / (sizeof(double) * (size_t)gen_elems));
-        if (chunk < 1) chunk = 1;
-        if (chunk > ngenerations) chunk = ngenerations;
-        if (chunk > h->trace_cap_gens) {
-            if (h->d_trace) KABC_HIP_CHECK(hipFree(h->d_trace));
-            h->d_trace = nullptr;
-            KABC_HIP_CHECK(hipMalloc(&h->d_trace, sizeof(double) * gen_elems * chunk));
-            h->trace_cap_gens = chunk;
-        }
-    }
-    for (int64_t g0 = 0; g0 < ngenerations; g0 += chunk) {
-        const int64_t gc = (ngenerations - g0 < chunk) ? ngenerations - g0 : chunk;
-        for (int64_t g = 0; g < gc; ++g) {
-            double* tr0 = out_samples ? h->d_trace + g * gen_elems : nullptr;
-            double* tr1 = out_samples ? tr0 + h->rows[0] * h->D : nullptr;
-            kabc_status_t st = kabc_ais_half_generation(h, 0, ntransitions, tr0);
+    const size_t gen_bytes = sizeof(double) * (size_t)gen_elems;
+    if (!out_samples || ngenerations == 0) {
+        for (int64_t g = 0; g < ngenerations; ++g) {
+            kabc_status_t st = kabc_ais_half_generation(h, 0, ntransitions, nullptr);
             if (st) return st;
-            st = kabc_ais_half_generation(h, 1, ntransitions, tr1);
+            st = kabc_ais_half_generation(h, 1, ntransitions, nullptr);
             if (st) return st;
             h->t += (uint64_t)ntransitions;
         }
-        if (out_samples) {
-            KABC_HIP_CHECK(hipMemcpyAsync(out_samples + g0 * gen_elems, h->d_trace,
-                                          sizeof(double) * gen_elems * gc, hipMemcpyDeviceToHost,
-                                          s));
-            KABC_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+        // ---- sample-trace streaming ------------------------------------------------
+        // The kernels write the trace into kTraceBufs device chunks in rotation; a drain
+        // thread copies each finished chunk to the caller's buffer while this thread keeps
+        // the device fed with the next chunks.  The copies are issued from their own
+        // thread because hipMemcpyAsync to host memory holds its calling thread until the
+        // chunk's kernels have finished (measured: the whole run time, pinned or not); on
+        // this thread that would stop kernel submission and idle the device.
+        // 4..32 MiB chunks (1/16 of the trace): long enough to amortise a copy's set-up,
+        // short enough that the last copy -- the only one no kernel hides -- is a short tail.
+        size_t target = gen_bytes * (size_t)ngenerations / 16;
+        if (target < (4ull << 20)) target = 4ull << 20;
+        if (target > (32ull << 20)) target = 32ull << 20;
+        if (const char* e = std::getenv("KABC_TRACE_CHUNK_MIB")) {  // tuning/probing only
+            const long mib = std::atol(e);
+            if (mib > 0) target = (size_t)mib << 20;
         }
+        int64_t chunk = (int64_t)(target / gen_bytes);
+        if (chunk < 1) chunk = 1;
+        if (chunk > ngenerations) chunk = ngenerations;
+        if (chunk > h->trace_cap_gens) {
+            for (int b = 0; b < kTraceBufs; ++b) {
+                if (h->d_trace[b]) KABC_HIP_CHECK(hipFree(h->d_trace[b]));
+                h->d_trace[b] = nullptr;
+                KABC_HIP_CHECK(hipMalloc(&h->d_trace[b], gen_bytes * chunk));
+            }
+            h->trace_cap_gens = chunk;
+        }
+        if (!h->copy_stream) {
+            KABC_HIP_CHECK(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+            for (int b = 0; b < kTraceBufs; ++b)
+                KABC_HIP_CHECK(hipEventCreateWithFlags(&h->ev_filled[b], hipEventDisableTiming));
+        }
+        const int64_t nchunks = (ngenerations + chunk - 1) / chunk;
+        std::mutex mu;
+        std::condition_variable cv;
+        int64_t filled = 0, drained = 0;  // chunks submitted / chunks copied out
+        bool abort_drain = false;
+        hipError_t drain_err = hipSuccess;
+        std::thread drainer([&] {
+            hipError_t e = hipSetDevice(h->ctx->device);
+            for (int64_t c = 0; c < nchunks && e == hipSuccess; ++c) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return filled > c || abort_drain; });
+                    if (abort_drain) break;
+                }
+                const int b = (int)(c % kTraceBufs);
+                const int64_t gc = (c + 1 < nchunks) ? chunk : ngenerations - c * chunk;
+                e = hipEventSynchronize(h->ev_filled[b]);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync(out_samples + c * chunk * gen_elems, h->d_trace[b],
+                                       gen_bytes * gc, hipMemcpyDeviceToHost, h->copy_stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(h->copy_stream);
+                std::lock_guard<std::mutex> lk(mu);
+                drained = c + 1;
+                cv.notify_all();
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            drain_err = e;
+            drained = nchunks;  // releases the submitter on error
+            cv.notify_all();
+        });
+        kabc_status_t st = KABC_OK;
+        hipError_t sub_err = hipSuccess;
+        for (int64_t c = 0; c < nchunks && st == KABC_OK && sub_err == hipSuccess; ++c) {
+            const int b = (int)(c % kTraceBufs);
+            const int64_t gc = (c + 1 < nchunks) ? chunk : ngenerations - c * chunk;
+            if (c >= kTraceBufs) {  // the chunk that used this buffer last must be out
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return drained > c - kTraceBufs; });
+                if (drain_err != hipSuccess) break;
+            }
+            for (int64_t g = 0; g < gc && st == KABC_OK; ++g) {
+                double* tr0 = h->d_trace[b] + g * gen_elems;
+                st = kabc_ais_half_generation(h, 0, ntransitions, tr0);
+                if (st == KABC_OK)
+                    st = kabc_ais_half_generation(h, 1, ntransitions, tr0 + h->rows[0] * h->D);
+                if (st == KABC_OK) h->t += (uint64_t)ntransitions;
+            }
+            if (st != KABC_OK) break;
+            sub_err = hipEventRecord(h->ev_filled[b], s);
+            if (sub_err != hipSuccess) break;
+            std::lock_guard<std::mutex> lk(mu);
+            filled = c + 1;
+            cv.notify_all();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (st != KABC_OK || sub_err != hipSuccess) abort_drain = true;
+            cv.notify_all();
+        }
+        drainer.join();
+        if (st != KABC_OK) return st;
+        KABC_HIP_CHECK(sub_err);
+        KABC_HIP_CHECK(drain_err);
     }
     DevCounters c;
     if (read_counters(h, &c)) return KABC_ERR_DEVICE;
@@ -634,7 +722,11 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h) {
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->d_prior) (void)hipFree(h->d_prior);
-    if (h->d_trace) (void)hipFree(h->d_trace);
+    for (int b = 0; b < kTraceBufs; ++b) {
+        if (h->d_trace[b]) (void)hipFree(h->d_trace[b]);
+        if (h->ev_filled[b]) (void)hipEventDestroy(h->ev_filled[b]);
+    }
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->d_dbg) (void)hipFree(h->d_dbg);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;

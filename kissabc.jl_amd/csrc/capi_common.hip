@@ -185,6 +185,21 @@ kabc_status_t kabc_ctx_synchronize(kabc_ctx_t* ctx) {
     return KABC_OK;
 }
 
+kabc_status_t kabc_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) {
+        set_error("kabc_host_alloc: NULL out pointer or zero size");
+        return KABC_ERR_INVALID_ARG;
+    }
+    *out = nullptr;
+    KABC_HIP_CHECK(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return KABC_OK;
+}
+
+kabc_status_t kabc_host_free(void* p) {
+    if (p) KABC_HIP_CHECK(hipHostFree(p));
+    return KABC_OK;
+}
+
 static kabc_status_t prior_util(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D, int64_t n,
                                 const double* x, double* out, int mode, uint64_t seed,
                                 uint64_t attempt, uint32_t first_walker, uint32_t domain) {
