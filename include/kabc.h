@@ -133,6 +133,15 @@ kabc_status_t kabc_factored_rand(kabc_ctx_t* ctx, const kabc_prior_t* prior, int
                                  uint64_t seed, uint32_t domain, int64_t first_walker, int64_t n,
                                  uint64_t attempt, double* out);
 
+/* ---- arithmetic-contract probe (verification only) ---------------------------
+ * Evaluates one function of include/kabc_math.h on the device for n host inputs, so
+ * that tests can compare the gfx950 code with the host build of the same header bit
+ * for bit.  fn: 0 log, 1 exp, 2 log1p, 3 lgamma, 4 sincos2pi (out[2n]), 5 sqrt,
+ * 6 rint, 7 log_pn, 8 sqrt_pn, 9 u01 (x = 64 random bits), 10 normal_pair
+ * (x = pairs of 64-bit words, out[2n]), 11 index32 (x = pairs (bits, n), out as double). */
+kabc_status_t kabc_math_probe(kabc_ctx_t* ctx, int32_t fn, int64_t n, const double* x,
+                              double* out);
+
 /* ---- user DeviceCost plugins ------------------------------------------------
  * Replaces "cost is an arbitrary closure" (src/types.jl:124,137; src/smc.jl:94) for
  * costs that can be written as a C function (signature: include/kabc_costs.h,

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "kabc_ctx_create": (C.c_int, [C.c_int32, VP, C.POINTER(VP)]),
     "kabc_ctx_destroy": (C.c_int, [VP]),
     "kabc_ctx_synchronize": (C.c_int, [VP]),
+    "kabc_math_probe": (C.c_int, [VP, C.c_int32, C.c_int64, c_double_p, c_double_p]),
     "kabc_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(VP)]),
     "kabc_host_free": (C.c_int, [VP]),
     "kabc_factored_logpdf": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.c_int64, c_double_p,

@@ -129,3 +129,22 @@ def pinned_empty(shape, dtype="float64"):
     buf = (C.c_char * n).from_address(blk.ptr)
     buf._kabc_block = blk
     return np.frombuffer(buf, dtype=dt).reshape(shape)
+
+
+MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6,
+           "log_pn": 7, "sqrt_pn": 8, "u01": 9, "normal_pair": 10, "index32": 11}
+
+
+def math_probe(name, x, ctx=None):
+    """kabc_math_probe: one include/kabc_math.h function evaluated on the device
+    (verification only; 64-bit words travel as the bit patterns of doubles)."""
+    import numpy as np
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = x.size // (2 if name in ("normal_pair", "index32") else 1)
+    ow = 2 if name in ("sincos2pi", "normal_pair") else 1
+    out = np.empty(n * ow)
+    ctx = ctx or default_context()
+    check(load().kabc_math_probe(ctx.handle, MATH_FN[name], n,
+                                 x.ctypes.data_as(_cdefs.c_double_p),
+                                 out.ctypes.data_as(_cdefs.c_double_p)))
+    return out.reshape(-1, 2) if ow == 2 else out

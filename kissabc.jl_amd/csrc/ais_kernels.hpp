@@ -213,7 +213,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         const kabc_u128_t B1 = kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_AIS_MOVE);
         const uint32_t m7 = (uint32_t)(((uint64_t)B0.w[2] * 7u) >> 32);  // rand((1,1,1,1,2,2,3))
         move = (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
-        a = (uint32_t)kabc_index(kabc_lo64(B0), nc);
+        a = kabc_index32(kabc_lo64(B0), (uint32_t)nc);
         R.logu[si][lane] = kabc_log_pn(kabc_u01(kabc_lo64(B1)));
         if (move == 1) {
             // Z = cdf_g_inv(rand(rng), 3.0); correction (D-1) log Z
@@ -247,10 +247,10 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         const uint32_t al = R.mva[si][l] & 0x3fffffffu;
         const kabc_u128_t B2 =
             kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 2u, KABC_DOM_AIS_MOVE);
-        int64_t b = (int64_t)kabc_index(kabc_lo64(B2), nc - 1u);
+        int64_t b = (int64_t)kabc_index32(kabc_lo64(B2), (uint32_t)nc - 1u);
         b += (b >= (int64_t)al);
         const int64_t lo = (int64_t)al < b ? (int64_t)al : b, hi = (int64_t)al < b ? b : (int64_t)al;
-        int64_t c = (int64_t)kabc_index(kabc_hi64(B2), nc - 2u);
+        int64_t c = (int64_t)kabc_index32(kabc_hi64(B2), (uint32_t)nc - 2u);
         c += (c >= lo);
         c += (c >= hi);
         R.bb[si][l] = (uint32_t)b;

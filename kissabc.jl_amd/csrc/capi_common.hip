@@ -123,6 +123,39 @@ __global__ void __launch_bounds__(256) prior_rand_kernel(const PriorUtilArgs A) 
 
 using namespace kabc;
 
+namespace kabc {
+// arithmetic-contract probe: one kabc_math.h function per launch (include/kabc.h)
+__global__ void math_probe_kernel(int fn, int64_t n, const double* __restrict__ x,
+                                  double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        switch (fn) {
+            case 0: out[i] = kabc_log(x[i]); break;
+            case 1: out[i] = kabc_exp(x[i]); break;
+            case 2: out[i] = kabc_log1p(x[i]); break;
+            case 3: out[i] = kabc_lgamma(x[i]); break;
+            case 4: {
+                double s, c;
+                kabc_sincos2pi(x[i], &s, &c);
+                out[2 * i] = s;
+                out[2 * i + 1] = c;
+            } break;
+            case 5: out[i] = kabc_sqrt(x[i]); break;
+            case 6: out[i] = kabc_rint(x[i]); break;
+            case 7: out[i] = kabc_log_pn(x[i]); break;
+            case 8: out[i] = kabc_sqrt_pn(x[i]); break;
+            case 9: out[i] = kabc_u01(kabc_bits(x[i])); break;
+            case 10:
+                kabc_normal_pair(kabc_bits(x[2 * i]), kabc_bits(x[2 * i + 1]), &out[2 * i],
+                                 &out[2 * i + 1]);
+                break;
+            default:
+                out[i] = (double)kabc_index32(kabc_bits(x[2 * i]), (uint32_t)x[2 * i + 1]);
+        }
+    }
+}
+}  // namespace kabc
+
 extern "C" {
 
 int32_t kabc_version(void) { return KABC_VERSION; }
@@ -259,6 +292,32 @@ kabc_status_t kabc_factored_rand(kabc_ctx_t* ctx, const kabc_prior_t* prior, int
                                  uint64_t attempt, double* out) {
     return prior_util(ctx, prior, D, n, nullptr, out, 2, seed, attempt, (uint32_t)first_walker,
                       domain);
+}
+
+kabc_status_t kabc_math_probe(kabc_ctx_t* ctx, int32_t fn, int64_t n, const double* x,
+                              double* out) {
+    if (!ctx || !x || !out || n < 0 || fn < 0 || fn > 11) {
+        set_error("kabc_math_probe: bad argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (n == 0) return KABC_OK;
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    const int in_w = (fn == 10 || fn == 11) ? 2 : 1, out_w = (fn == 4 || fn == 10) ? 2 : 1;
+    double *dx = nullptr, *dout = nullptr;
+    KABC_HIP_CHECK(hipMalloc(&dx, sizeof(double) * n * in_w));
+    KABC_HIP_CHECK(hipMalloc(&dout, sizeof(double) * n * out_w));
+    KABC_HIP_CHECK(hipMemcpyAsync(dx, x, sizeof(double) * n * in_w, hipMemcpyHostToDevice,
+                                  ctx->stream));
+    const int blocks = (int)((n + 255) / 256 < 65535 ? (n + 255) / 256 : 65535);
+    hipLaunchKernelGGL(kabc::math_probe_kernel, dim3(blocks), dim3(256), 0, ctx->stream, fn, n, dx,
+                       dout);
+    KABC_HIP_CHECK(hipGetLastError());
+    KABC_HIP_CHECK(hipMemcpyAsync(out, dout, sizeof(double) * n * out_w, hipMemcpyDeviceToHost,
+                                  ctx->stream));
+    KABC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    KABC_HIP_CHECK(hipFree(dx));
+    KABC_HIP_CHECK(hipFree(dout));
+    return KABC_OK;
 }
 
 }  // extern "C"

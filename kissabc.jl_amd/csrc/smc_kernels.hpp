@@ -565,10 +565,10 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
             const kabc_u128_t B1 = kabc_stream_block(A.seed, w, pass, 1u, KABC_DOM_SMC_MOVE);
             const kabc_u128_t B2 = kabc_stream_block(A.seed, w, pass, 2u, KABC_DOM_SMC_MOVE);
             // while a==i ... ; while b==i || b==a ...  (src/smc.jl:163-164)
-            int64_t a = (int64_t)kabc_index(kabc_lo64(B0), N - 1u);
+            int64_t a = (int64_t)kabc_index32(kabc_lo64(B0), (uint32_t)N - 1u);
             a += (a >= i);
             const int64_t lo = a < i ? a : i, hi = a < i ? i : a;
-            int64_t b = (int64_t)kabc_index(kabc_hi64(B0), N - 2u);
+            int64_t b = (int64_t)kabc_index32(kabc_hi64(B0), (uint32_t)N - 2u);
             b += (b >= lo);
             b += (b >= hi);
             double z0, z1;

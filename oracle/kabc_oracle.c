@@ -84,6 +84,15 @@ void orc_math_vec(int32_t fn, int64_t n, const double* x, double* out) {
             case 5: out[i] = kabc_sqrt(x[i]); break;
             case 6: out[i] = kabc_rint(x[i]); break;
             case 7: out[i] = kabc_log_pn(x[i]); break;
+            case 8: out[i] = kabc_sqrt_pn(x[i]); break;
+            case 9: out[i] = kabc_u01(kabc_bits(x[i])); break;
+            case 10:
+                kabc_normal_pair(kabc_bits(x[2 * i]), kabc_bits(x[2 * i + 1]), &out[2 * i],
+                                 &out[2 * i + 1]);
+                break;
+            case 11:
+                out[i] = (double)kabc_index32(kabc_bits(x[2 * i]), (uint32_t)x[2 * i + 1]);
+                break;
             default: out[i] = KABC_NAN;
         }
     }

@@ -97,14 +97,21 @@ def _dp(a):
     return a.ctypes.data_as(cd.c_double_p)
 
 
-MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6, "log_pn": 7}
+MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6,
+           "log_pn": 7, "sqrt_pn": 8, "u01": 9, "normal_pair": 10, "index32": 11}
+MATH_IN_W = {"normal_pair": 2, "index32": 2}
+MATH_OUT_W = {"sincos2pi": 2, "normal_pair": 2}
 
 
 def math_vec(name, x):
+    """x: float64 array (for u01 / normal_pair / index32 the 64-bit words are passed as
+    the bit patterns of doubles: use .view(np.float64) on a uint64 array)."""
     x = np.ascontiguousarray(x, dtype=np.float64)
-    out = np.empty(x.size * (2 if name == "sincos2pi" else 1))
-    load().orc_math_vec(MATH_FN[name], x.size, _dp(x), _dp(out))
-    return out.reshape(-1, 2) if name == "sincos2pi" else out
+    n = x.size // MATH_IN_W.get(name, 1)
+    ow = MATH_OUT_W.get(name, 1)
+    out = np.empty(n * ow)
+    load().orc_math_vec(MATH_FN[name], n, _dp(x), _dp(out))
+    return out.reshape(-1, 2) if ow == 2 else out
 
 
 def div_rc(x, c):
