@@ -37,7 +37,7 @@ struct AisArgs {
     double eps;             // scale | maxcost
     double reps;            // RN(1/eps) for kabc_div_rc
     double box_lp;          // prior class BOX: the in-support log-density (ordered sum of c0)
-    int32_t ablate;         // timing experiments only (KABC_ABLATE): 1 no consumer, 2 no producers
+    int32_t ablate;         // timing experiments only (KABC_ABLATE): 1 no consumer, 2 no producers, 64 HW_ID probe;
     const PriorDev* prior;  // [D] prepared components, device memory (scalar-loaded)
 };
 
@@ -200,7 +200,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 template <int D>
 __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R, int si,
                                                 uint64_t t, uint32_t w_base, int n_active,
-                                                uint8_t* listB, int lane) {
+                                                uint8_t* listB, int lane,
+                                                const double* logtab) {
     constexpr int NB = RecGeom<D>::NB;
     const uint64_t nc = (uint64_t)A.n_comp;
     const bool active = lane < n_active;
@@ -214,7 +215,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         const uint32_t m7 = (uint32_t)(((uint64_t)B0.w[2] * 7u) >> 32);  // rand((1,1,1,1,2,2,3))
         move = (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
         a = kabc_index32(kabc_lo64(B0), (uint32_t)nc);
-        R.logu[si][lane] = kabc_log_pn(kabc_u01(kabc_lo64(B1)));
+        R.logu[si][lane] = kabc_log_pn_tab(kabc_u01(kabc_lo64(B1)), logtab);
         if (move == 1) {
             // Z = cdf_g_inv(rand(rng), 3.0); correction (D-1) log Z
             const double sq3 = kabc_sqrt(3.0), isq3 = kabc_sqrt(1.0 / 3.0);
@@ -222,7 +223,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
             const double tz = u * (sq3 - isq3) + isq3;
             const double Z = tz * tz;
             R.zs[si][0][lane] = Z;
-            R.zs[si][1][lane] = (double)(D - 1) * kabc_log_pn(Z);
+            R.zs[si][1][lane] = (double)(D - 1) * kabc_log_pn_tab(Z, logtab);
         }
     }
     R.mva[si][lane] = ((uint32_t)move << 30) | a;
@@ -276,7 +277,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         const kabc_u128_t Bn = kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 3u + (uint32_t)j,
                                                  KABC_DOM_AIS_MOVE);
         double z0, z1;
-        kabc_normal_pair(kabc_lo64(Bn), kabc_hi64(Bn), &z0, &z1);
+        kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &z0, &z1, logtab);
         const int lim = is_de ? D : 2;  // last variate index used
         if (2 * j <= lim) R.zs[si][2 * j][l] = z0;
         if (2 * j + 1 <= lim) R.zs[si][2 * j + 1][l] = z1;
@@ -309,6 +310,8 @@ ais_half_kernel(const AisArgs A) {
     // and spill them to VGPR lanes (385 v_readlane per transition).
     __shared__ PriorDev sprior[D];
     __shared__ double sbox_lo[D], sbox_hi[D];
+    // the producers' copy of the log table (include/kabc_math.h): per-lane lookups
+    __shared__ __attribute__((aligned(16))) double slogtab[384];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     const int64_t r0 = (int64_t)blockIdx.x * kBatch;
@@ -331,6 +334,7 @@ ais_half_kernel(const AisArgs A) {
         ll = A.ll[r];
     }
 
+    for (int j = threadIdx.x; j < 384; j += kAisBlock) slogtab[j] = kabc_log_tab[j];
     if (threadIdx.x < D * (int)(sizeof(PriorDev) / 8))
         reinterpret_cast<double*>(sprior)[threadIdx.x] =
             reinterpret_cast<const double*>(A.prior)[threadIdx.x];
@@ -342,12 +346,15 @@ ais_half_kernel(const AisArgs A) {
     for (int k = 0; k < D; ++k) dmask |= (A.prior[k].discrete ? 1u : 0u) << k;
     const BoxPrior box = {sbox_lo, sbox_hi, dmask, A.box_lp};
 
+    // the log table is staged by all four waves and read by the producers right away
+    __syncthreads();
+
     // prologue: producers fill chunk 0
     if (wave > 0) {
         const int si = wave - 1;
         if (si < A.nt && !(A.ablate & 4))
             produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
-                               lane);
+                               lane, slogtab);
     }
     __syncthreads();
 
@@ -360,7 +367,7 @@ ais_half_kernel(const AisArgs A) {
             const int s = s0 + kChunk + si;
             if (s < A.nt && !(A.ablate & 2))
                 produce_substep<D>(A, rec[(c + 1) & 1], si, A.t0 + (uint64_t)s, w_base, n_active,
-                                   listB[si], lane);
+                                   listB[si], lane, slogtab);
         } else if (active && !(A.ablate & 1)) {
             // CONSUMER
             const ChunkRec<D>& R = rec[(A.ablate & 2) ? 0 : (c & 1)];
@@ -474,6 +481,12 @@ ais_half_kernel(const AisArgs A) {
         __syncthreads();
     }
 
+    if ((A.ablate & 64) && A.dbg && lane == 0) {
+        // placement probe (KABC_ABLATE=64 with debug records on): HW_ID of each wave
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        A.dbg[(r0 * A.nt) * 6 + wave] = (int32_t)hw;
+    }
     if (wave == 0) {
         if (active) {
             store_row<D>(A.x_act + row * D, x);
