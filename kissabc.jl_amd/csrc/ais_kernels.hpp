@@ -319,6 +319,20 @@ ais_half_kernel(const AisArgs A) {
     const int n_active = rem >= kBatch ? kBatch : (int)rem;
     const uint32_t w_base = A.id_base + (uint32_t)(A.row_first + r0);
     const int nchunks = (A.nt + kChunk - 1) / kChunk;
+    // KABC_ABLATE=128 (with debug records on): cycles each wave spends at the barriers
+    const bool tprobe = (A.ablate & 128) && A.dbg;
+    unsigned long long t_begin = 0, t_bar = 0;
+    if (tprobe) t_begin = __builtin_amdgcn_s_memtime();
+#define KABC_TIMED_BARRIER()                                              \
+    do {                                                                  \
+        if (tprobe) {                                                     \
+            const unsigned long long tb_ = __builtin_amdgcn_s_memtime(); \
+            __syncthreads();                                              \
+            t_bar += __builtin_amdgcn_s_memtime() - tb_;                  \
+        } else {                                                          \
+            __syncthreads();                                              \
+        }                                                                 \
+    } while (0)
 
     // consumer state (wave 0)
     const bool active = (wave == 0) && (lane < n_active);
@@ -347,7 +361,7 @@ ais_half_kernel(const AisArgs A) {
     const BoxPrior box = {sbox_lo, sbox_hi, dmask, A.box_lp};
 
     // the log table is staged by all four waves and read by the producers right away
-    __syncthreads();
+    KABC_TIMED_BARRIER();
 
     // prologue: producers fill chunk 0
     if (wave > 0) {
@@ -356,7 +370,7 @@ ais_half_kernel(const AisArgs A) {
             produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
                                lane, slogtab);
     }
-    __syncthreads();
+    KABC_TIMED_BARRIER();
 
 #pragma unroll 1
     for (int c = 0; c < nchunks; ++c) {
@@ -478,9 +492,15 @@ ais_half_kernel(const AisArgs A) {
                 if (si + 1 < ns && !err) substep(si + 1, r1a, r1b, r0a, r0b);
             }
         }
-        __syncthreads();
+        KABC_TIMED_BARRIER();
     }
 
+    if (tprobe && lane == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        int32_t* d = A.dbg + (r0 * A.nt) * 6 + 8 + wave * 2;
+        d[0] = (int32_t)(t_end - t_begin);
+        d[1] = (int32_t)t_bar;
+    }
     if ((A.ablate & 64) && A.dbg && lane == 0) {
         // placement probe (KABC_ABLATE=64 with debug records on): HW_ID of each wave
         uint32_t hw;

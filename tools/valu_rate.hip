@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 
 #define ITERS 2048
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -161,13 +162,16 @@ MIXK(k_mix_e64, "v_cndmask_b32_e64 %0, %0, %1, vcc")
 
 typedef void (*kern_t)(double*, double);
 
-int main() {
+int main(int argc, char** argv) {
     double* d;
     CK(hipMalloc(&d, 64));
     hipDeviceProp_t p;
     CK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
-    const int blocks = cus * 8;  // 8 workgroups of 256 = 32 waves per CU = 8 per SIMD
+    // default: 8 workgroups of 256 = 32 waves per CU = 8 per SIMD (throughput);
+    // argv[1] = waves per SIMD (1 shows what ONE wave with 8 independent chains can issue)
+    const int wps = argc > 1 ? atoi(argv[1]) : 8;
+    const int blocks = cus * wps;
     struct { const char* name; kern_t k; } ks[] = {
         {"v_add_f32", k_add_f32},       {"v_bitop3_b32", k_xor3},       {"v_cndmask_b32", k_cndmask},
         {"mix_6add_2cndmask_e32", k_mix2_e32}, {"mix_4add_4cndmask_e32", k_mix4_e32},
@@ -192,7 +196,7 @@ int main() {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     double base = 0;
-    printf("{\"cus\": %d, \"clock_mhz\": %d, \"rates\": {", cus, p.clockRate / 1000);
+    printf("{\"cus\": %d, \"clock_mhz\": %d, \"waves_per_simd\": %d, \"rates\": {", cus, p.clockRate / 1000, wps);
     for (size_t i = 0; i < sizeof ks / sizeof ks[0]; ++i) {
         hipLaunchKernelGGL(ks[i].k, dim3(blocks), dim3(256), 0, 0, d, 1.0);
         CK(hipDeviceSynchronize());
@@ -203,7 +207,7 @@ int main() {
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
         // wave-instructions per SIMD: 8 waves * ITERS * 8 chains * 5 launches
-        const double per_simd = 8.0 * ITERS * 8 * 5;
+        const double per_simd = (double)wps * ITERS * 8 * 5;
         const double ns_per_instr = ms * 1e6 / per_simd;
         if (i == 0) base = ns_per_instr;
         printf("%s\"%s\": {\"ns_per_wave_instr_per_simd\": %.3f, \"cycles_if_add_f32_is_4\": %.2f}",
