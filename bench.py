@@ -3,10 +3,15 @@
 
 Workload (BASELINE.json configs[2]): AIS, 65 536 walkers per GPU,
 D = 8, prior Factored(Uniform(-5,5))^8, cost sqrt(sum 100(x[k+1]-x[k]^2)^2 +
-(1-x[k])^2), ApproxKernelizedPosterior scale 1.0, ntransitions = 16, seed 1.
+(1-x[k])^2), ApproxKernelizedPosterior scale 1.0, seed 1, ntransitions = 100 -- the
+value the reference itself samples with (README.md:57, four of the AIS testsets of
+test/runtests.jl; BASELINE.json configs[0]); SURVEY §8d's ntransitions = 16 is timed
+in the same run and reported beside it as `also_at_ntransitions_16`.
 A "step" is one GENERATION: every walker receives `ntransitions` transition!()
 calls (two half-generation kernel launches per GPU; for N>1 one RCCL all-gather
-after each).  Weak scaling: per-GPU walkers are fixed, N_total = 65 536 * gpus.
+after each, i.e. the exchange is amortised over ntransitions sub-steps exactly as
+the reference amortises its per-sample overhead).  Weak scaling: per-GPU walkers are
+fixed, N_total = 65 536 * gpus.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the half-generation kernel:
 algorithmic bytes per launch = rows * ntransitions * 8(3D+4)
@@ -26,7 +31,8 @@ if ROOT not in sys.path:
 
 WALKERS_PER_GPU = 65536
 D = 8
-NT = 16
+NT = 100
+NT_ALT = 16
 SEED = 1
 HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
@@ -88,7 +94,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true",
-                    help="skip the secondary ntransitions=100 region (clean rocprof summaries)")
+                    help="skip the secondary ntransitions=16 region (clean rocprof summaries)")
     args = ap.parse_args()
     nt = args.ntransitions
 
@@ -155,12 +161,12 @@ def main():
         return float(tmax.item()), kms_r, nl_r, s0, s1
 
     el, kms, nl, st0, st1 = timed_region(nt, args.steps, args.warmup)
-    # secondary figure at the reference's own setting: README.md:57 and four of its
-    # testsets run AIS with ntransitions = 100 (reported beside the headline, never as it)
+    # secondary figure at SURVEY §8d's ntransitions = 16 (launch prologue, tail and -- for
+    # N > 1 -- the exchange weigh 6x more per evaluation); reported beside the headline
     alt = None
-    if nt != 100 and not args.no_alt:
-        k2 = max(10, args.steps // 8)
-        el2, kms2, nl2, a0, a1 = timed_region(100, k2, 2)
+    if nt != NT_ALT and not args.no_alt:
+        k2 = max(20, args.steps)
+        el2, kms2, nl2, a0, a1 = timed_region(NT_ALT, k2, 5)
         alt = (el2, kms2, nl2, a1["proposals"] - a0["proposals"], k2)
 
     # RCCL prints a version banner to the C stdout of every rank when its communicator
@@ -185,8 +191,8 @@ def main():
         # passes (FETCH_SIZE / WRITE_SIZE cannot share a pass); the committed summary
         # of that run is reported here when it was taken on this very workload.
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if nt == NT and os.path.exists(tf):
+        tf = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_nt{nt}.json")
+        if os.path.exists(tf):
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         out = {
             "metric": "walker proposal+cost evals/sec at N=65536 walkers, D=8",
@@ -210,11 +216,12 @@ def main():
         }
         if alt is not None:
             el2, kms2, nl2, prop2, k2 = alt
-            ach2 = rows * 100 * bytes_per_eval / (kms2 * 1e-3) / 1e9 if kms2 > 0 else 0.0
-            out["also_at_ntransitions_100"] = {
-                "value": prop2 / el2, "unit": "evals/s", "steps": k2, "kernel_avg_ms": kms2,
-                "roofline_achieved_GBps": ach2, "roofline_frac": ach2 / HBM_PEAK_GBS,
-                "why": "README.md:57 and test/runtests.jl run AIS with ntransitions=100"}
+            ach2 = rows * NT_ALT * bytes_per_eval / (kms2 * 1e-3) / 1e9 if kms2 > 0 else 0.0
+            out[f"also_at_ntransitions_{NT_ALT}"] = {
+                "value": prop2 / el2, "unit": "evals/s", "steps": k2, "ms_per_step": el2 / k2 * 1e3,
+                "kernel_avg_ms": kms2, "roofline_achieved_GBps": ach2,
+                "roofline_frac": ach2 / HBM_PEAK_GBS,
+                "why": "SURVEY 8d times C3 at ntransitions = 16 as well"}
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

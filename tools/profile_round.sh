@@ -2,7 +2,7 @@ cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r01f; mkdir -p $O
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-alt > $O/bench_under_rocprof.json 2> $O/stats.err
-B="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-alt"
+B="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-alt"   # default ntransitions = 100; add --ntransitions 16 for the secondary figure
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $B > /dev/null 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH --output-format csv -d $O/pmc_inst -- $B > /dev/null 2>&1
