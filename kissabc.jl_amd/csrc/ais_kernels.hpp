@@ -300,7 +300,10 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     }
 }
 
-template <int D, int COST, int PC>
+// PK = posterior kind (KABC_POSTERIOR_*) as a compile-time constant: with the kind read
+// from the arguments the consumer carried three run-time branches per sub-step in
+// loglike/accept and the SGPRs to feed them -- 8 % of the launch.
+template <int D, int COST, int PC, int PK>
 __global__ void __launch_bounds__(kAisBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
 ais_half_kernel(const AisArgs A) {
     __shared__ ChunkRec<D> rec[2];
@@ -446,20 +449,20 @@ ais_half_kernel(const AisArgs A) {
                 kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u};
                 double nlp, nll;
                 bool ev;
-                loglike<D, COST, PC>(sprior, box, A.posterior, A.eps, A.reps, y, A.cost_params,
+                loglike<D, COST, PC>(sprior, box, PK, A.eps, A.reps, y, A.cost_params,
                                      A.cost_data, A.cost_ndata, &rng, nlp, nll, ev);
                 __builtin_amdgcn_sched_barrier(0);
                 n_eval += ev ? 1u : 0u;
                 // accept(...)  src/types.jl:144-157, :178-186
                 bool acc = false;
                 if (!kabc_isfinite(corr)) err = 1;
-                else if (!ld_valid(A.posterior, lp, ll)) err = 2;
-                else if (ld_valid(A.posterior, nlp, nll)) {
+                else if (!ld_valid(PK, lp, ll)) err = 2;
+                else if (ld_valid(PK, nlp, nll)) {
                     const double e = -logu;  // randexp(rng)
-                    if (A.posterior == KABC_POSTERIOR_KERNELIZED) {
+                    if (PK == KABC_POSTERIOR_KERNELIZED) {
                         const double lW = corr + (nlp + nll) - (lp + ll);
                         acc = (-e <= lW);
-                    } else if (A.posterior == KABC_POSTERIOR_COMMON) {
+                    } else if (PK == KABC_POSTERIOR_COMMON) {
                         const double lW = corr + nll - ll;  // src/types.jl:209
                         acc = (-e <= lW);
                     } else {
@@ -516,7 +519,7 @@ ais_half_kernel(const AisArgs A) {
                 double xp[D];
 #pragma unroll
                 for (int k = 0; k < D; ++k)
-                    xp[k] = (sprior[k].discrete && A.posterior != KABC_POSTERIOR_COMMON)
+                    xp[k] = (sprior[k].discrete && PK != KABC_POSTERIOR_COMMON)
                                 ? kabc_rint(x[k]) : x[k];
                 store_row<D>(A.trace + r * D, xp);
             }
@@ -585,7 +588,9 @@ __global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) 
 
 // launchers (defined by the instantiation units)
 using AisLaunchFn = void (*)(const AisArgs&, hipStream_t);
-AisLaunchFn find_ais_kernel(int cost_id, int D, int prior_class);
+// pcx = prior class + 3 * (posterior kind - 1)
+AisLaunchFn find_ais_kernel(int cost_id, int D, int pcx);
+constexpr int kAisVariants = 9;
 void launch_ais_init(int D, const InitArgs& a, hipStream_t s);
 
 }  // namespace kabc

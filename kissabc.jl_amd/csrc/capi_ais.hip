@@ -171,7 +171,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
                           m->prior[k].kind == KABC_PRIOR_DISCRETE_UNIFORM);
     }
     const int pc = isbox ? kPriorBox : simple ? kPriorSimple : kPriorGeneral;
-    AisLaunchFn fn = find_ais_kernel(m->cost.id, m->D, pc);
+    AisLaunchFn fn = find_ais_kernel(m->cost.id, m->D, pc + 3 * (m->posterior - 1));
     if (!fn) {
         set_error("no gfx950 kernel instantiated for cost id %d, D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
