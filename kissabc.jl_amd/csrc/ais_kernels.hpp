@@ -349,6 +349,7 @@ ais_half_kernel(const AisArgs A) {
         load_row<D>(A.x_act + row * D, x);
         lp = A.lp[r];
         ll = A.ll[r];
+        if (!ld_valid(PK, lp, ll)) err = 2;  // accept(): "old log-density is invalid"
     }
 
     for (int j = threadIdx.x; j < 384; j += kAisBlock) slogtab[j] = kabc_log_tab[j];
@@ -454,9 +455,10 @@ ais_half_kernel(const AisArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
                 n_eval += ev ? 1u : 0u;
                 // accept(...)  src/types.jl:144-157, :178-186
+                // (the old state's validity is checked once, before the first sub-step: it
+                // can only change through an accept, which requires a valid new state)
                 bool acc = false;
-                if (!kabc_isfinite(corr)) err = 1;
-                else if (!ld_valid(PK, lp, ll)) err = 2;
+                if (!kabc_isfinite(corr)) err = err ? err : 1;
                 else if (ld_valid(PK, nlp, nll)) {
                     const double e = -logu;  // randexp(rng)
                     if (PK == KABC_POSTERIOR_KERNELIZED) {
@@ -489,10 +491,13 @@ ais_half_kernel(const AisArgs A) {
                     d[5] = ev ? 1 : 0;
                 }
             };
+            // an error (src/types.jl:145-150) is sticky and reported after the launch; the
+            // remaining sub-steps still run (their result is discarded by the host), which
+            // keeps the loop bounds wave-uniform
 #pragma unroll 1
-            for (int si = 0; si < ns && !err; si += 2) {
+            for (int si = 0; si < ns; si += 2) {
                 substep(si, r0a, r0b, r1a, r1b);
-                if (si + 1 < ns && !err) substep(si + 1, r1a, r1b, r0a, r0b);
+                if (si + 1 < ns) substep(si + 1, r1a, r1b, r0a, r0b);
             }
         }
         KABC_TIMED_BARRIER();
