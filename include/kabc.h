@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KABC_VERSION 100 /* 0.1.0 */
+#define KABC_VERSION 101 /* 0.1.1 */
 #define KABC_MAX_DIM 16  /* compile-time upper bound on length(prior) on the device path */
 
 typedef enum kabc_status {

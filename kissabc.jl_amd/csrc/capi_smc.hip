@@ -172,6 +172,9 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&ctrl, 1));
     KABC_HIP_CHECK(bufs.alloc(&slots, (size_t)kSmcSlots * 8));
+    unsigned long long* part;  // per-workgroup cost statistics for the select kernel
+    const int64_t npart = (N + kSmcBlock - 1) / kSmcBlock;
+    KABC_HIP_CHECK(bufs.alloc(&part, (size_t)npart * 4));
     KABC_HIP_CHECK(bufs.alloc(&d_out, (size_t)N * D));
     KABC_HIP_CHECK(bufs.alloc(&d_Xout, (size_t)N));
     if (log_cap > 0) KABC_HIP_CHECK(bufs.alloc(&d_log, (size_t)log_cap));
@@ -209,6 +212,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         a.seed = o->seed;
         a.cost_id = cost->id;
         a.prior = P;
+        a.part = part;
         std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
         if (const CostPlugin* pl = find_plugin(cost->id)) {
             using Fn = void (*)(const SmcInitArgs&, hipStream_t);
@@ -230,6 +234,8 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     sa.min_r_ess = min_r_ess;
     sa.mode = 0;
     sa.alive_out = alive;
+    sa.part = part;
+    sa.npart = npart;
     sa.stamps = nullptr;
     if (getenv("KABC_SMC_STAMPS")) {
         KABC_HIP_CHECK(bufs.alloc(&sa.stamps, 8));
@@ -253,6 +259,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     ma.seed = o->seed;
     ma.max_stretch = o->max_stretch;
     ma.prior = P;
+    ma.part = part;
     SmcLoopParams lpz;
     lpz.mcmc_tol = o->mcmc_tol;
     lpz.epstol = o->epstol;
@@ -527,6 +534,8 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     sa.min_r_ess = 1.0;
     sa.stamps = nullptr;
     sa.mode = 1;
+    sa.part = nullptr;  // pfilter's kernels do not produce the partials: select scans C
+    sa.npart = 0;
     PfArgs pa;
     std::memset(&pa, 0, sizeof pa);
     pa.theta = th;

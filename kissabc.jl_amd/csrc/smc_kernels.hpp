@@ -60,6 +60,7 @@ struct SmcInitArgs {
     int32_t cost_id;
     PriorSet prior;
     kabc_prior_t raw[KABC_MAX_DIM];
+    unsigned long long* part;  // [workgroups][4] cost statistics of the block, see smc_block_stats
 };
 
 struct SmcSelectArgs {
@@ -77,6 +78,10 @@ struct SmcSelectArgs {
     // cidx, count to ctrl->ess; no resampling, no ridx.  mode 0: alive_out == alive.
     int32_t mode;
     uint8_t* alive_out;
+    // per-workgroup (count, NaNs, min key, ~max key) of the alive costs, written by the
+    // kernel that produced X (smc_init_kernel / smc_mcmc_kernel); NULL = scan X here
+    const unsigned long long* part;
+    int64_t npart;
 };
 
 struct SmcMcmcArgs {
@@ -94,6 +99,7 @@ struct SmcMcmcArgs {
     uint64_t seed;
     double max_stretch;
     PriorSet prior;
+    unsigned long long* part;  // [workgroups][4], see smc_block_stats
 };
 
 struct SmcFinalArgs {
@@ -121,31 +127,57 @@ __device__ __forceinline__ double val_of(uint64_t k) {
     return kabc_from_bits(u);
 }
 
+// The kernels that produce X leave what the next ε-selection needs to know about it --
+// count, NaN count and key range of the ALIVE costs of their 64 particles -- so that the
+// single-workgroup select kernel reads N/64 partials instead of scanning X once more
+// (that scan was 12 of its 54 us at C4).  Called by all 64 threads of the workgroup.
+__device__ __forceinline__ void smc_block_stats(unsigned long long* part, bool alive, double x) {
+    if (!part) return;
+    const uint64_t k = key_of(x);
+    unsigned long long cnt = wave_sum(alive ? 1ull : 0ull);
+    unsigned long long nan = wave_sum((alive && x != x) ? 1ull : 0ull);
+    uint64_t kmin = alive ? k : ~0ull, kmaxn = alive ? ~k : ~0ull;
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const uint64_t a = __shfl_down(kmin, off, kWave), b = __shfl_down(kmaxn, off, kWave);
+        kmin = a < kmin ? a : kmin;
+        kmaxn = b < kmaxn ? b : kmaxn;
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        unsigned long long* p = part + (size_t)blockIdx.x * 4;
+        p[0] = cnt;
+        p[1] = nan;
+        p[2] = kmin;
+        p[3] = kmaxn;
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(kSmcBlock) smc_init_kernel(const SmcInitArgs A) {
     const int64_t i = (int64_t)blockIdx.x * kSmcBlock + threadIdx.x;
-    if (i >= A.N) return;
-    double x[D], xp[D];
-    for (int k = 0; k < D; ++k) {
-        kabc_slotwin_t win = {A.seed, 0ull, (uint32_t)i, KABC_DOM_SMC_INIT,
-                              (uint32_t)k * KABC_SLOTS_PER_DIM};
-        x[k] = kabc_sample_prior(&A.raw[k], &win);
+    double c = 0.0;
+    if (i < A.N) {
+        double x[D], xp[D];
+        for (int k = 0; k < D; ++k) {
+            kabc_slotwin_t win = {A.seed, 0ull, (uint32_t)i, KABC_DOM_SMC_INIT,
+                                  (uint32_t)k * KABC_SLOTS_PER_DIM};
+            x[k] = kabc_sample_prior(&A.raw[k], &win);
+        }
+        const double lp = factored_logpdf_push<D>(A.prior, x, xp);
+        kabc_cost_rng_t rng = {A.seed, 0ull, (uint32_t)i, KABC_DOM_SMC_INIT_COST, 0u};
+        c = kabc_cost_eval(A.cost_id, xp, D, A.cost_params, A.cost_data, A.cost_ndata, &rng);
+        store_row<D>(A.theta + i * D, x);
+        A.X[i] = c;
+        A.lpi[i] = lp;
+        A.alive[i] = 1;
+        if (i == 0) {
+            SmcCtrl cc = {};
+            cc.eps = KABC_INF;       // ϵ = Inf  (src/smc.jl:127)
+            cc.eps_prev = KABC_INF;
+            cc.cost_evals = (unsigned long long)A.N;
+            *A.ctrl = cc;
+        }
     }
-    const double lp = factored_logpdf_push<D>(A.prior, x, xp);
-    kabc_cost_rng_t rng = {A.seed, 0ull, (uint32_t)i, KABC_DOM_SMC_INIT_COST, 0u};
-    const double c =
-        kabc_cost_eval(A.cost_id, xp, D, A.cost_params, A.cost_data, A.cost_ndata, &rng);
-    store_row<D>(A.theta + i * D, x);
-    A.X[i] = c;
-    A.lpi[i] = lp;
-    A.alive[i] = 1;
-    if (i == 0) {
-        SmcCtrl c = {};
-        c.eps = KABC_INF;       // ϵ = Inf  (src/smc.jl:127)
-        c.eps_prev = KABC_INF;
-        c.cost_evals = (unsigned long long)A.N;
-        *A.ctrl = c;
-    }
+    smc_block_stats(A.part, i < A.N, c);
 }
 
 #ifdef KABC_SMC_SINGLE_UNIT  // non-template kernels: defined once, in capi_smc.hip
@@ -217,7 +249,8 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     __shared__ unsigned int s_wcnt[kSelBlock / kWave];
     __shared__ uint64_t s_klo, s_khi, s_keya, s_keyb;
     __shared__ long long s_kt, s_nrange;
-    __shared__ unsigned int s_ncand;
+    __shared__ unsigned int s_ncand, s_ncand_all;
+    __shared__ int s_listed;  // cand[0..s_ncand_all) holds every alive key of one first-round bin
     __shared__ int s_state;  // 0 narrowing, 1 collect+sort, 2 a known (all keys of range equal)
     __shared__ double s_eps;
     __shared__ int s_flag, s_needmin;
@@ -235,16 +268,27 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     const double* __restrict__ X = A.Xbuf[A.ctrl->cur];
     const int64_t ntile = (N + kSelBlock - 1) / kSelBlock;
 
-    // (a) n = count(alive), NaN check, key range of the alive costs
+    // (a) n = count(alive), NaN check, key range of the alive costs: from the producers'
+    //     per-workgroup partials when there are any, else by scanning X
     long long cnt = 0, nanc = 0;
     uint64_t kmin = ~0ull, kmaxn = ~0ull;  // kmaxn = ~max
-    for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
-        ++cnt;
-        if (x != x) ++nanc;
-        const uint64_t k = key_of(x);
-        kmin = k < kmin ? k : kmin;
-        kmaxn = ~k < kmaxn ? ~k : kmaxn;
-    });
+    if (A.part) {
+        for (int64_t b = tid; b < A.npart; b += kSelBlock) {
+            const unsigned long long* p = A.part + (size_t)b * 4;
+            cnt += (long long)p[0];
+            nanc += (long long)p[1];
+            kmin = p[2] < kmin ? p[2] : kmin;
+            kmaxn = p[3] < kmaxn ? p[3] : kmaxn;
+        }
+    } else {
+        for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+            ++cnt;
+            if (x != x) ++nanc;
+            const uint64_t k = key_of(x);
+            kmin = k < kmin ? k : kmin;
+            kmaxn = ~k < kmaxn ? ~k : kmaxn;
+        });
+    }
     const long long n = block_sum_ll(cnt, sh_ll);
     const long long nn = block_sum_ll(nanc, sh_ll);
     kmin = block_min_u64(kmin, sh_u);
@@ -275,6 +319,8 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         s_kt = j - 1;
         s_nrange = n;
         s_state = (kmin == kmax) ? 2 : (n <= kSelCand ? 1 : 0);
+        s_listed = 0;
+        s_ncand_all = 0;
     }
     __syncthreads();
     for (int round = 0; round < 12 && s_state == 0; ++round) {
@@ -337,7 +383,11 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         }
         __syncthreads();
         const unsigned nc = s_ncand;
-        if (tid == 0) s_state = (s_nrange <= kWave) ? 3 : 0;
+        if (tid == 0) {
+            s_state = (s_nrange <= kWave) ? 3 : 0;
+            s_listed = 1;
+            s_ncand_all = nc;
+        }
         __syncthreads();
         for (int round = 0; round < 12 && s_state == 0; ++round) {
             const uint64_t klo = s_klo, khi = s_khi;
@@ -420,14 +470,25 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     }
     __syncthreads();
     if (s_needmin && n > 1) {
-        // rank j is the smallest alive key above the final range
+        // rank j is the smallest alive key above the final range.  It is nearly always
+        // among the candidates already in LDS (they cover the whole bin the first round
+        // selected); only when the final range ends that bin is X scanned again.
         const uint64_t khi = s_khi;
         uint64_t kgt = ~0ull;
-        for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
-            const uint64_t k = key_of(x);
-            if (k > khi) kgt = k < kgt ? k : kgt;
-        });
-        kgt = block_min_u64(kgt, sh_u);
+        if (s_listed) {
+            for (unsigned q = tid; q < s_ncand_all; q += kSelBlock) {
+                const uint64_t k = cand[q];
+                if (k > khi) kgt = k < kgt ? k : kgt;
+            }
+            kgt = block_min_u64(kgt, sh_u);
+        }
+        if (kgt == ~0ull) {  // uniform: kgt is the block-wide minimum
+            for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+                const uint64_t k = key_of(x);
+                if (k > khi) kgt = k < kgt ? k : kgt;
+            });
+            kgt = block_min_u64(kgt, sh_u);
+        }
         if (tid == 0) s_keyb = kgt;
     }
     __syncthreads();
@@ -552,13 +613,16 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
     const double* __restrict__ theta_src = A.theta[cur];
     const double* __restrict__ X_src = A.X[cur];
     const double* __restrict__ lpi_src = A.lpi[cur];
+    double Xfin = 0.0;
+    bool alive_i = false;
     if (i < A.N) {
         const int64_t si = gather ? A.ridx[i] : i;
         double th[D];
         load_row<D>(theta_src + si * D, th);
         double Xi = X_src[si];
         double lpi = lpi_src[si];
-        if (A.alive[i]) {
+        alive_i = A.alive[i] != 0;
+        if (alive_i) {
             const uint64_t N = (uint64_t)A.N;
             const uint32_t w = (uint32_t)i;
             const kabc_u128_t B0 = kabc_stream_block(A.seed, w, pass, 0u, KABC_DOM_SMC_MOVE);
@@ -610,7 +674,9 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
         store_row<D>(A.theta[1 - cur] + i * D, th);
         A.X[1 - cur][i] = Xi;
         A.lpi[1 - cur][i] = lpi;
+        Xfin = Xi;
     }
+    smc_block_stats(A.part, alive_i, Xfin);
     // one counter line per workgroup (mod kSmcSlots): same-line atomics from 512
     // workgroups cost ~20 us per launch
     const unsigned long long se = wave_sum(n_eval), sa = wave_sum(n_acc), sp = wave_sum(n_prop);
