@@ -78,6 +78,43 @@ struct DevBufs {
 
 using namespace kabc;
 
+namespace kabc {
+// workgroups of the select kernel: one per 2048 particles, at most 16 (a device-wide
+// barrier costs ~1.7-2.4 us and grows with the count; KABC_SMC_SELECT_BLOCKS overrides)
+static unsigned select_blocks(int64_t N) {
+    long g = (long)((N + 2047) / 2048);
+    if (g > 16) g = 16;
+    if (const char* e = std::getenv("KABC_SMC_SELECT_BLOCKS")) {
+        const long v = std::atol(e);
+        if (v >= 1) g = v;
+    }
+    const long ntile = (long)((N + kSelBlock - 1) / kSelBlock);
+    if (g > ntile) g = ntile;
+    if (g > kSelMaxBlocks) g = kSelMaxBlocks;
+    return g < 1 ? 1u : (unsigned)g;
+}
+// The kernel's device-wide barrier needs its G <= 32 workgroups resident at the same
+// time.  They are launched as an ordinary grid: on this stream the previous kernel has
+// completed, 32 workgroups occupy 16 of 256 CUs, and a workgroup that has to wait for a
+// CU held by another stream's kernel only delays the barrier (that kernel does not wait
+// for us).  hipLaunchCooperativeKernel would guarantee residency but costs ~20 us per
+// launch here (measured: C4 went from 14.2 to 16.1 ms with it); KABC_SMC_COOPERATIVE=1
+// selects it anyway.
+static hipError_t launch_select(const SmcSelectArgs& sa, unsigned G, hipStream_t s) {
+    static const bool coop = [] {
+        const char* e = std::getenv("KABC_SMC_COOPERATIVE");
+        return e && e[0] == '1';
+    }();
+    if (G <= 1u || !coop) {
+        hipLaunchKernelGGL(smc_select_kernel, dim3(G), dim3(kSelBlock), 0, s, sa);
+        return hipGetLastError();
+    }
+    SmcSelectArgs a = sa;
+    void* args[] = {&a};
+    return hipLaunchCooperativeKernel((void*)smc_select_kernel, dim3(G), dim3(kSelBlock), args, 0, s);
+}
+}  // namespace kabc
+
 extern "C" {
 
 void kabc_smc_default_opts(kabc_smc_opts_t* o) {
@@ -172,6 +209,10 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&ctrl, 1));
     KABC_HIP_CHECK(bufs.alloc(&slots, (size_t)kSmcSlots * 8));
+    SmcSelScratch* sel_scratch;
+    KABC_HIP_CHECK(bufs.alloc(&sel_scratch, 1));
+    KABC_HIP_CHECK(hipMemsetAsync(sel_scratch, 0, sizeof(SmcSelScratch), s));
+    const unsigned selG = select_blocks(N);
     unsigned long long* part;  // per-workgroup cost statistics for the select kernel
     const int64_t npart = (N + kSmcBlock - 1) / kSmcBlock;
     KABC_HIP_CHECK(bufs.alloc(&part, (size_t)npart * 4));
@@ -236,6 +277,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     sa.alive_out = alive;
     sa.part = part;
     sa.npart = npart;
+    sa.scratch = sel_scratch;
     sa.stamps = nullptr;
     if (getenv("KABC_SMC_STAMPS")) {
         KABC_HIP_CHECK(bufs.alloc(&sa.stamps, 8));
@@ -278,7 +320,8 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     bool first = true;
     while (true) {
         for (int it = 0; it < kBatch; ++it) {
-            hipLaunchKernelGGL(smc_select_kernel, dim3(1), dim3(kSelBlock), 0, s, sa);
+            KABC_HIP_CHECK(launch_select(sa, selG, s));
+            bool ended = false;  // the iteration's end rode on the last pass_end launch
             for (int r0 = 0; r0 < R; r0 += kGroup) {
                 const int r1 = (r0 + kGroup < R) ? r0 + kGroup : R;
                 for (int r = r0; r < r1; ++r) {
@@ -286,8 +329,9 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
                     if (timed) KABC_HIP_CHECK(hipEventRecord(ev0, s));
                     mcmc(ma, s);
                     if (timed) KABC_HIP_CHECK(hipEventRecord(ev1, s));
+                    ended = (r == R - 1);
                     hipLaunchKernelGGL(smc_pass_end_kernel, dim3(1), dim3(kSmcSlots), 0, s, ctrl,
-                                       slots, N, o->mcmc_tol);
+                                       slots, N, o->mcmc_tol, ended ? 1 : 0, d_log, log_cap, lpz);
                 }
                 if (r1 < R) {  // many retries allowed: look before enqueueing more
                     KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
@@ -295,8 +339,9 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
                     if (hc.done || !hc.pass_open) break;
                 }
             }
-            hipLaunchKernelGGL(smc_iter_end_kernel, dim3(1), dim3(1), 0, s, ctrl, d_log, log_cap, N,
-                               lpz);
+            if (!ended)
+                hipLaunchKernelGGL(smc_iter_end_kernel, dim3(1), dim3(1), 0, s, ctrl, d_log,
+                                   log_cap, N, lpz);
         }
         KABC_HIP_CHECK(hipGetLastError());
         KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
@@ -536,6 +581,9 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     sa.mode = 1;
     sa.part = nullptr;  // pfilter's kernels do not produce the partials: select scans C
     sa.npart = 0;
+    KABC_HIP_CHECK(bufs.alloc(&sa.scratch, 1));
+    KABC_HIP_CHECK(hipMemsetAsync(sa.scratch, 0, sizeof(SmcSelScratch), s));
+    const unsigned selG = select_blocks(N);
     PfArgs pa;
     std::memset(&pa, 0, sizeof pa);
     pa.theta = th;
@@ -560,7 +608,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     std::memset(&hp, 0, sizeof hp);
     while (true) {
         ++iters;
-        hipLaunchKernelGGL(smc_select_kernel, dim3(1), dim3(kSelBlock), 0, s, sa);
+        KABC_HIP_CHECK(launch_select(sa, selG, s));
         hipLaunchKernelGGL(pf_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
                            pending, ok, pctrl, sel, N);
         pa.iteration = (uint64_t)iters;

@@ -63,6 +63,24 @@ struct SmcInitArgs {
     unsigned long long* part;  // [workgroups][4] cost statistics of the block, see smc_block_stats
 };
 
+constexpr int kSelBins = 1024;      // histogram bins per narrowing round
+constexpr int kSelCand = 4096;      // candidate keys narrowed in LDS
+constexpr int kSelRounds = 7;       // 7 x 10 bits > 64: global narrowing rounds at most
+constexpr int kSelMaxBlocks = 32;   // workgroups of the select kernel
+
+// global scratch of the multi-workgroup select kernel: zeroed once by the host, left
+// zeroed by every call (barrier words excepted: the generation only ever counts up)
+struct SmcSelScratch {
+    unsigned int bar_count, pad0[31];
+    unsigned int bar_gen, pad1[31];
+    unsigned int ncand, pad2[31];
+    unsigned int hist[kSelRounds][kSelBins];
+    unsigned long long part_stats[kSelMaxBlocks][4];
+    unsigned long long part_kgt[kSelMaxBlocks];
+    unsigned int slice_cnt[kSelMaxBlocks];
+    unsigned long long cand[kSelCand];
+};
+
 struct SmcSelectArgs {
     const double* Xbuf[2];
     uint8_t* alive;
@@ -82,6 +100,7 @@ struct SmcSelectArgs {
     // kernel that produced X (smc_init_kernel / smc_mcmc_kernel); NULL = scan X here
     const unsigned long long* part;
     int64_t npart;
+    SmcSelScratch* scratch;  // used when the kernel runs with more than one workgroup
 };
 
 struct SmcMcmcArgs {
@@ -206,22 +225,21 @@ __device__ __forceinline__ uint64_t block_min_u64(uint64_t v, uint64_t* sh) {
     return t;
 }
 
-// visit (i, key) of every alive particle; four independent (alive, X) load pairs are
-// issued per thread and iteration so that L2 latency overlaps (one dependent pair
-// per iteration made every pass over N cost ~13 us on the single workgroup)
+// visit (i, key) of every alive particle of [i_lo, i_hi); four independent (alive, X)
+// load pairs are issued per thread and iteration so that memory latency overlaps
 template <class F>
 __device__ __forceinline__ void for_each_alive(const uint8_t* __restrict__ alive,
-                                               const double* __restrict__ X, int64_t N, int tid,
-                                               F&& f) {
+                                               const double* __restrict__ X, int64_t i_lo,
+                                               int64_t i_hi, int tid, F&& f) {
     constexpr int U = 4;
-    for (int64_t i0 = tid; i0 < N; i0 += (int64_t)U * kSelBlock) {
+    for (int64_t i0 = i_lo + tid; i0 < i_hi; i0 += (int64_t)U * kSelBlock) {
         uint8_t al[U];
         double xv[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + (int64_t)u * kSelBlock;
-            al[u] = (i < N) ? alive[i] : (uint8_t)0;
-            xv[u] = (i < N) ? X[i] : 0.0;
+            al[u] = (i < i_hi) ? alive[i] : (uint8_t)0;
+            xv[u] = (i < i_hi) ? X[i] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -229,18 +247,44 @@ __device__ __forceinline__ void for_each_alive(const uint8_t* __restrict__ alive
     }
 }
 
-constexpr int kSelBins = 1024;   // histogram bins per narrowing round
-constexpr int kSelCand = 4096;   // candidate keys sorted in LDS
+// Device-wide barrier of the select kernel's G workgroups (cooperative launch: all of
+// them are resident).  Sense-reversing: one atomic per workgroup, thread 0 spins on the
+// generation word; 2.4 us at 32 x 1024 threads, about a kernel boundary (cooperative
+// groups' grid.sync() is 5.1 us; tools/gridsync_probe.hip).  G == 1: __syncthreads.
+__device__ __forceinline__ void sel_grid_barrier(SmcSelScratch* g, unsigned G) {
+    __syncthreads();
+    if (G > 1u) {
+        if (threadIdx.x == 0) {
+            volatile unsigned* gen = &g->bar_gen;
+            const unsigned my = *gen;
+            __threadfence();
+            if (atomicAdd(&g->bar_count, 1u) == G - 1u) {
+                atomicExch(&g->bar_count, 0u);
+                __threadfence();
+                atomicAdd(&g->bar_gen, 1u);
+            } else {
+                while (*gen == my) __builtin_amdgcn_s_sleep(1);
+            }
+            __threadfence();
+        }
+        __syncthreads();
+    }
+}
 
-// ε-selection, alive mask, ESS, resample decision and index -- one workgroup.
+// ε-selection, alive mask, ESS, resample decision and index -- G workgroups of 1024
+// (G = 1 for small N).  Every pass over the particles is split by contiguous slices;
+// everything that follows a pass (bin search, candidate ranking, ε) is computed
+// redundantly and identically by every workgroup from global scratch, so nothing has
+// to be broadcast and all workgroups take the same branches (and barriers).
 //
 // quantile: the two bracketing order statistics of the alive costs are found by
 // NARROWING on the order-preserving u64 keys: a 1024-bin histogram of
 // (key - klo) >> shift over the current key range [klo, khi] (bins are spread over
-// the range actually occupied, so LDS atomics do not pile onto one bin the way a
-// fixed leading-byte radix pass does), then the bin holding the target rank
-// becomes the new range, until at most 4096 candidates remain; those are
-// bitonic-sorted in LDS.  Typically: stats pass + 1 histogram pass + 1 collect pass.
+// the range actually occupied, so atomics do not pile onto one bin the way a fixed
+// leading-byte radix pass does), then the bin holding the target rank becomes the new
+// range, until at most 4096 candidates remain; those are narrowed further in LDS and
+// the last <= 64 ranked inside one wavefront.  Typically: 1 histogram pass + 1 collect
+// pass + the compaction passes, 4 device-wide barriers.
 __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectArgs A) {
     __shared__ unsigned int hist[kSelBins];
     __shared__ uint64_t cand[kSelCand];
@@ -249,24 +293,31 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     __shared__ unsigned int s_wcnt[kSelBlock / kWave];
     __shared__ uint64_t s_klo, s_khi, s_keya, s_keyb;
     __shared__ long long s_kt, s_nrange;
-    __shared__ unsigned int s_ncand, s_ncand_all;
+    __shared__ unsigned int s_ncand, s_ncand_all, s_base;
     __shared__ int s_listed;  // cand[0..s_ncand_all) holds every alive key of one first-round bin
-    __shared__ int s_state;  // 0 narrowing, 1 collect+sort, 2 a known (all keys of range equal)
+    __shared__ int s_state;   // 0 narrowing, 1 collect+sort, 2 a known (all keys of range equal)
     __shared__ double s_eps;
     __shared__ int s_flag, s_needmin;
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
+    const unsigned G = gridDim.x, bid = blockIdx.x;
+    SmcSelScratch* __restrict__ g = A.scratch;
     const int64_t N = A.N;
     if (A.ctrl->done) return;  // uniform: the loop ended in an earlier iteration
-    unsigned long long t_prev = A.stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+    unsigned long long t_prev = (A.stamps && bid == 0) ? __builtin_amdgcn_s_memtime() : 0ull;
 #define KABC_STAMP(slot)                                                   \
-    if (A.stamps && tid == 0) {                                            \
+    if (A.stamps && bid == 0 && tid == 0) {                                \
         const unsigned long long t_now = __builtin_amdgcn_s_memtime();     \
         A.stamps[slot] += t_now - t_prev;                                  \
         t_prev = t_now;                                                    \
     }
     const double* __restrict__ X = A.Xbuf[A.ctrl->cur];
+    // this workgroup's contiguous slice (whole tiles of 1024)
     const int64_t ntile = (N + kSelBlock - 1) / kSelBlock;
+    const int64_t tpb = (ntile + G - 1) / G;
+    int64_t i_lo = (int64_t)bid * tpb * kSelBlock, i_hi = i_lo + tpb * kSelBlock;
+    i_lo = i_lo < N ? i_lo : N;
+    i_hi = i_hi < N ? i_hi : N;
 
     // (a) n = count(alive), NaN check, key range of the alive costs: from the producers'
     //     per-workgroup partials when there are any, else by scanning X
@@ -281,7 +332,7 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
             kmaxn = p[3] < kmaxn ? p[3] : kmaxn;
         }
     } else {
-        for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+        for_each_alive(A.alive, X, i_lo, i_hi, tid, [&](int64_t, double x) {
             ++cnt;
             if (x != x) ++nanc;
             const uint64_t k = key_of(x);
@@ -289,12 +340,54 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
             kmaxn = ~k < kmaxn ? ~k : kmaxn;
         });
     }
-    const long long n = block_sum_ll(cnt, sh_ll);
-    const long long nn = block_sum_ll(nanc, sh_ll);
-    kmin = block_min_u64(kmin, sh_u);
-    const uint64_t kmax = ~block_min_u64(kmaxn, sh_u);
-    if (n == 0 || nn > 0) {
+    // one combined workgroup reduction (four separate ones cost eight barriers)
+    __shared__ unsigned long long s_red[kSelBlock / kWave][4];
+    {
+        const unsigned long long wc = wave_sum((unsigned long long)cnt);
+        const unsigned long long wn = wave_sum((unsigned long long)nanc);
+        for (int off = kWave / 2; off > 0; off >>= 1) {
+            const uint64_t a = __shfl_down(kmin, off, kWave), b = __shfl_down(kmaxn, off, kWave);
+            kmin = a < kmin ? a : kmin;
+            kmaxn = b < kmaxn ? b : kmaxn;
+        }
+        if (lane == 0) {
+            s_red[wid][0] = wc;
+            s_red[wid][1] = wn;
+            s_red[wid][2] = kmin;
+            s_red[wid][3] = kmaxn;
+        }
+        __syncthreads();
+    }
+    long long n = 0, nn = 0;
+    kmin = kmaxn = ~0ull;
+    for (int w = 0; w < kSelBlock / kWave; ++w) {
+        n += (long long)s_red[w][0];
+        nn += (long long)s_red[w][1];
+        kmin = s_red[w][2] < kmin ? s_red[w][2] : kmin;
+        kmaxn = s_red[w][3] < kmaxn ? s_red[w][3] : kmaxn;
+    }
+    if (!A.part && G > 1u) {
         if (tid == 0) {
+            unsigned long long* p = g->part_stats[bid];
+            p[0] = (unsigned long long)n;
+            p[1] = (unsigned long long)nn;
+            p[2] = kmin;
+            p[3] = kmaxn;
+        }
+        sel_grid_barrier(g, G);
+        n = nn = 0;
+        kmin = kmaxn = ~0ull;
+        for (unsigned b = 0; b < G; ++b) {  // G <= 32: every thread reads them all
+            const unsigned long long* p = g->part_stats[b];
+            n += (long long)p[0];
+            nn += (long long)p[1];
+            kmin = p[2] < kmin ? p[2] : kmin;
+            kmaxn = p[3] < kmaxn ? p[3] : kmaxn;
+        }
+    }
+    const uint64_t kmax = ~kmaxn;
+    if (n == 0 || nn > 0) {
+        if (bid == 0 && tid == 0) {
             A.ctrl->error = (nn > 0) ? 1 : 2;
             A.ctrl->done = 1;
         }
@@ -309,8 +402,8 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     if (j < 1) j = 1;
     if (j > n - 1) j = n - 1;
     if (n == 1) j = 1;
-    double g = aleph - (double)j;
-    g = g < 0.0 ? 0.0 : (g > 1.0 ? 1.0 : g);
+    double gq = aleph - (double)j;
+    gq = gq < 0.0 ? 0.0 : (gq > 1.0 ? 1.0 : gq);
 
     // (c) narrowing for the key of rank j-1 (0-based) inside [klo, khi]
     if (tid == 0) {
@@ -323,20 +416,27 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         s_ncand_all = 0;
     }
     __syncthreads();
-    for (int round = 0; round < 12 && s_state == 0; ++round) {
+    int rounds_used = 0;
+    for (int round = 0; round < kSelRounds && s_state == 0; ++round) {
         const uint64_t klo = s_klo, khi = s_khi;
         const uint64_t span = khi - klo;  // > 0
         const int bits = 64 - __clzll((long long)span);
         const int shift = bits > 10 ? bits - 10 : 0;
         for (int b = tid; b < kSelBins; b += kSelBlock) hist[b] = 0;
         __syncthreads();
-        for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+        for_each_alive(A.alive, X, i_lo, i_hi, tid, [&](int64_t, double x) {
             const uint64_t k = key_of(x);
             if (k >= klo && k <= khi) atomicAdd(&hist[(unsigned)((k - klo) >> shift)], 1u);
         });
         __syncthreads();
+        unsigned c = hist[tid];
+        if (G > 1u) {  // fold the workgroups' histograms in global scratch (pre-zeroed)
+            if (c) atomicAdd(&g->hist[round][tid], c);
+            sel_grid_barrier(g, G);
+            c = g->hist[round][tid];
+        }
+        rounds_used = round + 1;
         // parallel search of the bin holding rank kt: inclusive scan of 1024 bins
-        const unsigned c = hist[tid];
         unsigned incl = c;
         for (int off = 1; off < kWave; off <<= 1) {
             const unsigned o = __shfl_up(incl, off, kWave);
@@ -361,27 +461,38 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         __syncthreads();
     }
     KABC_STAMP(1)
-    if (s_state == 0) {  // cannot happen: 12 rounds x 10 bits > 64 bits
-        if (tid == 0) {
+    if (s_state == 0) {  // cannot happen: 7 rounds x 10 bits > 64 bits
+        if (bid == 0 && tid == 0) {
             A.ctrl->error = 2;
             A.ctrl->done = 1;
         }
         return;
     }
     if (s_state == 1) {
-        // collect the <= 4096 keys of the range into LDS, keep narrowing ON THE LIST
-        // (4 keys per thread per round) until <= 64 keys remain, then rank those
-        // inside one wavefront.
+        // collect the <= 4096 keys of the range (every workgroup ends up with all of them
+        // in LDS), keep narrowing ON THE LIST (4 keys per thread per round) until <= 64
+        // keys remain, then rank those inside one wavefront.
         if (tid == 0) s_ncand = 0;
         __syncthreads();
         {
             const uint64_t klo = s_klo, khi = s_khi;
-            for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+            for_each_alive(A.alive, X, i_lo, i_hi, tid, [&](int64_t, double x) {
                 const uint64_t k = key_of(x);
                 if (k >= klo && k <= khi) cand[atomicAdd(&s_ncand, 1u)] = k;
             });
         }
         __syncthreads();
+        if (G > 1u) {
+            const unsigned mine = s_ncand;
+            if (tid == 0) s_base = mine ? atomicAdd(&g->ncand, mine) : 0u;
+            __syncthreads();
+            for (unsigned q = tid; q < mine; q += kSelBlock) g->cand[s_base + q] = cand[q];
+            sel_grid_barrier(g, G);
+            const unsigned all = g->ncand;  // == s_nrange <= kSelCand
+            for (unsigned q = tid; q < all; q += kSelBlock) cand[q] = g->cand[q];
+            if (tid == 0) s_ncand = all;
+            __syncthreads();
+        }
         const unsigned nc = s_ncand;
         if (tid == 0) {
             s_state = (s_nrange <= kWave) ? 3 : 0;
@@ -440,7 +551,6 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
                 const uint64_t k = cand[i];
                 if (k >= klo && k <= khi) {
                     const unsigned pos = atomicAdd(&s_ncand, 1u);
-                    sh_u[pos % (kSelBlock / kWave)] = 0;  // (keeps sh_u initialised)
                     reinterpret_cast<uint64_t*>(hist)[pos] = k;  // hist is free now: 64 x u64
                 }
             }
@@ -482,12 +592,18 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
             }
             kgt = block_min_u64(kgt, sh_u);
         }
-        if (kgt == ~0ull) {  // uniform: kgt is the block-wide minimum
-            for_each_alive(A.alive, X, N, tid, [&](int64_t, double x) {
+        if (kgt == ~0ull) {  // uniform over the grid: kgt is the same in every workgroup
+            for_each_alive(A.alive, X, i_lo, i_hi, tid, [&](int64_t, double x) {
                 const uint64_t k = key_of(x);
                 if (k > khi) kgt = k < kgt ? k : kgt;
             });
             kgt = block_min_u64(kgt, sh_u);
+            if (G > 1u) {
+                if (tid == 0) g->part_kgt[bid] = kgt;
+                sel_grid_barrier(g, G);
+                kgt = ~0ull;
+                for (unsigned b = 0; b < G; ++b) kgt = g->part_kgt[b] < kgt ? g->part_kgt[b] : kgt;
+            }
         }
         if (tid == 0) s_keyb = kgt;
     }
@@ -496,8 +612,8 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         const double a = val_of(s_keya);
         const double b = (n == 1) ? a : val_of(s_keyb);
         double eps;
-        if (kabc_isfinite(a) && kabc_isfinite(b)) eps = a + g * (b - a);
-        else eps = (1.0 - g) * a + g * b;
+        if (kabc_isfinite(a) && kabc_isfinite(b)) eps = a + gq * (b - a);
+        else eps = (1.0 - gq) * a + gq * b;
         s_eps = eps;
         s_flag = (A.mode == 1) ? 1 : ((eps > mn) ? 0 : 1);  // src/smc.jl:135-141
     }
@@ -507,19 +623,37 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     KABC_STAMP(3)
 
     // (d) new alive mask over ALL particles, ESS, compaction of the alive indices in
-    //     ascending order: coalesced tiles of 1024 with ballot + mbcnt
-    // four tiles of 1024 per round: the 4 x 16 per-wave counts form one 64-entry
-    // vector that every wave scans with shuffles (tile-major = ascending index)
+    //     ascending order.  First the count of this workgroup's slice (its offset is the
+    //     sum of the slices before it), then coalesced tiles of 1024 with ballot + mbcnt,
+    //     four tiles per round: the 4 x 16 per-wave counts form one 64-entry vector
+    //     that every wave scans with shuffles (tile-major = ascending index).
+    long long mycnt = 0;
+    for (int64_t i = i_lo + tid; i < i_hi; i += kSelBlock) {
+        const double x = X[i];
+        mycnt += (flag ? (x <= eps) : (x < eps)) ? 1 : 0;
+    }
+    mycnt = block_sum_ll(mycnt, sh_ll);
+    long long base = 0, ESS = mycnt;
+    if (G > 1u) {
+        if (tid == 0) g->slice_cnt[bid] = (unsigned)mycnt;
+        sel_grid_barrier(g, G);
+        ESS = 0;
+        for (unsigned b = 0; b < G; ++b) {
+            const long long cb = (long long)g->slice_cnt[b];
+            if (b < bid) base += cb;
+            ESS += cb;
+        }
+    }
     __shared__ unsigned int s_cnt4[4 * (kSelBlock / kWave)];
-    long long base = 0;
-    for (int64_t tile0 = 0; tile0 < ntile; tile0 += 4) {
+    const int64_t tile_lo = (int64_t)bid * tpb, tile_hi = (tile_lo + tpb < ntile) ? tile_lo + tpb : ntile;
+    for (int64_t tile0 = tile_lo; tile0 < tile_hi; tile0 += 4) {
         bool al[4];
         unsigned long long bm[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t i = (tile0 + u) * kSelBlock + tid;
             double x = 0.0;
-            const bool in = i < N;
+            const bool in = (tile0 + u < tile_hi) && i < N;
             if (in) x = X[i];
             al[u] = in && (flag ? (x <= eps) : (x < eps));
         }
@@ -548,43 +682,44 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         base += tot;
         __syncthreads();
     }
-    const long long ESS = base;
     KABC_STAMP(4)
     // Step 2 decision: α*ESS <= nparticles*min_r_ess  (src/smc.jl:145)
     const int resample =
         (A.mode == 0 && A.alpha * (double)ESS <= (double)N * A.min_r_ess) ? 1 : 0;
-    if (resample && ESS == 0) {
-        if (tid == 0) {
-            A.ctrl->error = 2;
-            A.ctrl->done = 1;
-        }
-        return;
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (resample) {
-        // idx = repeat(idxalive, ceil(N/m))[1:N]  (src/smc.jl:146-147)
+    const bool fail = resample && ESS == 0;
+    if (resample && !fail) {
+        // idx = repeat(idxalive, ceil(N/m))[1:N]  (src/smc.jl:146-147): needs the whole cidx
+        sel_grid_barrier(g, G);
         const unsigned e = (unsigned)ESS;
-        unsigned rmod = (unsigned)tid % e;
+        unsigned rmod = (unsigned)((i_lo + tid) % (int64_t)e);
         const unsigned step = (unsigned)kSelBlock % e;
-        for (int64_t jdx = tid; jdx < N; jdx += kSelBlock) {
+        for (int64_t jdx = i_lo + tid; jdx < i_hi; jdx += kSelBlock) {
             A.ridx[jdx] = A.cidx[rmod];
             A.alive[jdx] = 1;
             rmod += step;
             if (rmod >= e) rmod -= e;
         }
-    } else {
-        for (int64_t tile = 0; tile < ntile; ++tile) {
-            const int64_t i = tile * kSelBlock + tid;
-            if (i < N) {
-                const double x = X[i];
-                A.alive_out[i] = (flag ? (x <= eps) : (x < eps)) ? 1 : 0;
-                if (A.mode == 0) A.ridx[i] = (int32_t)i;
-            }
+    } else if (!fail) {
+        for (int64_t i = i_lo + tid; i < i_hi; i += kSelBlock) {
+            const double x = X[i];
+            A.alive_out[i] = (flag ? (x <= eps) : (x < eps)) ? 1 : 0;
+            if (A.mode == 0) A.ridx[i] = (int32_t)i;
         }
     }
     KABC_STAMP(5)
+    if (bid != 0) return;
+    // workgroup 0 leaves the scratch zeroed for the next call (every workgroup has passed
+    // a barrier since its last read of it) and publishes the iteration's control block
+    if (G > 1u) {
+        for (int r = 0; r < rounds_used; ++r) g->hist[r][tid] = 0;
+        if (tid == 0) g->ncand = 0;
+    }
     if (tid == 0) {
+        if (fail) {
+            A.ctrl->error = 2;
+            A.ctrl->done = 1;
+            return;
+        }
         if (A.stamps) A.stamps[7] += 1;
         A.ctrl->iteration += 1;
         A.ctrl->eps_prev = A.ctrl->eps;  // ϵv = ϵ
@@ -700,41 +835,9 @@ __global__ void __launch_bounds__(256) smc_finalize_kernel(const SmcFinalArgs A)
     A.Xout[i] = A.X[cur][i];
 }
 
-// after every MCMC pass: fold the per-workgroup counter lines, flip the buffers,
-// apply `accepted[] >= mcmc_tol * nparticles && break` (src/smc.jl:192)
-__global__ void __launch_bounds__(kSmcSlots) smc_pass_end_kernel(SmcCtrl* ctrl,
-                                                                 unsigned long long* slots,
-                                                                 int64_t N, double mcmc_tol) {
-    __shared__ unsigned long long sh[3][kSmcSlots / kWave];
-    if (ctrl->done || !ctrl->pass_open) return;
-    const int tid = threadIdx.x;
-    unsigned long long v[3];
-    for (int j = 0; j < 3; ++j) {
-        v[j] = wave_sum(slots[(size_t)tid * 8 + j]);
-        slots[(size_t)tid * 8 + j] = 0;
-    }
-    if ((tid & (kWave - 1)) == 0)
-        for (int j = 0; j < 3; ++j) sh[j][tid >> 6] = v[j];
-    __syncthreads();
-    if (tid == 0) {
-        unsigned long long t[3] = {0, 0, 0};
-        for (int w = 0; w < kSmcSlots / kWave; ++w)
-            for (int j = 0; j < 3; ++j) t[j] += sh[j][w];
-        ctrl->accepted += t[0];
-        ctrl->cost_evals += t[1];
-        ctrl->proposals += t[2];
-        ctrl->pass += 1;
-        ctrl->passes += 1;
-        ctrl->cur ^= 1;
-        ctrl->use_ridx = 0;
-        if ((double)ctrl->accepted >= mcmc_tol * (double)N) ctrl->pass_open = 0;
-    }
-}
-
-// end of an ε-iteration: log it and apply the stop tests of src/smc.jl:194-198
-__global__ void smc_iter_end_kernel(SmcCtrl* ctrl, kabc_smc_iter_t* log, int64_t log_cap,
-                                    int64_t N, SmcLoopParams P) {
-    if (ctrl->done) return;
+// end of an ε-iteration: log it and apply the stop tests of src/smc.jl:194-198 (one thread)
+__device__ __forceinline__ void smc_iter_end(SmcCtrl* ctrl, kabc_smc_iter_t* log, int64_t log_cap,
+                                             int64_t N, const SmcLoopParams& P) {
     ctrl->pass_open = 0;
     const long long it = ctrl->iteration;
     const double eps = ctrl->eps, epsv = ctrl->eps_prev;
@@ -753,6 +856,52 @@ __global__ void smc_iter_end_kernel(SmcCtrl* ctrl, kabc_smc_iter_t* log, int64_t
     if (2.0 * kabc_fabs(epsv - eps) < P.r_epstol * (kabc_fabs(epsv) + kabc_fabs(eps)) ||
         eps <= P.epstol || acc < P.mcmc_tol * (double)N || it >= P.max_iterations)
         ctrl->done = 1;
+}
+
+// after every MCMC pass: fold the per-workgroup counter lines, flip the buffers,
+// apply `accepted[] >= mcmc_tol * nparticles && break` (src/smc.jl:192); after the last
+// pass of an iteration (end_iter) also the iteration's end, in the same launch
+__global__ void __launch_bounds__(kSmcSlots) smc_pass_end_kernel(SmcCtrl* ctrl,
+                                                                 unsigned long long* slots,
+                                                                 int64_t N, double mcmc_tol,
+                                                                 int end_iter,
+                                                                 kabc_smc_iter_t* log,
+                                                                 int64_t log_cap,
+                                                                 SmcLoopParams P) {
+    __shared__ unsigned long long sh[3][kSmcSlots / kWave];
+    if (ctrl->done) return;
+    const int tid = threadIdx.x;
+    if (ctrl->pass_open) {  // uniform: thread 0 changes it only after the barrier below
+        unsigned long long v[3];
+        for (int j = 0; j < 3; ++j) {
+            v[j] = wave_sum(slots[(size_t)tid * 8 + j]);
+            slots[(size_t)tid * 8 + j] = 0;
+        }
+        if ((tid & (kWave - 1)) == 0)
+            for (int j = 0; j < 3; ++j) sh[j][tid >> 6] = v[j];
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t[3] = {0, 0, 0};
+            for (int w = 0; w < kSmcSlots / kWave; ++w)
+                for (int j = 0; j < 3; ++j) t[j] += sh[j][w];
+            ctrl->accepted += t[0];
+            ctrl->cost_evals += t[1];
+            ctrl->proposals += t[2];
+            ctrl->pass += 1;
+            ctrl->passes += 1;
+            ctrl->cur ^= 1;
+            ctrl->use_ridx = 0;
+            if ((double)ctrl->accepted >= mcmc_tol * (double)N) ctrl->pass_open = 0;
+        }
+    }
+    if (end_iter && tid == 0) smc_iter_end(ctrl, log, log_cap, N, P);
+}
+
+// the iteration's end on its own (when the host stopped enqueueing retry passes early)
+__global__ void smc_iter_end_kernel(SmcCtrl* ctrl, kabc_smc_iter_t* log, int64_t log_cap,
+                                    int64_t N, SmcLoopParams P) {
+    if (ctrl->done) return;
+    smc_iter_end(ctrl, log, log_cap, N, P);
 }
 
 #endif  // KABC_SMC_SINGLE_UNIT
