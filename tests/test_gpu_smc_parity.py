@@ -61,3 +61,36 @@ def test_smc_argument_errors_match_reference(k, gpu_ctx):
         with pytest.raises(k.KabcError) as e:
             k.smc(pri, c, **kw)
         assert str(e.value) == msg
+
+
+@pytest.mark.parametrize("blocks", [None, "1", "32"])
+def test_c4_full_size_bit_exact(k, orc, gpu_ctx, monkeypatch, blocks):
+    """BASELINE.json configs[3] at full size (32 768 particles, D = 16, hierarchical
+    Gaussian simulator, ~190 ε-iterations): θ of every particle, ε and the iteration
+    log equal the oracle's bit for bit -- with the select kernel on its default 16
+    workgroups, on one, and on 32."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from smc_c4_probe import c4_problem
+    if blocks is None:
+        monkeypatch.delenv("KABC_SMC_SELECT_BLOCKS", raising=False)
+    else:
+        monkeypatch.setenv("KABC_SMC_SELECT_BLOCKS", blocks)
+    prior, cost = c4_problem()
+    kw = dict(nparticles=32768, alpha=0.95, epstol=0.05, seed=1)
+    r = k.smc(prior, cost, return_array=True, **kw)
+    ro = _oracle_c4(orc, prior, cost, kw)
+    assert r.info["iterations"] == ro["iterations"] > 100
+    assert r.eps == ro["eps"] and np.array_equal(r.info["theta_all"], ro["theta_all"])
+    assert [it["eps"] for it in r.info["log"]] == [it["eps"] for it in ro["log"]]
+    assert [it["ess"] for it in r.info["log"]] == [it["ess"] for it in ro["log"]]
+
+
+_C4_ORACLE = {}
+
+
+def _oracle_c4(orc, prior, cost, kw):
+    if "r" not in _C4_ORACLE:      # 1.7 s of CPU, once for the three cases
+        _C4_ORACLE["r"] = orc.smc(prior, cost, **kw)
+    return _C4_ORACLE["r"]
