@@ -79,11 +79,13 @@ struct DevBufs {
 using namespace kabc;
 
 namespace kabc {
-// workgroups of the select kernel: one per 2048 particles, at most 16 (a device-wide
-// barrier costs ~1.7-2.4 us and grows with the count; KABC_SMC_SELECT_BLOCKS overrides)
+// workgroups of the select kernel: one per 2048 particles, at most 16 (32 from 131 072
+// particles on: a device-wide barrier costs ~1.7-2.4 us and grows with the count);
+// KABC_SMC_SELECT_BLOCKS overrides
 static unsigned select_blocks(int64_t N) {
     long g = (long)((N + 2047) / 2048);
-    if (g > 16) g = 16;
+    const long cap = N >= (1 << 17) ? kSelMaxBlocks : 16;
+    if (g > cap) g = cap;
     if (const char* e = std::getenv("KABC_SMC_SELECT_BLOCKS")) {
         const long v = std::atol(e);
         if (v >= 1) g = v;
