@@ -3,7 +3,7 @@
  *
  * Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy
  * as 1, 2, 3", SC'11), restated from the published round function; pinned by
- * the Random123 known-answer vectors in tests/test_math.py.
+ * the Random123 known-answer vectors in tests/test_math_contract.py.
  *
  * The reference draws from ONE serial Julia RNG (rand/randn/randexp call sites
  * src/transition.jl:3,6,9,13,27-33,38-40,49,54,62; src/types.jl:74,103;
