@@ -10,7 +10,10 @@ import os
 from . import _cdefs
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkabc_hip.so")
+# KABC_PROBES=1 selects the build with the timing probes of tools/ compiled into the AIS
+# kernel (make -C kissabc.jl_amd/csrc PROBES=1; built on first use)
+PROBES = os.environ.get("KABC_PROBES") == "1"
+LIB_PATH = os.path.join(_HERE, "lib", "libkabc_hip_probes.so" if PROBES else "libkabc_hip.so")
 _lib = None
 
 
@@ -42,6 +45,10 @@ def load():
     global _lib
     if _lib is None:
         _preload_torch_hip()
+        if PROBES and not os.path.exists(LIB_PATH):
+            import subprocess
+            subprocess.run(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "PROBES=1",
+                            f"-j{min(32, os.cpu_count() or 8)}"], check=True)
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "

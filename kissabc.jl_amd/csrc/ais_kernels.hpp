@@ -37,7 +37,7 @@ struct AisArgs {
     double eps;             // scale | maxcost
     double reps;            // RN(1/eps) for kabc_div_rc
     double box_lp;          // prior class BOX: the in-support log-density (ordered sum of c0)
-    int32_t ablate;         // timing experiments only (KABC_ABLATE): 1 no consumer, 2 no producers, 64 HW_ID probe;
+    int32_t ablate;         // PROBES=1 builds only (KABC_ABLATE): 1 no consumer, 2 no producers, 64 HW_ID, 128 barrier time
     const PriorDev* prior;  // [D] prepared components, device memory (scalar-loaded)
 };
 
@@ -197,6 +197,14 @@ __device__ __forceinline__ void wave_lds_fence() {
 
 // PRODUCER: fill sub-step `si` (transition counter t) of a record buffer for the
 // 64 walkers of the batch.  Runs in ONE wavefront; lists are wave-private.
+// Timing probes (KABC_ABLATE, tools/ablate_probe.py / barrier_probe.py / placement_probe.py)
+// exist only in the PROBES=1 build of the library (libkabc_hip_probes.so): the run-time
+// tests on A.ablate cost 3.5 % of a launch when compiled in.
+#ifdef KABC_PROBES
+#define KABL A.ablate
+#else
+#define KABL 0
+#endif
 template <int D>
 __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R, int si,
                                                 uint64_t t, uint32_t w_base, int n_active,
@@ -243,7 +251,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     wave_lds_fence();
     // -- phase B2: partner rows b (and c) for DE / walk lanes, dense
 #pragma unroll 1
-    for (int e = lane; e < ((A.ablate & 32) ? 0 : nB); e += kWave) {
+    for (int e = lane; e < ((KABL & 32) ? 0 : nB); e += kWave) {
         const int l = listB[e];
         const uint32_t al = R.mva[si][l] & 0x3fffffffu;
         const kabc_u128_t B2 =
@@ -268,7 +276,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     }
     // -- phase N: Box-Muller blocks, dense
 #pragma unroll 1
-    for (int e = lane; e < ((A.ablate & 8) ? 0 : nN); e += kWave) {
+    for (int e = lane; e < ((KABL & 8) ? 0 : nN); e += kWave) {
         const int e2 = e - nDE * NB;
         const bool is_de = e2 < 0;
         const int q = is_de ? e / NB : nDE + (e2 >> 1);
@@ -284,7 +292,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     }
     wave_lds_fence();
     // -- phase C: gamma = 2.38/sqrt(2D) * exp(0.1 randn)   (src/transition.jl:3)
-    if (A.ablate & 16) return;
+    if (KABL & 16) return;
     if (move == 2) {
         const double z0 = R.zs[si][0][lane];
         R.zs[si][0][lane] = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp(z0 * 0.1);
@@ -323,7 +331,7 @@ ais_half_kernel(const AisArgs A) {
     const uint32_t w_base = A.id_base + (uint32_t)(A.row_first + r0);
     const int nchunks = (A.nt + kChunk - 1) / kChunk;
     // KABC_ABLATE=128 (with debug records on): cycles each wave spends at the barriers
-    const bool tprobe = (A.ablate & 128) && A.dbg;
+    const bool tprobe = (KABL & 128) && A.dbg;
     unsigned long long t_begin = 0, t_bar = 0;
     if (tprobe) t_begin = __builtin_amdgcn_s_memtime();
 #define KABC_TIMED_BARRIER()                                              \
@@ -370,7 +378,7 @@ ais_half_kernel(const AisArgs A) {
     // prologue: producers fill chunk 0
     if (wave > 0) {
         const int si = wave - 1;
-        if (si < A.nt && !(A.ablate & 4))
+        if (si < A.nt && !(KABL & 4))
             produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
                                lane, slogtab);
     }
@@ -383,12 +391,12 @@ ais_half_kernel(const AisArgs A) {
             // PRODUCER: sub-step (s0 + kChunk + wave - 1) of the next chunk
             const int si = wave - 1;
             const int s = s0 + kChunk + si;
-            if (s < A.nt && !(A.ablate & 2))
+            if (s < A.nt && !(KABL & 2))
                 produce_substep<D>(A, rec[(c + 1) & 1], si, A.t0 + (uint64_t)s, w_base, n_active,
                                    listB[si], lane, slogtab);
-        } else if (active && !(A.ablate & 1)) {
+        } else if (active && !(KABL & 1)) {
             // CONSUMER
-            const ChunkRec<D>& R = rec[(A.ablate & 2) ? 0 : (c & 1)];
+            const ChunkRec<D>& R = rec[(KABL & 2) ? 0 : (c & 1)];
             const int ns = (A.nt - s0 < kChunk) ? (A.nt - s0) : kChunk;
             // partner rows: (pa, pb) serve this sub-step, (na, nb) are the next one's, in
             // flight while this one computes.  Both rows are fetched for every lane
@@ -509,7 +517,7 @@ ais_half_kernel(const AisArgs A) {
         d[0] = (int32_t)(t_end - t_begin);
         d[1] = (int32_t)t_bar;
     }
-    if ((A.ablate & 64) && A.dbg && lane == 0) {
+    if ((KABL & 64) && A.dbg && lane == 0) {
         // placement probe (KABC_ABLATE=64 with debug records on): HW_ID of each wave
         uint32_t hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));

@@ -2,6 +2,7 @@
 // AIS(N) + AISState + step(init) + step(advance) of src/KissABC.jl:21-80,
 // executed by the gfx950 kernels in ais_kernels.hpp.
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <thread>
@@ -402,8 +403,16 @@ kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntra
     a.box_lp = h->box_lp;
     a.prior = h->d_prior;
     {
-        static const char* ab = getenv("KABC_ABLATE");
-        a.ablate = ab ? atoi(ab) : 0;
+        static const int ab = [] {
+            const char* e = getenv("KABC_ABLATE");
+            const int v = e ? atoi(e) : 0;
+#ifndef KABC_PROBES
+            if (v) fprintf(stderr, "[kabc] KABC_ABLATE=%d ignored: the timing probes are compiled "
+                                   "only into libkabc_hip_probes.so (make PROBES=1, KABC_PROBES=1)\n", v);
+#endif
+            return v;
+        }();
+        a.ablate = ab;
     }
     hipStream_t s = h->ctx->stream;
     // timing: one hipEvent pair brackets `timing_stride` consecutive launches (the

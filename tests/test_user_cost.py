@@ -61,7 +61,7 @@ def test_oracle_runs_a_user_cost(k, orc):
 @pytest.mark.gpu
 def test_user_cost_equals_builtin_and_oracle(k, orc, gpu_ctx):
     """Same formula as the built-in Rosenbrock => bit-identical trajectories, AIS and SMC."""
-    user = k.costs.UserCost(ROSEN_SRC, dims=[2, 8])
+    user = k.costs.UserCost(ROSEN_SRC, dims=[2, 8], posteriors=["kernelized"])
     assert user.id >= 100
     U = k.Factored(*[k.Uniform(-5, 5)] * 8)
     N, nt, gens = 2048, 6, 3
@@ -92,7 +92,8 @@ def test_user_cost_equals_builtin_and_oracle(k, orc, gpu_ctx):
 def test_user_stochastic_simulator_bit_exact_vs_oracle(k, orc, gpu_ctx):
     rng = np.random.default_rng(5)
     data = np.cumsum(rng.normal(size=24)) * 0.3
-    user = k.costs.UserCost(SIM_SRC, dims=[3], params=[0.5], data=data, name="ar1")
+    user = k.costs.UserCost(SIM_SRC, dims=[3], params=[0.5], data=data, name="ar1",
+                            posteriors=["kernelized"])
     orc.register_user_cost(user)
     prior = k.Factored(k.Uniform(-1, 1), k.Uniform(0, 2), k.Normal(0, 1))
     model = k.ApproxKernelizedPosterior(prior, user, 0.2)
@@ -142,7 +143,7 @@ def test_common_log_density_on_oracle(k, orc):
 
 @pytest.mark.gpu
 def test_common_log_density_gpu_parity_and_reference_tests(k, orc, gpu_ctx):
-    banana = k.costs.UserCost(BANANA_LPI, dims=[2], name="banana")
+    banana = k.costs.UserCost(BANANA_LPI, dims=[2], name="banana", posteriors=["common"])
     orc.register_user_cost(banana)
     D = k.CommonLogDensity(2, k.Factored(k.Normal(0, 1), k.Normal(0, 1)), banana)
     got = k.AisEnsemble(D, 50, seed=1).init().advance(5, 20, collect=True)
@@ -152,12 +153,12 @@ def test_common_log_density_gpu_parity_and_reference_tests(k, orc, gpu_ctx):
     lp = -100 * (res[:, 0] - res[:, 1] ** 2) ** 2 - (res[:, 1] - 1) ** 2
     assert np.quantile(lp, 0.97) > -0.69                  # test/runtests.jl:217
     # "Handling of ∞ costs", test/runtests.jl:221-238
-    disc = k.costs.UserCost(DISC_LPI, dims=[2], params=[1.0], name="disc")
+    disc = k.costs.UserCost(DISC_LPI, dims=[2], params=[1.0], name="disc", posteriors=["common"])
     init = k.Factored(k.Uniform(-1, 1), k.Uniform(0, 1))
     res = k.sample(k.CommonLogDensity(2, init, disc), k.AIS(50), 1000, ntransitions=100,
                    discard_initial=5000, seed=2, return_array=True)
     assert np.all((res ** 2).sum(1) <= 1.0)
-    never = k.costs.UserCost(DISC_LPI, dims=[2], params=[-1.0], name="never")   # lπ = -Inf
+    never = k.costs.UserCost(DISC_LPI, dims=[2], params=[-1.0], name="never", posteriors=["common"])   # lπ = -Inf
     with pytest.raises(k.KabcError) as e:
         k.sample(k.CommonLogDensity(2, init, never), k.AIS(50), 10)
     assert "Prior leads to ∞ costs too often" in str(e.value)

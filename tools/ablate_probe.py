@@ -4,6 +4,8 @@ WRONG under ablation; only the kernel duration is of interest."""
 import os
 import sys
 
+os.environ["KABC_PROBES"] = "1"   # the library variant with the probes compiled in
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import kissabc_jl_amd as k  # noqa: E402

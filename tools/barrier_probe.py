@@ -5,6 +5,8 @@ C3 launch for the consumer (wave 0) and the producers (waves 1-3)."""
 import os
 import sys
 
+os.environ["KABC_PROBES"] = "1"   # the library variant with the probes compiled in
+
 os.environ["KABC_ABLATE"] = "128"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402

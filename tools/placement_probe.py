@@ -5,6 +5,8 @@ import collections
 import os
 import sys
 
+os.environ["KABC_PROBES"] = "1"   # the library variant with the probes compiled in
+
 os.environ["KABC_ABLATE"] = "64"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
