@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=${1:-gpurun_out/r01h}; mkdir -p $O
+O=${1:-gpurun_out/r01k}; mkdir -p $O
 (rocm-smi --showclocks --showpower 2>/dev/null || true) > $O/rocm_smi_before.txt
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-alt > $O/bench_under_rocprof.json 2> $O/stats.err
