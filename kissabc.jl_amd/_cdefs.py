@@ -6,6 +6,7 @@ oracle's test binding (oracle/oracle.py).  Nothing here computes anything.
 import ctypes as C
 
 KABC_MAX_DIM = 16
+KABC_VERSION = 101   # include/kabc.h
 
 # kabc_status_t
 KABC_OK, KABC_ERR_INVALID_ARG, KABC_ERR_RETRY_EXHAUSTED, KABC_ERR_INVALID_STATE, \
