@@ -1,4 +1,4 @@
-"""CPU, world_size = 2 over gloo: the multi-GPU driver's exchange logic
+"""CPU, world_size = 2 and 4 over gloo: the multi-GPU driver's exchange logic
 (kissabc_jl_amd.sharded.ShardedAIS: row ownership, one all-gather per
 half-generation, counter stride) with the CPU oracle standing in for the
 per-rank HIP engine.  The sharded trajectory must equal the single-process
@@ -100,7 +100,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4])
 def test_sharded_equals_single_process(tmp_path, orc, k, world):
     N, nt, gens, seed = 512, 3, 4, 21
     out = str(tmp_path / "sharded.npz")
