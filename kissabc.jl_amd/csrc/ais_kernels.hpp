@@ -41,6 +41,7 @@ struct AisArgs {
     const PriorDev* prior;  // [D] prepared components, device memory (scalar-loaded)
 };
 
+constexpr int kLateFrom = 10;  // D above this: the consumer keeps ONE set of partner-row registers
 constexpr int kCounterSlots = 1024;  // one 64-byte line per workgroup (mod 1024)
 
 struct InitArgs {
@@ -403,7 +404,8 @@ ais_half_kernel(const AisArgs A) {
             // whatever its move (bb defaults to a): no divergence around the loads.
             // The sub-step body is instantiated twice with the two register sets
             // swapped, so no row is ever copied.
-            double r0a[D], r0b[D], r1a[D], r1b[D];
+            constexpr bool kLate = D > kLateFrom;
+            double r0a[D], r0b[D], r1a[kLate ? 1 : D], r1b[kLate ? 1 : D];
             load_row<D>(A.x_comp + (int64_t)(R.mva[0][lane] & 0x3fffffffu) * D, r0a);
             load_row<D>(A.x_comp + (int64_t)R.bb[0][lane] * D, r0b);
             auto substep = [&](const int si, const double (&pa)[D], const double (&pb)[D],
@@ -418,9 +420,14 @@ ais_half_kernel(const AisArgs A) {
                 double zs[D + 1];
 #pragma unroll
                 for (int j = 0; j < D + 1; ++j) zs[j] = R.zs[si][j][lane];
-                // (2) prefetch
-                load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
-                load_row<D>(A.x_comp + (int64_t)bn * D, nb);
+                // (2) prefetch.  D <= kLateFrom: into the second register set, right away.
+                //     Larger D (two more rows would not fit 256 VGPRs: D = 16 spilled 480 B
+                //     and ran 4.3x slower than D = 8): into the SAME registers, as soon as
+                //     the proposal below has consumed the current rows.
+                if constexpr (!kLate) {
+                    load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
+                    load_row<D>(A.x_comp + (int64_t)bn * D, nb);
+                }
                 // scheduling fences: without them hipcc interleaves the phases of a
                 // sub-step for ILP and needs > 300 VGPRs (spills, 1 wave per SIMD)
                 __builtin_amdgcn_sched_barrier(0);
@@ -454,6 +461,10 @@ ais_half_kernel(const AisArgs A) {
                     for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (kLate) {  // pa/pb are dead now: na/nb alias them
+                    load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
+                    load_row<D>(A.x_comp + (int64_t)bn * D, nb);
+                }
                 // ld = loglike(density, push_p(density, p))   src/transition.jl:75
                 kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u};
                 double nlp, nll;
@@ -502,10 +513,15 @@ ais_half_kernel(const AisArgs A) {
             // an error (src/types.jl:145-150) is sticky and reported after the launch; the
             // remaining sub-steps still run (their result is discarded by the host), which
             // keeps the loop bounds wave-uniform
+            if constexpr (kLate) {
 #pragma unroll 1
-            for (int si = 0; si < ns; si += 2) {
-                substep(si, r0a, r0b, r1a, r1b);
-                if (si + 1 < ns) substep(si + 1, r1a, r1b, r0a, r0b);
+                for (int si = 0; si < ns; ++si) substep(si, r0a, r0b, r0a, r0b);
+            } else {
+#pragma unroll 1
+                for (int si = 0; si < ns; si += 2) {
+                    substep(si, r0a, r0b, r1a, r1b);
+                    if (si + 1 < ns) substep(si + 1, r1a, r1b, r0a, r0b);
+                }
             }
         }
         KABC_TIMED_BARRIER();
