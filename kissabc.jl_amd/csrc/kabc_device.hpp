@@ -42,7 +42,7 @@ struct PriorSet {
 //   comp_logpdf_simple : the families whose logpdf needs no transcendental per
 //       walker (Uniform, Normal, truncated Normal, DiscreteUniform, Exponential);
 //       inlined into the hot loop.
-//   comp_logpdf_general: every family; kept out of line so that D copies of
+//   comp_logpdf_general: every family; out of line for D > 8 so that D copies of
 //       log/log1p/lgamma do not bloat the kernel past the instruction cache.
 __device__ __forceinline__ double comp_logpdf_simple(const PriorDev& q, double x) {
     const double a = q.p[0], b = q.p[1], rb = q.rb;
@@ -64,9 +64,9 @@ __device__ __forceinline__ double comp_logpdf_simple(const PriorDev& q, double x
     }
 }
 
-static __device__ __noinline__ double comp_logpdf_general(int kind, double a, double b, double p2,
-                                                          double p3, double c0, double c1, double rb,
-                                                          double x) {
+__device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, double b, double p2,
+                                                           double p3, double c0, double c1, double rb,
+                                                           double x) {
     switch (kind) {
         case KABC_PRIOR_UNIFORM: return (x >= a && x <= b) ? c0 : -KABC_INF;
         case KABC_PRIOR_NORMAL: {
@@ -106,8 +106,22 @@ static __device__ __noinline__ double comp_logpdf_general(int kind, double a, do
     }
 }
 
+static __device__ __noinline__ double comp_logpdf_general(int kind, double a, double b, double p2,
+                                                          double p3, double c0, double c1, double rb,
+                                                          double x) {
+    return comp_logpdf_general_body(kind, a, b, p2, p3, c0, c1, rb, x);
+}
+
+// Inlined up to kGeneralInlineD components: a call costs the caller its live registers
+// (spilled around it) -- 19 % of a launch at D = 4; beyond that D copies of the switch
+// would bloat the kernel (and the build) for little.
+constexpr int kGeneralInlineD = 8;
+template <int D = KABC_MAX_DIM>
 __device__ __forceinline__ double comp_logpdf(const PriorDev& q, double x) {
-    return comp_logpdf_general(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
+    if constexpr (D <= kGeneralInlineD)
+        return comp_logpdf_general_body(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
+    else
+        return comp_logpdf_general(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
 }
 
 // host-side classification used to pick the kernel variant
@@ -130,7 +144,7 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restric
         const PriorDev& q = P[k];
         const double v = q.discrete ? kabc_rint(x[k]) : x[k];
         xp[k] = v;
-        const double l = SIMPLE ? comp_logpdf_simple(q, v) : comp_logpdf(q, v);
+        const double l = SIMPLE ? comp_logpdf_simple(q, v) : comp_logpdf<D>(q, v);
         s = (k == 0) ? l : s + l;
     }
     return s;
