@@ -44,9 +44,9 @@ struct PriorSet {
 //       inlined into the hot loop.
 //   comp_logpdf_general: every family; out of line for D > 8 so that D copies of
 //       log/log1p/lgamma do not bloat the kernel past the instruction cache.
-__device__ __forceinline__ double comp_logpdf_simple(const PriorDev& q, double x) {
+__device__ __forceinline__ double comp_logpdf_simple(int kind, const PriorDev& q, double x) {
     const double a = q.p[0], b = q.p[1], rb = q.rb;
-    switch (q.kind) {
+    switch (kind) {
         case KABC_PRIOR_UNIFORM: return (x >= a && x <= b) ? q.c0 : -KABC_INF;
         case KABC_PRIOR_NORMAL: {
             const double z = kabc_div_rc(x - a, b, rb);
@@ -117,11 +117,11 @@ static __device__ __noinline__ double comp_logpdf_general(int kind, double a, do
 // would bloat the kernel (and the build) for little.
 constexpr int kGeneralInlineD = 8;
 template <int D = KABC_MAX_DIM>
-__device__ __forceinline__ double comp_logpdf(const PriorDev& q, double x) {
+__device__ __forceinline__ double comp_logpdf(int kind, const PriorDev& q, double x) {
     if constexpr (D <= kGeneralInlineD)
-        return comp_logpdf_general_body(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
+        return comp_logpdf_general_body(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
     else
-        return comp_logpdf_general(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
+        return comp_logpdf_general(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
 }
 
 // host-side classification used to pick the kernel variant
@@ -142,9 +142,13 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restric
     for (int k = 0; k < D; ++k) {
         __builtin_amdgcn_sched_barrier(0);
         const PriorDev& q = P[k];
-        const double v = q.discrete ? kabc_rint(x[k]) : x[k];
+        // the prior is the same for every lane: kind / discrete as SCALARS make the family
+        // dispatch a uniform branch instead of an exec-masked walk through every case
+        const int kind = __builtin_amdgcn_readfirstlane(q.kind);
+        const bool disc = __builtin_amdgcn_readfirstlane(q.discrete) != 0;
+        const double v = disc ? kabc_rint(x[k]) : x[k];
         xp[k] = v;
-        const double l = SIMPLE ? comp_logpdf_simple(q, v) : comp_logpdf<D>(q, v);
+        const double l = SIMPLE ? comp_logpdf_simple(kind, q, v) : comp_logpdf<D>(kind, q, v);
         s = (k == 0) ? l : s + l;
     }
     return s;
