@@ -87,10 +87,23 @@ KABC_HD double kabc_cost_hier_gauss_sim(const double* x, int D, const double* da
     return kabc_sqrt(acc / (double)G);
 }
 
+/* ---- prepared costs ----------------------------------------------------------
+ * A simulator often spends most of its time on draws that do not depend on the
+ * parameters (README.md:45: `randn(1000)` scaled and shifted afterwards).  Such a cost
+ * splits into  prepare(params, rng) -> aux[W]  (parameter-independent) and the rest;
+ * on the device the AIS producer waves run `prepare` for the sub-steps ahead while the
+ * consumer wave -- the serial part of the chain -- only finishes the cost.  The draws
+ * are counter-based, so preparing them early (or for a proposal the prior then
+ * rejects) changes nothing; kabc_cost_eval computes the same aux in place when none was
+ * prepared. */
+#define KABC_COST_MAX_AUX 2
+KABC_HD int kabc_cost_aux_words(int id) { return id == KABC_COST_NORMAL_MEANSTD_SIM ? 2 : 0; }
+
 /* params = (n, mean(tdata), std(tdata)); x = (mu, sigma).  The n draws are
- * mu + sigma z_j, so mean = mu + sigma mean(z), std = |sigma| std(z). */
-KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* params,
-                                            kabc_cost_rng_t* rng) {
+ * mu + sigma z_j, so mean = mu + sigma mean(z), std = |sigma| std(z).
+ * prepare: aux = (sum z_j, sum z_j^2) over the n standard normals of the stream */
+KABC_HD void kabc_cost_normal_meanstd_prepare(const double* params, kabc_cost_rng_t* rng,
+                                              double* aux) {
     int n = (int)params[0];
     double sz = 0.0, szz = 0.0;
     for (int j = 0; j < n; j += 2) {
@@ -103,6 +116,20 @@ KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* param
             szz += z1 * z1;
         }
     }
+    aux[0] = sz;
+    aux[1] = szz;
+}
+KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* params,
+                                            kabc_cost_rng_t* rng) {
+    double aux[2];
+    if (rng->aux) {
+        aux[0] = rng->aux[0];
+        aux[1] = rng->aux[rng->aux_stride];
+    } else {
+        kabc_cost_normal_meanstd_prepare(params, rng, aux);
+    }
+    const double sz = aux[0], szz = aux[1];
+    int n = (int)params[0];
     double dn = (double)n;
     double mz = sz / dn;
     double vz = (szz - dn * mz * mz) / (dn - 1.0);
@@ -112,6 +139,11 @@ KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* param
     double a = mean - params[1];
     double b = 50.0 * (sd - params[2]);
     return kabc_sqrt(a * a + b * b);
+}
+
+/* runtime dispatch of the prepare step (producers; W = kabc_cost_aux_words(id) > 0) */
+KABC_HD void kabc_cost_prepare(int id, const double* params, kabc_cost_rng_t* rng, double* aux) {
+    if (id == KABC_COST_NORMAL_MEANSTD_SIM) kabc_cost_normal_meanstd_prepare(params, rng, aux);
 }
 
 KABC_HD double kabc_cost_dirac_sq(const double* x, const double* params) {

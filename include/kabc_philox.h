@@ -103,6 +103,11 @@ typedef struct kabc_cost_rng {
     uint32_t walker;
     uint32_t domain;
     uint32_t slot;
+    /* State-independent part of the cost, prepared ahead of time (kabc_costs.h
+     * "prepared costs"): aux[j * aux_stride] is word j; NULL = not prepared, the cost
+     * computes it itself from the stream.  Same arithmetic either way. */
+    uint32_t aux_stride;
+    const double* aux;
 } kabc_cost_rng_t;
 
 KABC_HD kabc_u128_t kabc_cost_rng_next(kabc_cost_rng_t* g) {

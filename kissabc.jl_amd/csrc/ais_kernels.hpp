@@ -309,6 +309,18 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     }
 }
 
+// producer side of a prepared cost: lane = walker of the batch, the same sequential
+// arithmetic kabc_cost_eval would do in place (include/kabc_costs.h)
+template <int COST, int W>
+__device__ __forceinline__ void prepare_cost_aux(const AisArgs& A, uint64_t t, uint32_t w_base,
+                                                 int lane, double (*aux)[kBatch]) {
+    kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u, 0u, nullptr};
+    double a[W];
+    kabc_cost_prepare(COST, A.cost_params, &rng, a);
+#pragma unroll
+    for (int j = 0; j < W; ++j) aux[j][lane] = a[j];
+}
+
 // PK = posterior kind (KABC_POSTERIOR_*) as a compile-time constant: with the kind read
 // from the arguments the consumer carried three run-time branches per sub-step in
 // loglike/accept and the SGPRs to feed them -- 8 % of the launch.
@@ -324,6 +336,10 @@ ais_half_kernel(const AisArgs A) {
     __shared__ double sbox_lo[D], sbox_hi[D];
     // the producers' copy of the log table (include/kabc_math.h): per-lane lookups
     __shared__ __attribute__((aligned(16))) double slogtab[384];
+    // prepared costs (include/kabc_costs.h): the parameter-independent part of the cost
+    // of every sub-step, computed by the producers; word j of lane l at [buf][si][j][l]
+    constexpr int kAuxW = cost_aux_c(COST);
+    __shared__ double saux[2][kChunk][kAuxW > 0 ? kAuxW : 1][kBatch];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     const int64_t r0 = (int64_t)blockIdx.x * kBatch;
@@ -379,9 +395,12 @@ ais_half_kernel(const AisArgs A) {
     // prologue: producers fill chunk 0
     if (wave > 0) {
         const int si = wave - 1;
-        if (si < A.nt && !(KABL & 4))
+        if (si < A.nt && !(KABL & 4)) {
             produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
                                lane, slogtab);
+            if constexpr (kAuxW > 0)
+                prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)si, w_base, lane, saux[0][si]);
+        }
     }
     KABC_TIMED_BARRIER();
 
@@ -392,9 +411,13 @@ ais_half_kernel(const AisArgs A) {
             // PRODUCER: sub-step (s0 + kChunk + wave - 1) of the next chunk
             const int si = wave - 1;
             const int s = s0 + kChunk + si;
-            if (s < A.nt && !(KABL & 2))
+            if (s < A.nt && !(KABL & 2)) {
                 produce_substep<D>(A, rec[(c + 1) & 1], si, A.t0 + (uint64_t)s, w_base, n_active,
                                    listB[si], lane, slogtab);
+                if constexpr (kAuxW > 0)
+                    prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)s, w_base, lane,
+                                                  saux[(c + 1) & 1][si]);
+            }
         } else if (active && !(KABL & 1)) {
             // CONSUMER
             const ChunkRec<D>& R = rec[(KABL & 2) ? 0 : (c & 1)];
@@ -466,7 +489,12 @@ ais_half_kernel(const AisArgs A) {
                     load_row<D>(A.x_comp + (int64_t)bn * D, nb);
                 }
                 // ld = loglike(density, push_p(density, p))   src/transition.jl:75
-                kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u};
+                kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u,
+                                       0u, nullptr};
+                if constexpr (kAuxW > 0) {
+                    rng.aux = &saux[(KABL & 2) ? 0 : (c & 1)][si][0][lane];
+                    rng.aux_stride = kBatch;
+                }
                 double nlp, nll;
                 bool ev;
                 loglike<D, COST, PC>(sprior, box, PK, A.eps, A.reps, y, A.cost_params,

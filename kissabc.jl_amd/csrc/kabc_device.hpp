@@ -159,6 +159,9 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorSet& P, const 
     return factored_logpdf_push<D, SIMPLE>(P.c, x, xp);
 }
 
+// words of parameter-independent "prepared" state of a cost (include/kabc_costs.h)
+constexpr int cost_aux_c(int cost) { return cost == KABC_COST_NORMAL_MEANSTD_SIM ? 2 : 0; }
+
 // compile-time cost dispatch on the DeviceCost id (formulas: include/kabc_costs.h)
 template <int COST, int D>
 __device__ __forceinline__ double eval_cost(const double* xp, const double* __restrict__ params,

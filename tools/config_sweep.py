@@ -17,7 +17,9 @@ def configs():
     Nn = lambda D: k.Factored(*[k.Normal(0, 5)] * D)           # noqa: E731
     H16 = k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 14)
     G4 = k.Factored(k.Gamma(2.5, 0.7), k.LogNormal(0.3, 0.6), k.Beta(2, 3), k.Normal(0, 1))
+    RD = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
     return [
+        ("README example N=65536 D=2, normal_meanstd_sim n=1000 (500 Box-Muller pairs per cost)", k.ApproxKernelizedPosterior(RD, k.costs.NormalMeanStdSim(1000, 2.0, 0.04), 0.005), 65536),
         ("C2 N=4096 D=2 Normal priors, gauss_dist", k.ApproxKernelizedPosterior(Nn(2), k.costs.GaussDist([1.0, -0.5]), 0.1), 4096),
         ("C3 N=65536 D=8 box, rosenbrock (bench)", k.ApproxKernelizedPosterior(U(8), k.costs.Rosenbrock(), 1.0), 65536),
         ("N=65536 D=8 box, rosenbrock, ApproxPosterior", k.ApproxPosterior(U(8), k.costs.Rosenbrock(), 30.0), 65536),
@@ -35,7 +37,7 @@ for name, model, N in configs():
     row = {"config": name}
     for nt in (100, 16):
         ens = k.AisEnsemble(model, N, seed=1).init()
-        gens = max(4, min(60, int(4e8 / (N * nt))))
+        gens = max(2, min(60, int((4e8 if 'README' not in name else 2e7) / (N * nt))))
         ens.advance(3, nt)
         ens.set_timing(2 * gens, stride=1 if gens < 8 else 8)
         ens.advance(gens, nt)
