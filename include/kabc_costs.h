@@ -141,9 +141,19 @@ KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* param
     return kabc_sqrt(a * a + b * b);
 }
 
-/* runtime dispatch of the prepare step (producers; W = kabc_cost_aux_words(id) > 0) */
-KABC_HD void kabc_cost_prepare(int id, const double* params, kabc_cost_rng_t* rng, double* aux) {
+/* runtime dispatch of the prepare step (producers; W = kabc_cost_aux_words(id) > 0).
+ * A user cost (KABC_COST_USER) takes part by defining, in its snippet,
+ *     #define KABC_USER_AUX_WORDS W          (1 .. KABC_COST_MAX_AUX)
+ *     KABC_HD void kabc_user_cost_prepare(const double* params, const double* data,
+ *                                         int64_t ndata, kabc_cost_rng_t* rng, double* aux);
+ * and by reading rng->aux[j * rng->aux_stride] in kabc_user_cost when rng->aux != NULL
+ * (calling kabc_user_cost_prepare itself otherwise). */
+KABC_HD void kabc_cost_prepare(int id, const double* params, const double* data, int64_t ndata,
+                               kabc_cost_rng_t* rng, double* aux) {
     if (id == KABC_COST_NORMAL_MEANSTD_SIM) kabc_cost_normal_meanstd_prepare(params, rng, aux);
+#ifdef KABC_USER_AUX_WORDS
+    else if (id >= KABC_COST_USER) kabc_user_cost_prepare(params, data, ndata, rng, aux);
+#endif
 }
 
 KABC_HD double kabc_cost_dirac_sq(const double* x, const double* params) {

@@ -316,7 +316,7 @@ __device__ __forceinline__ void prepare_cost_aux(const AisArgs& A, uint64_t t, u
                                                  int lane, double (*aux)[kBatch]) {
     kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u, 0u, nullptr};
     double a[W];
-    kabc_cost_prepare(COST, A.cost_params, &rng, a);
+    kabc_cost_prepare(COST, A.cost_params, A.cost_data, A.cost_ndata, &rng, a);
 #pragma unroll
     for (int j = 0; j < W; ++j) aux[j][lane] = a[j];
 }

@@ -160,7 +160,15 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorSet& P, const 
 }
 
 // words of parameter-independent "prepared" state of a cost (include/kabc_costs.h)
-constexpr int cost_aux_c(int cost) { return cost == KABC_COST_NORMAL_MEANSTD_SIM ? 2 : 0; }
+#ifndef KABC_USER_AUX_WORDS
+#define KABC_USER_AUX_WORDS_OR_0 0
+#else
+#define KABC_USER_AUX_WORDS_OR_0 KABC_USER_AUX_WORDS
+#endif
+constexpr int cost_aux_c(int cost) {
+    return cost == KABC_COST_NORMAL_MEANSTD_SIM ? 2 : cost >= KABC_COST_USER ? KABC_USER_AUX_WORDS_OR_0 : 0;
+}
+static_assert(KABC_USER_AUX_WORDS_OR_0 <= KABC_COST_MAX_AUX, "KABC_USER_AUX_WORDS too large");
 
 // compile-time cost dispatch on the DeviceCost id (formulas: include/kabc_costs.h)
 template <int COST, int D>

@@ -162,3 +162,52 @@ def test_common_log_density_gpu_parity_and_reference_tests(k, orc, gpu_ctx):
     with pytest.raises(k.KabcError) as e:
         k.sample(k.CommonLogDensity(2, init, never), k.AIS(50), 10)
     assert "Prior leads to ∞ costs too often" in str(e.value)
+
+
+# ---- prepared user cost (include/kabc_costs.h "prepared costs") -----------------------
+PREP_SRC = r'''
+#define KABC_USER_AUX_WORDS 2
+KABC_HD void kabc_user_cost_prepare(const double* params, const double* data, int64_t ndata,
+                                    kabc_cost_rng_t* rng, double* aux) {
+    int n = (int)params[0];
+    double sz = 0.0, szz = 0.0;
+    for (int j = 0; j < n; j += 2) {
+        double z0, z1;
+        kabc_cost_rng_normal2(rng, &z0, &z1);
+        sz += z0;  szz += z0 * z0;
+        if (j + 1 < n) { sz += z1;  szz += z1 * z1; }
+    }
+    aux[0] = sz;  aux[1] = szz;
+}
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params, const double* data,
+                              int64_t ndata, kabc_cost_rng_t* rng) {
+    double aux[2];
+    if (rng->aux) { aux[0] = rng->aux[0];  aux[1] = rng->aux[rng->aux_stride]; }
+    else kabc_user_cost_prepare(params, data, ndata, rng, aux);
+    double dn = (double)(int)params[0];
+    double mz = aux[0] / dn;
+    double vz = (aux[1] - dn * mz * mz) / (dn - 1.0);
+    if (vz < 0.0) vz = 0.0;
+    double a = x[0] + x[1] * mz - params[1];
+    double b = 50.0 * (kabc_fabs(x[1]) * kabc_sqrt(vz) - params[2]);
+    return kabc_sqrt(a * a + b * b);
+}
+'''
+
+
+@pytest.mark.gpu
+def test_prepared_user_cost_equals_builtin_and_oracle(k, orc, gpu_ctx):
+    """A user simulator with a prepare step (run by the AIS producer waves) gives the
+    bits of the built-in normal_meanstd_sim and of the oracle, which evaluates the same
+    snippet without any preparation."""
+    prior = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
+    user = k.costs.UserCost(PREP_SRC, dims=[2], params=[200, 2.0, 0.04], name="prep",
+                            posteriors=["kernelized"])
+    orc.register_user_cost(user)
+    N, gens, nt = 300, 3, 4
+    mu = k.ApproxKernelizedPosterior(prior, user, 0.005)
+    mb = k.ApproxKernelizedPosterior(prior, k.costs.NormalMeanStdSim(200, 2.0, 0.04), 0.005)
+    got = k.AisEnsemble(mu, N, seed=2).init().advance(gens, nt, collect=True)
+    ref = k.AisEnsemble(mb, N, seed=2).init().advance(gens, nt, collect=True)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got, orc.OracleAIS(mu, N, seed=2).init().generations_sync(gens, nt))
