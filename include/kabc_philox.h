@@ -108,6 +108,9 @@ typedef struct kabc_cost_rng {
      * computes it itself from the stream.  Same arithmetic either way. */
     uint32_t aux_stride;
     const double* aux;
+    /* copy of kabc_log_tab the normals should look their logs up in (a kernel's LDS copy:
+     * a per-lane gather from LDS instead of global memory); NULL = kabc_log_tab */
+    const double* logtab;
 } kabc_cost_rng_t;
 
 KABC_HD kabc_u128_t kabc_cost_rng_next(kabc_cost_rng_t* g) {
@@ -116,7 +119,7 @@ KABC_HD kabc_u128_t kabc_cost_rng_next(kabc_cost_rng_t* g) {
 /* two N(0,1) per block */
 KABC_HD void kabc_cost_rng_normal2(kabc_cost_rng_t* g, double* z0, double* z1) {
     kabc_u128_t b = kabc_cost_rng_next(g);
-    kabc_normal_pair(kabc_lo64(b), kabc_hi64(b), z0, z1);
+    kabc_normal_pair_tab(kabc_lo64(b), kabc_hi64(b), z0, z1, g->logtab ? g->logtab : kabc_log_tab);
 }
 /* two U(0,1) per block */
 KABC_HD void kabc_cost_rng_uniform2(kabc_cost_rng_t* g, double* u0, double* u1) {

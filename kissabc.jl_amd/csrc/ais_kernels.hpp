@@ -313,8 +313,10 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
 // arithmetic kabc_cost_eval would do in place (include/kabc_costs.h)
 template <int COST, int W>
 __device__ __forceinline__ void prepare_cost_aux(const AisArgs& A, uint64_t t, uint32_t w_base,
-                                                 int lane, double (*aux)[kBatch]) {
-    kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u, 0u, nullptr};
+                                                 int lane, double (*aux)[kBatch],
+                                                 const double* logtab) {
+    kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u, 0u, nullptr,
+                           logtab};
     double a[W];
     kabc_cost_prepare(COST, A.cost_params, A.cost_data, A.cost_ndata, &rng, a);
 #pragma unroll
@@ -399,7 +401,8 @@ ais_half_kernel(const AisArgs A) {
             produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
                                lane, slogtab);
             if constexpr (kAuxW > 0)
-                prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)si, w_base, lane, saux[0][si]);
+                prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)si, w_base, lane, saux[0][si],
+                                              slogtab);
         }
     }
     KABC_TIMED_BARRIER();
@@ -416,7 +419,7 @@ ais_half_kernel(const AisArgs A) {
                                    listB[si], lane, slogtab);
                 if constexpr (kAuxW > 0)
                     prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)s, w_base, lane,
-                                                  saux[(c + 1) & 1][si]);
+                                                  saux[(c + 1) & 1][si], slogtab);
             }
         } else if (active && !(KABL & 1)) {
             // CONSUMER
@@ -490,7 +493,7 @@ ais_half_kernel(const AisArgs A) {
                 }
                 // ld = loglike(density, push_p(density, p))   src/transition.jl:75
                 kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u,
-                                       0u, nullptr};
+                                       0u, nullptr, slogtab};
                 if constexpr (kAuxW > 0) {
                     rng.aux = &saux[(KABL & 2) ? 0 : (c & 1)][si][0][lane];
                     rng.aux_stride = kBatch;

@@ -296,7 +296,7 @@ static int cost_dim_ok_any(int id, int D) {
 
 double orc_cost_eval(const kabc_cost_t* cost, int32_t D, const double* x, uint64_t seed,
                      uint32_t walker, uint64_t t, uint32_t domain) {
-    kabc_cost_rng_t rng = {seed, t, walker, domain, 0, 0, NULL};
+    kabc_cost_rng_t rng = {seed, t, walker, domain, 0, 0, NULL, NULL};
     if (cost->id >= KABC_COST_USER)
         return g_user_cost[cost->id - KABC_COST_USER](x, D, cost->params, cost->data, cost->ndata,
                                                       &rng);
