@@ -337,7 +337,7 @@ ais_half_kernel(const AisArgs A) {
     __shared__ PriorDev sprior[D];
     __shared__ double sbox_lo[D], sbox_hi[D];
     // the producers' copy of the log table (include/kabc_math.h): per-lane lookups
-    __shared__ __attribute__((aligned(16))) double slogtab[384];
+    __shared__ __attribute__((aligned(16))) double slogtab[KABC_MATH_TAB_WORDS];
     // prepared costs (include/kabc_costs.h): the parameter-independent part of the cost
     // of every sub-step, computed by the producers; word j of lane l at [buf][si][j][l]
     constexpr int kAuxW = cost_aux_c(COST);
@@ -379,7 +379,7 @@ ais_half_kernel(const AisArgs A) {
         if (!ld_valid(PK, lp, ll)) err = 2;  // accept(): "old log-density is invalid"
     }
 
-    for (int j = threadIdx.x; j < 384; j += kAisBlock) slogtab[j] = kabc_log_tab[j];
+    for (int j = threadIdx.x; j < KABC_MATH_TAB_WORDS; j += kAisBlock) slogtab[j] = kabc_log_tab[j];
     if (threadIdx.x < D * (int)(sizeof(PriorDev) / 8))
         reinterpret_cast<double*>(sprior)[threadIdx.x] =
             reinterpret_cast<const double*>(A.prior)[threadIdx.x];
