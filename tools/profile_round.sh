@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-O=${1:-gpurun_out/r01k}; mkdir -p $O
+O=${1:-gpurun_out/r01m}; mkdir -p $O
 (rocm-smi --showclocks --showpower 2>/dev/null || true) > $O/rocm_smi_before.txt
 python3 bench.py > $O/bench.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu-baseline --no-alt > $O/bench_under_rocprof.json 2> $O/stats.err
@@ -20,3 +20,4 @@ KABC_SMC_STAMPS=1 python3 tools/smc_c4_probe.py --oracle > $O/smc_c4.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/smc_stats -- python3 tools/smc_c4_probe.py > /dev/null 2>&1
 find $O -name "*kernel_stats.csv" | head; tail -1 $O/bench.json | cut -c1-400; cat $O/pmc_summary.txt | head -40
 (rocm-smi --showclocks --showpower 2>/dev/null || true) > $O/rocm_smi_after.txt
+python3 tools/config_sweep.py > $O/config_sweep.jsonl 2>/dev/null
