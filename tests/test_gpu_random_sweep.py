@@ -5,7 +5,11 @@ hand-picked cases of test_gpu_ais_parity.py / test_gpu_smc_parity.py."""
 import numpy as np
 import pytest
 
+import os
+
 pytestmark = pytest.mark.gpu
+# KABC_SWEEP_SCALE=k multiplies the number of random configurations (soak runs)
+_SCALE = max(1, int(os.environ.get("KABC_SWEEP_SCALE", "1")))
 
 
 def _random_prior(k, rng, D):
@@ -47,7 +51,7 @@ def _random_cost(k, rng, D):
     return k.costs.HierGaussSim(rng.normal(size=D - 2))
 
 
-@pytest.mark.parametrize("case", range(60))
+@pytest.mark.parametrize("case", range(60 * _SCALE))
 def test_ais_random_case_bit_exact(k, orc, gpu_ctx, case):
     rng = np.random.default_rng(1000 + case)
     D = int(rng.integers(1, 17))
@@ -69,7 +73,7 @@ def test_ais_random_case_bit_exact(k, orc, gpu_ctx, case):
     assert ens.stats() == o.stats()
 
 
-@pytest.mark.parametrize("case", range(32))
+@pytest.mark.parametrize("case", range(32 * _SCALE))
 def test_smc_random_case_bit_exact(k, orc, gpu_ctx, monkeypatch, case):
     rng = np.random.default_rng(5000 + case)
     D = int(rng.integers(1, 9))
@@ -92,7 +96,7 @@ def test_smc_random_case_bit_exact(k, orc, gpu_ctx, monkeypatch, case):
         [(it["eps"], it["ess"], it["accepted"]) for it in ro["log"]]
 
 
-@pytest.mark.parametrize("case", range(8))
+@pytest.mark.parametrize("case", range(8 * _SCALE))
 def test_pfilter_random_case_bit_exact(k, orc, gpu_ctx, monkeypatch, case):
     rng = np.random.default_rng(9000 + case)
     D = int(rng.integers(1, 5))
