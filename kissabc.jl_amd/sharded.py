@@ -102,6 +102,13 @@ class ShardedAIS:
             buf = self.engine.half[half]
             lo, hi = self.engine.rows[half]
             own = buf[lo:hi]
+            if buf.is_cuda and dist.get_backend(self.group) == "gloo":
+                # test configuration only (several ranks sharing one GPU, where RCCL refuses
+                # duplicate devices): exchange through host memory
+                out = torch.empty(buf.shape, dtype=buf.dtype)
+                dist.all_gather_into_tensor(out, own.cpu(), group=self.group)
+                buf.copy_(out)
+                return
             if not getattr(self.engine, "inplace_gather", False):
                 own = own.clone()
             dist.all_gather_into_tensor(buf, own, group=self.group)
@@ -137,8 +144,11 @@ class ShardedAIS:
     def global_stats(self):
         st = self.engine.stats()
         with self._stream_ctx():
+            dev = self.engine.half[0].device
+            if dev.type == "cuda" and dist.is_initialized() and dist.get_backend(self.group) == "gloo":
+                dev = torch.device("cpu")
             t = torch.tensor([st["proposals"], st["cost_evals"], st["accepted"]],
-                             dtype=torch.int64, device=self.engine.half[0].device)
+                             dtype=torch.int64, device=dev)
             if self.world > 1:
                 dist.all_reduce(t, group=self.group)
         return dict(zip(("proposals", "cost_evals", "accepted"), (int(v) for v in t.tolist())))
