@@ -118,13 +118,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # dry-run knobs (tests/test_gpu_bench_two_ranks.py): all ranks on one device, exchange
+    # over gloo through host memory -- exercises this script's N > 1 branch on a 1-GPU box
+    backend = os.environ.get("KABC_BENCH_BACKEND", "nccl")
+    if os.environ.get("KABC_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["KABC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_pg = world > 1 or os.environ.get("KABC_FORCE_COLLECTIVE") == "1"
     if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     model = build_model(k)
     n_total = WALKERS_PER_GPU * world
@@ -155,7 +163,7 @@ def main():
         kms_r, nl_r = ens.kernel_ms()
         ens.set_timing(0)
         s1 = sh.global_stats()
-        tmax = torch.tensor([el_r], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([el_r], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         if use_pg:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item()), kms_r, nl_r, s0, s1
