@@ -389,10 +389,23 @@ ais_half_kernel(const AisArgs A) {
     }
     uint32_t dmask = 0;
     for (int k = 0; k < D; ++k) dmask |= (A.prior[k].discrete ? 1u : 0u) << k;
-    const BoxPrior box = {sbox_lo, sbox_hi, dmask, A.box_lp};
+    // BOX class, D <= 8: the bounds live in registers for the whole launch (32 VGPRs at
+    // D = 8) instead of being re-read from LDS in every sub-step (-1.5 %); larger D has
+    // no registers to spare
+    constexpr bool kBoxRegs = (PC == kPriorBox) && D <= 8;
+    double blo[kBoxRegs ? D : 1], bhi[kBoxRegs ? D : 1];
+    const BoxPrior box = {kBoxRegs ? blo : sbox_lo, kBoxRegs ? bhi : sbox_hi, dmask, A.box_lp};
 
     // the log table is staged by all four waves and read by the producers right away
     KABC_TIMED_BARRIER();
+    if constexpr (kBoxRegs) {  // per-lane copies from LDS (vector registers: scalar ones ran
+                               // out and spilled when these were loaded as uniform values)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            blo[k] = sbox_lo[k];
+            bhi[k] = sbox_hi[k];
+        }
+    }
 
     // prologue: producers fill chunk 0
     if (wave > 0) {
