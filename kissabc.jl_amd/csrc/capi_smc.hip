@@ -196,7 +196,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     double *th[2], *X[2], *lp[2], *d_params = nullptr, *d_data = nullptr, *d_out = nullptr,
            *d_Xout = nullptr;
     uint8_t* alive;
-    int32_t *ridx, *cidx;
+    int32_t* cidx;
     SmcCtrl* ctrl;
     unsigned long long* slots;
     kabc_smc_iter_t* d_log = nullptr;
@@ -207,7 +207,6 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         KABC_HIP_CHECK(bufs.alloc(&lp[b], (size_t)N));
     }
     KABC_HIP_CHECK(bufs.alloc(&alive, (size_t)N));
-    KABC_HIP_CHECK(bufs.alloc(&ridx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&ctrl, 1));
     KABC_HIP_CHECK(bufs.alloc(&slots, (size_t)kSmcSlots * 8));
@@ -269,7 +268,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     sa.Xbuf[0] = X[0];
     sa.Xbuf[1] = X[1];
     sa.alive = alive;
-    sa.ridx = ridx;
+    sa.ridx = nullptr;
     sa.cidx = cidx;
     sa.ctrl = ctrl;
     sa.N = N;
@@ -293,7 +292,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         ma.lpi[b] = lp[b];
     }
     ma.alive = alive;
-    ma.ridx = ridx;
+    ma.cidx = cidx;
     ma.ctrl = ctrl;
     ma.slots = slots;
     ma.cost_params = d_params;
@@ -509,7 +508,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     DevBufs bufs;
     double *th, *Cc, *lpi, *d_params = nullptr, *d_data = nullptr, *d_out, *d_cout;
     uint8_t *ones, *ok, *pending;
-    int32_t *ridx, *cidx;
+    int32_t* cidx;
     SmcCtrl* sel;
     PfCtrl* pctrl;
     AbcdeCtrl* actrl;
@@ -521,7 +520,6 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     KABC_HIP_CHECK(bufs.alloc(&ones, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&ok, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&pending, (size_t)N));
-    KABC_HIP_CHECK(bufs.alloc(&ridx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&sel, 1));
     KABC_HIP_CHECK(bufs.alloc(&pctrl, 1));
@@ -573,7 +571,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     sa.Xbuf[1] = Cc;
     sa.alive = ones;
     sa.alive_out = ok;
-    sa.ridx = ridx;
+    sa.ridx = nullptr;
     sa.cidx = cidx;
     sa.ctrl = sel;
     sa.N = N;

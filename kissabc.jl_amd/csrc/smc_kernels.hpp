@@ -84,7 +84,7 @@ struct SmcSelScratch {
 struct SmcSelectArgs {
     const double* Xbuf[2];
     uint8_t* alive;
-    int32_t* ridx;   // out: source row of particle i for the next MCMC pass
+    int32_t* ridx;   // unused (the resample index is cidx[j mod ESS], see smc_mcmc_kernel)
     int32_t* cidx;   // scratch: compacted alive indices
     SmcCtrl* ctrl;
     int64_t N;
@@ -108,7 +108,8 @@ struct SmcMcmcArgs {
     double* X[2];
     double* lpi[2];
     const uint8_t* alive;
-    const int32_t* ridx;  // used when ctrl->use_ridx
+    const int32_t* cidx;  // compacted alive indices of the last select: after a resample the
+                          // first pass of the iteration reads particle j from row cidx[j mod ESS]
     SmcCtrl* ctrl;
     unsigned long long* slots;  // [kSmcSlots][8]: accepted, cost_evals, proposals
     const double* cost_params;
@@ -688,22 +689,15 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         (A.mode == 0 && A.alpha * (double)ESS <= (double)N * A.min_r_ess) ? 1 : 0;
     const bool fail = resample && ESS == 0;
     if (resample && !fail) {
-        // idx = repeat(idxalive, ceil(N/m))[1:N]  (src/smc.jl:146-147): needs the whole cidx
-        sel_grid_barrier(g, G);
-        const unsigned e = (unsigned)ESS;
-        unsigned rmod = (unsigned)((i_lo + tid) % (int64_t)e);
-        const unsigned step = (unsigned)kSelBlock % e;
-        for (int64_t jdx = i_lo + tid; jdx < i_hi; jdx += kSelBlock) {
-            A.ridx[jdx] = A.cidx[rmod];
-            A.alive[jdx] = 1;
-            rmod += step;
-            if (rmod >= e) rmod -= e;
-        }
+        // idx = repeat(idxalive, ceil(N/m))[1:N]  (src/smc.jl:146-147) is not materialised:
+        // the next MCMC pass reads particle j from row cidx[j mod ESS] itself (the compacted
+        // index is complete at the kernel boundary), so no barrier and no pass is needed
+        // here.  Nothing reads `alive` after the slice-count barrier above.
+        for (int64_t jdx = i_lo + tid; jdx < i_hi; jdx += kSelBlock) A.alive[jdx] = 1;
     } else if (!fail) {
         for (int64_t i = i_lo + tid; i < i_hi; i += kSelBlock) {
             const double x = X[i];
             A.alive_out[i] = (flag ? (x <= eps) : (x < eps)) ? 1 : 0;
-            if (A.mode == 0) A.ridx[i] = (int32_t)i;
         }
     }
     KABC_STAMP(5)
@@ -751,7 +745,10 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
     double Xfin = 0.0;
     bool alive_i = false;
     if (i < A.N) {
-        const int64_t si = gather ? A.ridx[i] : i;
+        // idx = repeat(idxalive, ceil(N/m))[1:N]  (src/smc.jl:146-147), evaluated on the fly
+        const bool remap = gather && A.ctrl->resampled != 0;
+        const unsigned ess = (unsigned)A.ctrl->ess;
+        const int64_t si = remap ? (int64_t)A.cidx[(unsigned)i % ess] : i;
         double th[D];
         load_row<D>(theta_src + si * D, th);
         double Xi = X_src[si];
@@ -773,8 +770,8 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
             double z0, z1;
             kabc_normal_pair(kabc_lo64(B1), kabc_hi64(B1), &z0, &z1);
             const double s = A.max_stretch * z0 / kabc_sqrt((double)D);
-            const int64_t sa = gather ? A.ridx[a] : a;
-            const int64_t sb = gather ? A.ridx[b] : b;
+            const int64_t sa = remap ? (int64_t)A.cidx[(unsigned)a % ess] : a;
+            const int64_t sb = remap ? (int64_t)A.cidx[(unsigned)b % ess] : b;
             double ta[D], tb[D], prop[D], xp[D];
             load_row<D>(theta_src + sa * D, ta);
             load_row<D>(theta_src + sb * D, tb);
