@@ -34,7 +34,7 @@ typedef enum kabc_status {
     KABC_OK = 0,
     KABC_ERR_INVALID_ARG = 1,     /* reference: error(...) on argument checks            */
     KABC_ERR_RETRY_EXHAUSTED = 2, /* src/KissABC.jl:58-59                                */
-    KABC_ERR_INVALID_STATE = 3,   /* src/types.jl:152 "starting sample invalid."         */
+    KABC_ERR_INVALID_STATE = 3,   /* src/types.jl:70 "starting sample invalid."         */
     KABC_ERR_DEVICE = 4,          /* HIP runtime error / no gfx950 device / no kernels   */
     KABC_ERR_UNSUPPORTED = 5,     /* model outside the DeviceCost / prior surface        */
     KABC_ERR_NAN_COST = 6         /* Statistics.quantile: "undefined in presence of NaNs" */
@@ -61,7 +61,7 @@ typedef struct kabc_prior {
     double p[4];
 } kabc_prior_t;
 
-/* DeviceCost: replaces the `cost` closure (src/types.jl:124,137; src/smc.jl:94).
+/* DeviceCost: replaces the `cost` closure (src/types.jl:42,55; src/smc.jl:94).
  * ids and formulas: include/kabc_costs.h */
 typedef struct kabc_cost {
     int32_t id;
@@ -72,9 +72,9 @@ typedef struct kabc_cost {
 } kabc_cost_t;
 
 typedef enum kabc_posterior_kind {
-    KABC_POSTERIOR_KERNELIZED = 1, /* ApproxKernelizedPosterior, src/types.jl:122-157; eps = scale   */
-    KABC_POSTERIOR_THRESHOLD = 2,  /* ApproxPosterior,           src/types.jl:158-186; eps = maxcost */
-    /* CommonLogDensity(nparameters, sample_init, lπ), src/types.jl:187-210: plain MCMC on a
+    KABC_POSTERIOR_KERNELIZED = 1, /* ApproxKernelizedPosterior, src/types.jl:40-75; eps = scale   */
+    KABC_POSTERIOR_THRESHOLD = 2,  /* ApproxPosterior,           src/types.jl:76-104; eps = maxcost */
+    /* CommonLogDensity(nparameters, sample_init, lπ), src/types.jl:105-128: plain MCMC on a
      * log-density.  `cost` IS lπ (returns the log-density), `prior` describes sample_init
      * (used only by step(init)); no push_p, no prior term, eps unused. */
     KABC_POSTERIOR_COMMON = 3
@@ -121,10 +121,10 @@ kabc_status_t kabc_host_alloc(size_t bytes, void** out);
 kabc_status_t kabc_host_free(void* p);
 
 /* ---- Factored utilities (device kernels; host in, host out) ----------------
- * logpdf(d::Factored, x) for n rows x[n][D]      -- src/priors.jl:275-281
- * push_p(d::Factored, x)                          -- src/types.jl:111-114
+ * logpdf(d::Factored, x) for n rows x[n][D]      -- src/priors.jl:30-36
+ * push_p(d::Factored, x)                          -- src/types.jl:29-32
  * rand(rng, d::Factored) for walkers first..first+n of stream (seed, domain, attempt)
- *                                                 -- src/priors.jl:287-288 */
+ *                                                 -- src/priors.jl:42-43 */
 kabc_status_t kabc_factored_logpdf(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
                                    int64_t n, const double* x, double* out);
 kabc_status_t kabc_factored_push_p(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
@@ -143,7 +143,7 @@ kabc_status_t kabc_math_probe(kabc_ctx_t* ctx, int32_t fn, int64_t n, const doub
                               double* out);
 
 /* ---- user DeviceCost plugins ------------------------------------------------
- * Replaces "cost is an arbitrary closure" (src/types.jl:124,137; src/smc.jl:94) for
+ * Replaces "cost is an arbitrary closure" (src/types.jl:42,55; src/smc.jl:94) for
  * costs that can be written as a C function (signature: include/kabc_costs.h,
  * KABC_COST_USER).  `path` is a shared library built from the user's snippet +
  * kissabc.jl_amd/csrc/user_plugin.inc with hipcc --offload-arch=gfx950; on success
@@ -154,7 +154,7 @@ kabc_status_t kabc_register_cost_plugin(const char* path, int32_t* out_cost_id);
  *
  * Ensemble layout.  Walker ids g = 0..N-1.  Half 0 = ids [0, N0), half 1 = ids
  * [N0, N), N0 = ceil(N/2).  Each half is a row-major [rows][D] f64 array; the
- * log-density pair (logprior, loglikelihood|cost) of src/types.jl:139,172 is two
+ * log-density pair (logprior, loglikelihood|cost) of src/types.jl:57,90 is two
  * f64 arrays per half.
  *
  * Schedule.  The reference sweeps serially: step() gives walker i `ntransitions`

@@ -2,7 +2,7 @@
  * kabc_costs.h -- the DeviceCost library.
  *
  * In the reference the `cost` argument of ApproxKernelizedPosterior /
- * ApproxPosterior / smc is an arbitrary Julia closure (src/types.jl:124,137;
+ * ApproxPosterior / smc is an arbitrary Julia closure (src/types.jl:42,55;
  * src/smc.jl:94,176).  A gfx950 kernel cannot call a Julia closure, so on this
  * path a cost is a DeviceCost: an id + parameter/data arrays whose formula is
  * defined ONCE here as a host+device inline.  The same definition is evaluated
@@ -10,7 +10,7 @@
  * closure handed to both the reference path and the accelerated path.
  *
  * Each entry cites the reference workload it restates.  `x` is the push_p'ed
- * parameter vector (discrete coordinates already rounded, src/types.jl:109-114).
+ * parameter vector (discrete coordinates already rounded, src/types.jl:27-32).
  * Stochastic simulators draw from the kabc_cost_rng_t stream they are given.
  */
 #ifndef KABC_COSTS_H

@@ -3,7 +3,7 @@
  * become prior draws.  Part of the stream contract (with kabc_philox.h).
  *
  * The reference calls Distributions.jl `rand` per component
- * (src/priors.jl:287-288 via src/types.jl:116-117); Distributions.jl is not in
+ * (src/priors.jl:42-43 via src/types.jl:34-35); Distributions.jl is not in
  * the reference tree and its samplers consume a serial RNG, so only the
  * DISTRIBUTION of each draw is reproducible, not the stream.  The samplers here
  * are textbook algorithms written against a bounded window of counter slots

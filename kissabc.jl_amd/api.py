@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's user API for the walker-update path:
 
-    ApproxKernelizedPosterior(prior, cost, scale)      src/types.jl:122-131
-    ApproxPosterior(prior, cost, maxcost)              src/types.jl:158-164
+    ApproxKernelizedPosterior(prior, cost, scale)      src/types.jl:40-49
+    ApproxPosterior(prior, cost, maxcost)              src/types.jl:76-82
     AIS(nparticles)                                    src/KissABC.jl:21-23
     sample(model, AIS(N), Ns; ntransitions, discard_initial, retry_sampling)
     sample(model, AIS(N), MCMCThreads(), Ns, Nc; ...)  src/KissABC.jl:106-173
@@ -64,7 +64,7 @@ class _ApproxModel:
         self.cost = cost
         self.eps = float(eps)
 
-    def __len__(self):  # length(density) = length(prior), src/types.jl:119
+    def __len__(self):  # length(density) = length(prior), src/types.jl:37
         return len(self.prior)
 
     def to_c(self):
@@ -79,7 +79,7 @@ class _ApproxModel:
 
 
 class ApproxKernelizedPosterior(_ApproxModel):
-    """Gaussian-kernel ABC density; `scale` = target_average_cost (src/types.jl:212-221)."""
+    """Gaussian-kernel ABC density; `scale` = target_average_cost (src/types.jl:130-139)."""
     posterior = cd.POSTERIOR_KERNELIZED
 
     @property
@@ -88,7 +88,7 @@ class ApproxKernelizedPosterior(_ApproxModel):
 
 
 class ApproxPosterior(_ApproxModel):
-    """Hard-threshold ABC density; `maxcost` (src/types.jl:222-231)."""
+    """Hard-threshold ABC density; `maxcost` (src/types.jl:140-149)."""
     posterior = cd.POSTERIOR_THRESHOLD
 
     @property
@@ -97,7 +97,7 @@ class ApproxPosterior(_ApproxModel):
 
 
 class CommonLogDensity(_ApproxModel):
-    """CommonLogDensity(nparameters, sample_init, lπ) -- src/types.jl:187-210, 233-243:
+    """CommonLogDensity(nparameters, sample_init, lπ) -- src/types.jl:105-128, 151-161:
     classical MCMC on a log-density.  On the device path `lπ` is a DeviceCost that
     RETURNS THE LOG-DENSITY (built-in or costs.UserCost) and `sample_init` is a
     Factored / univariate distribution the initial walkers are drawn from

@@ -4,9 +4,9 @@
 // Replaces, for a whole half-ensemble at once:
 //   transition!            src/transition.jl:67-82
 //   propose + three moves  src/transition.jl:2-65
-//   push_p                 src/types.jl:109-114
-//   loglike / accept       src/types.jl:133-157 (kernelized), :166-186 (threshold)
-//   Factored logpdf        src/priors.jl:275-281
+//   push_p                 src/types.jl:27-32
+//   loglike / accept       src/types.jl:51-75 (kernelized), :84-104 (threshold)
+//   Factored logpdf        src/priors.jl:30-36
 //   step(init)             src/KissABC.jl:35-64
 #pragma once
 
@@ -102,7 +102,7 @@ struct ChunkRec {
     uint32_t mva[kChunk][kBatch];   // (move << 30) | partner row a
     uint32_t bb[kChunk][kBatch];    // partner row b (DE, walk)
     uint32_t cc[kChunk][kBatch];    // partner row c (walk)
-    double logu[kChunk][kBatch];    // log(u) = -randexp(rng)          (src/types.jl:156)
+    double logu[kChunk][kBatch];    // log(u) = -randexp(rng)          (src/types.jl:74)
     // stretch: zs[0] = Z, zs[1] = (D-1) log Z     (src/transition.jl:56-58)
     // de     : zs[0] = gamma, zs[1..D] = randn per coordinate (:3, :13)
     // walk   : zs[0..2] = the three randn           (:38-40)
@@ -111,8 +111,8 @@ struct ChunkRec {
 
 template <int POSTERIOR_RUNTIME = 0>
 __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
-    // is_valid_logdensity: src/types.jl:142 and :175-176
-    // (CommonLogDensity, :203: isfinite(ld), held as lp = 0, ll = lπ)
+    // is_valid_logdensity: src/types.jl:60 and :93-94
+    // (CommonLogDensity, :121: isfinite(ld), held as lp = 0, ll = lπ)
     return posterior != KABC_POSTERIOR_THRESHOLD ? kabc_isfinite(lp + ll)
                                                  : (kabc_isfinite(ll) && kabc_isfinite(lp));
 }
@@ -120,7 +120,7 @@ __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
 // Prior classes (chosen on the host, identical results):
 //   BOX     every component is Uniform / DiscreteUniform: logpdf is the constant
 //           c0_1 + ... + c0_D (summed left to right on the host, as
-//           src/priors.jl:275-281 would) inside the box and -Inf outside
+//           src/priors.jl:30-36 would) inside the box and -Inf outside
 //   SIMPLE  no per-walker transcendental (adds Normal, truncated Normal, Exponential)
 //   GENERAL everything (Beta, NegativeBinomial, Gamma, LogNormal ...)
 enum { kPriorBox = 0, kPriorSimple = 1, kPriorGeneral = 2 };
@@ -132,7 +132,7 @@ struct BoxPrior {
     double lp;          // in-support log-density
 };
 
-// loglike(density, push_p(density, y)) -- src/types.jl:133-140, :166-173
+// loglike(density, push_p(density, y)) -- src/types.jl:51-58, :84-91
 template <int D, int COST, int PC>
 __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const BoxPrior& B,
                                         int posterior, double eps, double reps, const double* y,
@@ -141,8 +141,8 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
                                         double& ll, bool& ev) {
     double yp[D];
     if (posterior == KABC_POSTERIOR_COMMON) {
-        // loglike(density::CommonLogDensity, sample) = lπ(sample.x)  src/types.jl:199-201;
-        // push_p is the identity for a plain AbstractDensity (:109)
+        // loglike(density::CommonLogDensity, sample) = lπ(sample.x)  src/types.jl:117-119;
+        // push_p is the identity for a plain AbstractDensity (:27)
         lp = 0.0;
         ev = true;
         ll = eval_cost<COST, D>(y, cost_params, cost_data, ndata, rng);
@@ -517,7 +517,7 @@ ais_half_kernel(const AisArgs A) {
                                      A.cost_data, A.cost_ndata, &rng, nlp, nll, ev);
                 __builtin_amdgcn_sched_barrier(0);
                 n_eval += ev ? 1u : 0u;
-                // accept(...)  src/types.jl:144-157, :178-186
+                // accept(...)  src/types.jl:62-75, :96-104
                 // (the old state's validity is checked once, before the first sub-step: it
                 // can only change through an accept, which requires a valid new state)
                 bool acc = false;
@@ -528,7 +528,7 @@ ais_half_kernel(const AisArgs A) {
                         const double lW = corr + (nlp + nll) - (lp + ll);
                         acc = (-e <= lW);
                     } else if (PK == KABC_POSTERIOR_COMMON) {
-                        const double lW = corr + nll - ll;  // src/types.jl:209
+                        const double lW = corr + nll - ll;  // src/types.jl:127
                         acc = (-e <= lW);
                     } else {
                         const double lW = corr + nlp - lp;
@@ -554,7 +554,7 @@ ais_half_kernel(const AisArgs A) {
                     d[5] = ev ? 1 : 0;
                 }
             };
-            // an error (src/types.jl:145-150) is sticky and reported after the launch; the
+            // an error (src/types.jl:69-70) is sticky and reported after the launch; the
             // remaining sub-steps still run (their result is discarded by the host), which
             // keeps the loop bounds wave-uniform
             if constexpr (kLate) {

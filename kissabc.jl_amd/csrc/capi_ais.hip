@@ -192,7 +192,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     }
     h->launch = fn;
     // BOX class: logpdf inside the box = c0_1 + ... + c0_D, summed left to right
-    // exactly as logpdf(d::Factored, x) does (src/priors.jl:275-281)
+    // exactly as logpdf(d::Factored, x) does (src/priors.jl:30-36)
     h->box_lp = h->prior.c[0].c0;
     for (int k = 1; k < h->D; ++k) h->box_lp += h->prior.c[k].c0;
     h->N = n_total;
@@ -285,11 +285,11 @@ static kabc_status_t read_counters(kabc_ais_t* h, DevCounters* c) {
 static kabc_status_t check_device_error(kabc_ais_t* h, const DevCounters& c) {
     (void)h;
     if (c.error == 1) {
-        set_error("ld_correction is invalid");  // src/types.jl:151
+        set_error("ld_correction is invalid");  // src/types.jl:69
         return KABC_ERR_INVALID_STATE;
     }
     if (c.error == 2) {
-        set_error("starting sample invalid.");  // src/types.jl:152
+        set_error("starting sample invalid.");  // src/types.jl:70
         return KABC_ERR_INVALID_STATE;
     }
     return KABC_OK;

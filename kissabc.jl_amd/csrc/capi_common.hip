@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(256) prior_logpdf_kernel(const PriorUtilArgs A
         if (A.mode == 1) {
             A.out[i * A.D + k] = v;
         } else {
-            // logpdf(Factored, x) is evaluated on x as given (src/priors.jl:275-281)
+            // logpdf(Factored, x) is evaluated on x as given (src/priors.jl:30-36)
             const double l = comp_logpdf(A.prior.c[k].kind, A.prior.c[k], xv);
             s = (k == 0) ? l : s + l;
         }

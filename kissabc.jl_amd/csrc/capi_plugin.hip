@@ -1,6 +1,6 @@
 // capi_plugin.hip -- run-time DeviceCost plugins.
 //
-// The reference accepts any Julia closure as `cost` (src/types.jl:124,137;
+// The reference accepts any Julia closure as `cost` (src/types.jl:42,55;
 // src/smc.jl:94).  The device path accepts any cost expressible as a C function
 //   double kabc_user_cost(const double* x, int D, const double* params,
 //                         const double* data, int64_t ndata, kabc_cost_rng_t* rng);

@@ -131,8 +131,8 @@ inline bool prior_is_simple(int kind) {
            kind == KABC_PRIOR_EXPONENTIAL;
 }
 
-// push_p (src/types.jl:109-114) followed by logpdf(d::Factored, x) = left-to-right
-// sum over components (src/priors.jl:275-281).  xp receives push_p(x).
+// push_p (src/types.jl:27-32) followed by logpdf(d::Factored, x) = left-to-right
+// sum over components (src/priors.jl:30-36).  xp receives push_p(x).
 // P: the prepared components (in LDS on the hot path).
 template <int D, bool SIMPLE = false>
 __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restrict__ P,

@@ -135,7 +135,7 @@ class LogNormal(UnivariateDistribution):
 
 
 class Factored:
-    """Factored(d1, d2, ...) -- src/priors.jl:255-258: a product of univariate
+    """Factored(d1, d2, ...) -- src/priors.jl:10-13: a product of univariate
     distributions with mixed continuous / discrete support."""
 
     def __init__(self, *components):
@@ -148,7 +148,7 @@ class Factored:
             raise ValueError(f"the device path supports length(prior) <= {cd.KABC_MAX_DIM}")
         self.p = tuple(components)
 
-    def __len__(self):  # length(p::Factored) = N, src/priors.jl:294
+    def __len__(self):  # length(p::Factored) = N, src/priors.jl:49
         return len(self.p)
 
     def __repr__(self):
@@ -174,7 +174,7 @@ class Factored:
         return a, single
 
     def logpdf(self, x, ctx=None):
-        """logpdf(d::Factored, x), src/priors.jl:275-281"""
+        """logpdf(d::Factored, x), src/priors.jl:30-36"""
         a, single = self._rows(x)
         out = np.empty(a.shape[0])
         ctx = ctx or _lib.default_context()
@@ -184,11 +184,11 @@ class Factored:
         return float(out[0]) if single else out
 
     def pdf(self, x, ctx=None):
-        """pdf(d::Factored, x), src/priors.jl:263-269"""
+        """pdf(d::Factored, x), src/priors.jl:18-24"""
         return np.exp(self.logpdf(x, ctx))
 
     def push_p(self, x, ctx=None):
-        """push_p(density::Factored, p), src/types.jl:111-114"""
+        """push_p(density::Factored, p), src/types.jl:29-32"""
         a, single = self._rows(x)
         out = np.empty_like(a)
         ctx = ctx or _lib.default_context()
@@ -198,7 +198,7 @@ class Factored:
         return out[0] if single else out
 
     def rand(self, n=None, seed=0, ctx=None):
-        """rand(rng, d::Factored), src/priors.jl:287-288 (n draws; stream `seed`)"""
+        """rand(rng, d::Factored), src/priors.jl:42-43 (n draws; stream `seed`)"""
         m = 1 if n is None else int(n)
         out = np.empty((m, len(self)))
         ctx = ctx or _lib.default_context()

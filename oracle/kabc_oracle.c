@@ -106,7 +106,7 @@ void orc_normal_pairs(int64_t n, const uint64_t* r, double* out) {
 }
 
 /* ------------------------------------------------------------------------- */
-/* Factored prior: logpdf / pdf / push_p  (src/priors.jl, src/types.jl:109-114) */
+/* Factored prior: logpdf / pdf / push_p  (src/priors.jl, src/types.jl:27-32) */
 /* ------------------------------------------------------------------------- */
 typedef struct prep {
     int32_t kind;
@@ -215,12 +215,12 @@ static double comp_logpdf(const prep_t* q, double x) {
 }
 
 /* push_p(density, p): continuous -> float(p), discrete -> round(Int, p)
- * (src/types.jl:111-114) */
+ * (src/types.jl:29-32) */
 static void push_p(const prep_t* q, int D, const double* x, double* out) {
     for (int k = 0; k < D; ++k) out[k] = q[k].discrete ? kabc_rint(x[k]) : x[k];
 }
 
-/* logpdf(d::Factored, x): s = logpdf(p[1],x[1]); for i=2:N s += ... (src/priors.jl:275-281) */
+/* logpdf(d::Factored, x): s = logpdf(p[1],x[1]); for i=2:N s += ... (src/priors.jl:30-36) */
 static double factored_logpdf(const prep_t* q, int D, const double* x) {
     double s = comp_logpdf(&q[0], x[0]);
     for (int k = 1; k < D; ++k) s += comp_logpdf(&q[k], x[k]);
@@ -242,7 +242,7 @@ int32_t orc_factored_logpdf(const kabc_prior_t* prior, int32_t D, int64_t n, con
     return KABC_OK;
 }
 
-/* pdf(d::Factored, x): product of component pdfs (src/priors.jl:263-269) */
+/* pdf(d::Factored, x): product of component pdfs (src/priors.jl:18-24) */
 int32_t orc_factored_pdf(const kabc_prior_t* prior, int32_t D, int64_t n, const double* x,
                          double* out) {
     prep_t q[KABC_MAX_DIM];
@@ -263,7 +263,7 @@ int32_t orc_push_p(const kabc_prior_t* prior, int32_t D, int64_t n, const double
 }
 
 /* rand(rng, Factored) = ntuple(i -> rand(rng, p[i])) then op(float, .)
- * (src/priors.jl:287-288, src/KissABC.jl:50) */
+ * (src/priors.jl:42-43, src/KissABC.jl:50) */
 static void factored_rand(const kabc_prior_t* prior, int D, uint64_t seed, uint32_t walker,
                           uint64_t attempt, uint32_t domain, double* out) {
     for (int k = 0; k < D; ++k) {
@@ -324,7 +324,7 @@ struct orc_ais {
     uint64_t seed;
     double* x;     /* [N][D] walker-id order (AISState.sample, src/KissABC.jl:27) */
     double* lp;    /* logprior */
-    double* ll;    /* loglikelihood (kernelized) or cost (threshold), src/types.jl:139,172 */
+    double* ll;    /* loglikelihood (kernelized) or cost (threshold), src/types.jl:57,90 */
     uint64_t* tc;  /* per-walker transition counter (serial schedule) */
     uint64_t t;    /* generation-synchronous counter */
     int64_t cursor; /* AISState.i (0-based), src/KissABC.jl:31 */
@@ -336,11 +336,11 @@ typedef struct ld {
     double lp, ll;
 } ld_t;
 
-/* loglike(density, sample): src/types.jl:133-140 (kernelized), :166-173 (threshold) */
+/* loglike(density, sample): src/types.jl:51-58 (kernelized), :84-91 (threshold) */
 static ld_t loglike(orc_ais_t* h, const double* xp, uint32_t walker, uint64_t t, uint32_t dom,
                     int* cost_evaluated) {
     ld_t r;
-    if (h->posterior == KABC_POSTERIOR_COMMON) { /* loglike = lπ(sample.x), src/types.jl:199-201 */
+    if (h->posterior == KABC_POSTERIOR_COMMON) { /* loglike = lπ(sample.x), src/types.jl:117-119 */
         r.lp = 0.0;
         r.ll = orc_cost_eval(&h->cost, h->D, xp, h->seed, walker, t, dom);
         *cost_evaluated = 1;
@@ -366,14 +366,14 @@ static ld_t loglike(orc_ais_t* h, const double* xp, uint32_t walker, uint64_t t,
     return r;
 }
 
-/* push_p(density, p): ABC posteriors project through the prior (src/types.jl:110),
- * a plain AbstractDensity (CommonLogDensity) is the identity (:109) */
+/* push_p(density, p): ABC posteriors project through the prior (src/types.jl:28),
+ * a plain AbstractDensity (CommonLogDensity) is the identity (:27) */
 static void model_push_p(const orc_ais_t* h, const double* x, double* out) {
     if (h->posterior == KABC_POSTERIOR_COMMON) memcpy(out, x, sizeof(double) * h->D);
     else push_p(h->q, h->D, x, out);
 }
 
-/* is_valid_logdensity: src/types.jl:142 (isfinite(sum(ld))), :175-176 */
+/* is_valid_logdensity: src/types.jl:60 (isfinite(sum(ld))), :93-94 */
 static int is_valid(const orc_ais_t* h, ld_t v) {
     if (h->posterior != KABC_POSTERIOR_THRESHOLD) return kabc_isfinite(v.lp + v.ll); /* :142, :203 */
     return kabc_isfinite(v.ll) && kabc_isfinite(v.lp);
@@ -566,7 +566,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
     h->st.proposals += 1;
     h->st.cost_evals += (uint64_t)ev;
 
-    /* accept(...) src/types.jl:144-157 / :178-186 */
+    /* accept(...) src/types.jl:62-75 / :96-104 */
     int acc = 0;
     if (!kabc_isfinite(corr)) return -1; /* "ld_correction is invalid" */
     if (!is_valid(h, old)) return -2;    /* "starting sample invalid." */
@@ -576,7 +576,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
             double lW = corr + (nw.lp + nw.ll) - (old.lp + old.ll);
             acc = (-e <= lW);
         } else if (h->posterior == KABC_POSTERIOR_COMMON) {
-            double lW = corr + nw.ll - old.ll; /* src/types.jl:209 */
+            double lW = corr + nw.ll - old.ll; /* src/types.jl:127 */
             acc = (-e <= lW);
         } else {
             double lW = corr + nw.lp - old.lp;

@@ -53,7 +53,7 @@ void orc_math_vec(int32_t fn, int64_t n, const double* x, double* out);
 void orc_normal_pairs(int64_t n, const uint64_t* r, double* out);
 void orc_div_rc_vec(int64_t n, const double* x, const double* c, double* out);
 
-/* Factored surface: src/priors.jl:263-294, src/types.jl:109-114 */
+/* Factored surface: src/priors.jl:18-49, src/types.jl:27-32 */
 int32_t orc_factored_logpdf(const kabc_prior_t* prior, int32_t D, int64_t n, const double* x,
                             double* out);
 int32_t orc_factored_pdf(const kabc_prior_t* prior, int32_t D, int64_t n, const double* x,

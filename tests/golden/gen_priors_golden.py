@@ -2,7 +2,7 @@
 """Generates tests/golden/priors_logpdf.json with scipy.stats.
 
 The reference evaluates prior densities through Distributions.jl
-(src/priors.jl:263-281), which is not in the reference tree and cannot run
+(src/priors.jl:18-36), which is not in the reference tree and cannot run
 here (no Julia).  These vectors pin our restatement of each family against an
 independent implementation (scipy 1.15).  Run: python tests/golden/gen_priors_golden.py
 """

@@ -119,7 +119,7 @@ def test_cdf_g_inv_closed_forms(orc):
 def test_div_rc_equals_ieee_division(orc):
     """kabc_div_rc(x, c, RN(1/c)) (Markstein: 1 mul + 2 fma) must equal the correctly
     rounded IEEE quotient x / c: the contract uses it for `/ 300`, `/ 3`
-    (src/transition.jl:13,35), `cost / scale` (src/types.jl:137) and (x - mu) / sigma."""
+    (src/transition.jl:13,35), `cost / scale` (src/types.jl:55) and (x - mu) / sigma."""
     n = 4_000_000
     x = np.ldexp(rng.random(n) + 0.5, rng.integers(-300, 300, n)) * rng.choice([-1.0, 1.0], n)
     for c in (3.0, 300.0, 0.1, 0.005, 0.001, 1.0, 5.0, 0.2, 0.5, 0.01 / np.sqrt(2), 12.0):

@@ -144,7 +144,7 @@ def test_readme_example_c1(orc, k):
 
 
 def test_set_state_invalid_start_is_an_error(orc, k):
-    # src/types.jl:152 "starting sample invalid."
+    # src/types.jl:70 "starting sample invalid."
     o = orc.OracleAIS(_c2(k), 16, seed=1).init()
     x, lp, ll, _ = o.state()
     lp[3] = -np.inf

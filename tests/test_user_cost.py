@@ -1,5 +1,5 @@
 """User DeviceCosts compiled at run time (kabc_register_cost_plugin): the
-device-path counterpart of "cost is an arbitrary closure" (src/types.jl:124,137)."""
+device-path counterpart of "cost is an arbitrary closure" (src/types.jl:42,55)."""
 import os
 
 import numpy as np
@@ -104,7 +104,7 @@ def test_user_stochastic_simulator_bit_exact_vs_oracle(k, orc, gpu_ctx):
     assert np.array_equal(r.info["theta_all"], o["theta_all"]) and r.eps == o["eps"]
 
 
-# ---- CommonLogDensity (src/types.jl:187-210) with user log-densities ---------------
+# ---- CommonLogDensity (src/types.jl:105-128) with user log-densities ---------------
 BANANA_LPI = """
 KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
                               const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
