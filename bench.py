@@ -3,24 +3,36 @@
 
 Workload (BASELINE.json configs[2]): AIS, 65 536 walkers per GPU,
 D = 8, prior Factored(Uniform(-5,5))^8, cost sqrt(sum 100(x[k+1]-x[k]^2)^2 +
-(1-x[k])^2), ApproxKernelizedPosterior scale 1.0, seed 1, ntransitions = 100 -- the
-value the reference itself samples with (README.md:57, four of the AIS testsets of
-test/runtests.jl; BASELINE.json configs[0]); SURVEY §8d's ntransitions = 16 is timed
-in the same run and reported beside it as `also_at_ntransitions_16`.
+(1-x[k])^2), ApproxKernelizedPosterior scale 1.0, seed 1.
 A "step" is one GENERATION: every walker receives `ntransitions` transition!()
 calls (two half-generation kernel launches per GPU; for N>1 one RCCL all-gather
-after each, i.e. the exchange is amortised over ntransitions sub-steps exactly as
-the reference amortises its per-sample overhead).  Weak scaling: per-GPU walkers are
-fixed, N_total = 65 536 * gpus.
+after each, issued by the library itself -- include/kabc.h "multi-GPU" -- so this
+script needs neither torch nor torch.distributed).  Weak scaling: per-GPU walkers
+are fixed, N_total = 65 536 * gpus.
+
+`ntransitions`: SURVEY §8d prescribes {1, 16}; the reference's own examples sample
+with 100 (README.md:57, BASELINE.json configs[0]).  All three are timed in every
+run and reported under `by_ntransitions`; the headline (`value`, `roofline`) is the
+one --ntransitions selects (default 100) and says so in `config`.
+
+Timed region: W warm-up steps, then blocks of EXACTLY K steps, each block bracketed
+by a barrier + stream synchronisation on both sides; blocks are repeated until at
+least --min-seconds of device work has been timed (so that an external sampler sees
+the GPU busy); `ms_per_step` is the mean over all timed steps.
 
 Prints ONE JSON line (rank 0).  `roofline` is for the half-generation kernel:
-algorithmic bytes per launch = rows * ntransitions * 8(3D+4)
-over the kernel's average duration measured with hipEvents on its stream over
-the timed region.  `cpu_baseline` times the CPU oracle's faithful serial
-restatement of the reference on a bounded sample of the same workload.
+algorithmic bytes per launch = rows * ntransitions * 8(3D+4) over the
+kernel's average duration measured with hipEvents on its stream over the timed
+region; `roofline.valu` is the second, binding resource: VALU wave-instructions per
+launch (committed PMC summary, profiles/) x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel
+time).  `smc_c4` times BASELINE.json configs[3] (smc, 32 768 particles, D = 16) the
+same way.  `cpu_baseline` times the CPU oracle's faithful serial restatement of the
+reference on a bounded sample of the same workloads.
 """
 import argparse
+import glob
 import json
+import math
 import os
 import sys
 import time
@@ -28,18 +40,33 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# this host never imports torch: keep the process on the system ROCm runtime alone
+os.environ.setdefault("KABC_NO_TORCH_PRELOAD", "1")
 
 WALKERS_PER_GPU = 65536
 D = 8
-NT = 100
-NT_ALT = 16
+NT_SET = (1, 16, 100)
+NT_HEADLINE = 100
 SEED = 1
-HBM_PEAK_GBS = 8000.0  # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0   # MI355X spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+SIMDS = 1024            # 256 CUs x 4
+CLOCK_HZ = 2.4e9        # max engine clock, same guide
+SMC_N, SMC_D = 32768, 16
 
 
 def build_model(k):
     prior = k.Factored(*[k.Uniform(-5, 5)] * D)
     return k.ApproxKernelizedPosterior(prior, k.costs.Rosenbrock(), 1.0)
+
+
+def c4_problem(k):
+    """theta = (m, s, z_1..z_14), sim ybar_g = m + s z_g + randn/sqrt(8)."""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    zstar = rng.normal(size=14)
+    ybar = 1.0 + 0.5 * zstar + rng.normal(size=14) / np.sqrt(8)
+    prior = k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 14)
+    return prior, k.costs.HierGaussSim(ybar), dict(nparticles=SMC_N, alpha=0.95, epstol=0.05, seed=1)
 
 
 def _cpu_chain(args):
@@ -48,27 +75,28 @@ def _cpu_chain(args):
     import kissabc_jl_amd as k
     from oracle import oracle as orc
     o = orc.OracleAIS(build_model(k), nwalkers, seed=seed).init()
-    o.steps_serial(1024, NT, collect=False)  # warm-up
+    o.steps_serial(1024, NT_HEADLINE, collect=False)  # warm-up
     nsteps, done, t0 = 4096, 0, time.perf_counter()
     while True:
-        o.steps_serial(nsteps, NT, collect=False)
+        o.steps_serial(nsteps, NT_HEADLINE, collect=False)
         done += nsteps
         el = time.perf_counter() - t0
         if el > budget_s:
             return done, el
 
 
-def cpu_baseline(k, budget_s):
+def cpu_baseline(k, budget_s, with_smc):
     """Oracle, serial reference schedule (src/KissABC.jl:66-80), same model, bounded
     sample: (i) 1 core, N = 65 536 walkers, as many step() calls as fit the budget;
-    (ii) all host cores as independent chains of N/cores walkers each."""
+    (ii) all host cores as independent chains of N/cores walkers each; (iii) the smc
+    restatement (src/smc.jl:92-206) on C4, one full run on 1 core."""
     import multiprocessing as mp
     done, el = _cpu_chain((WALKERS_PER_GPU, SEED, budget_s))
     out = {
-        "value": done * NT / el, "unit": "evals/s", "cores": 1, "kind": "port",
+        "value": done * NT_HEADLINE / el, "unit": "evals/s", "cores": 1, "kind": "port",
         "sample": f"oracle ref_serial (C restatement of src/transition.jl + src/KissABC.jl:66-80), "
-                  f"N={WALKERS_PER_GPU} D={D} rosenbrock, {done} step() calls x ntransitions={NT} "
-                  f"in {el:.1f}s on 1 host core",
+                  f"N={WALKERS_PER_GPU} D={D} rosenbrock, {done} step() calls x "
+                  f"ntransitions={NT_HEADLINE} in {el:.1f}s on 1 host core",
     }
     try:
         cores = len(os.sched_getaffinity(0))
@@ -77,12 +105,38 @@ def cpu_baseline(k, budget_s):
             with mp.get_context("spawn").Pool(cores) as pool:
                 res = pool.map(_cpu_chain, [(per, SEED + 1 + c, budget_s / 2) for c in range(cores)])
             out["all_cores"] = {
-                "value": sum(d * NT / e for d, e in res), "cores": cores, "unit": "evals/s",
+                "value": sum(d * NT_HEADLINE / e for d, e in res), "cores": cores, "unit": "evals/s",
                 "sample": f"{cores} independent chains of {per} walkers (MCMCThreads analogue), "
                           f"{budget_s / 2:.0f}s each"}
     except Exception as e:  # the baseline is informational; never fail the bench on it
         out["all_cores"] = {"error": repr(e)}
+    if with_smc:
+        try:
+            from oracle import oracle as orc
+            prior, cost, kw = c4_problem(k)
+            t0 = time.perf_counter()
+            ro = orc.smc(prior, cost, **kw)
+            w = time.perf_counter() - t0
+            out["smc_c4"] = {"wall_s": w, "particle_updates_per_s": ro["proposals"] / w,
+                             "iterations": ro["iterations"], "eps": ro["eps"], "cores": 1,
+                             "kind": "port",
+                             "sample": "oracle smc (C restatement of src/smc.jl:92-206), one full "
+                                       "C4 run on 1 host core"}
+        except Exception as e:
+            out["smc_c4"] = {"error": repr(e)}
     return out
+
+
+def _pmc_table():
+    """VALU wave-instructions per half-generation launch from the newest committed PMC
+    summary (profiles/r*_pmc_insts.json: {"<nt>": {"SQ_INSTS_VALU": per-launch mean, ...}})."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_insts.json")))
+    if not files:
+        return None, {}
+    try:
+        return os.path.basename(files[-1]), json.load(open(files[-1]))
+    except Exception:
+        return None, {}
 
 
 def main():
@@ -90,17 +144,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--ntransitions", type=int, default=NT)
+    ap.add_argument("--ntransitions", type=int, default=NT_HEADLINE,
+                    help="the setting the headline value is quoted on")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the K-step block until this much has been timed (per setting)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true",
-                    help="skip the secondary ntransitions=16 region (clean rocprof summaries)")
+                    help="time the headline ntransitions only (clean rocprof summaries)")
+    ap.add_argument("--no-smc", action="store_true", help="skip the C4 smc leg")
     args = ap.parse_args()
-    nt = args.ntransitions
+    nt_head = args.ntransitions
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N "
+                         "bench.py --gpus N` (one process per GPU; the ranks find each other "
+                         "through RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)")
 
     # The CPU baseline runs FIRST, before this process touches the GPU: its all-core
     # leg spawns worker processes, and a process that has initialised HIP must not
@@ -108,74 +170,97 @@ def main():
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
         import kissabc_jl_amd as k0
-        cpu = cpu_baseline(k0, args.cpu_seconds)
-
-    import torch
-    import torch.distributed as dist
+        cpu = cpu_baseline(k0, args.cpu_seconds, with_smc=not args.no_smc)
 
     import kissabc_jl_amd as k
-    from kissabc_jl_amd.sharded import ShardedAIS
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    # dry-run knobs (tests/test_gpu_bench_two_ranks.py): all ranks on one device, exchange
-    # over gloo through host memory -- exercises this script's N > 1 branch on a 1-GPU box
-    backend = os.environ.get("KABC_BENCH_BACKEND", "nccl")
-    if os.environ.get("KABC_BENCH_DEVICE") is not None:
-        local_rank = int(os.environ["KABC_BENCH_DEVICE"])
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_pg = world > 1 or os.environ.get("KABC_FORCE_COLLECTIVE") == "1"
-    if use_pg:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    from kissabc_jl_amd.comm import Comm
+
+    dev = int(os.environ.get("KABC_BENCH_DEVICE", local_rank))
+    use_comm = world > 1 or os.environ.get("KABC_FORCE_COLLECTIVE") == "1"
+    comm = Comm.from_env(device=dev) if use_comm else None
+    ctx = comm.ctx if comm else k.Context(dev)
 
     model = build_model(k)
     n_total = WALKERS_PER_GPU * world
-    sh = ShardedAIS(model, n_total, seed=SEED, device=dev).init()
-    ens = sh.engine.ens
+    ens = k.AisEnsemble(model, n_total, seed=SEED, ctx=ctx, comm=comm).init()
 
     def sync():
-        torch.cuda.synchronize(dev)
-        if use_pg:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        ctx.synchronize()
+        if comm:
+            comm.barrier()   # an all-reduce over the ranks + a stream synchronisation
+            ctx.synchronize()
+
+    def global_stats():
+        st = ens.stats()
+        v = [st["proposals"], st["cost_evals"], st["accepted"]]
+        if comm:
+            v = comm.allreduce_sum(v)
+        return dict(zip(("proposals", "cost_evals", "accepted"), v))
 
     def timed_region(nt_r, steps, warm):
-        for _ in range(warm):
-            sh.generation(nt_r)
+        ens.advance(warm, nt_r)
         sync()
-        s0 = sh.global_stats()
+        t0 = time.perf_counter()   # calibration block (not reported): how long K steps take
+        ens.advance(steps, nt_r)
+        sync()
+        blocks = max(1, int(math.ceil(args.min_seconds / max(time.perf_counter() - t0, 1e-9))))
+        if comm:   # every rank must run the same number of blocks
+            blocks = int(comm.allreduce_max([float(blocks)])[0])
+        s0 = global_stats()
         # hipEvent pairs on the kernel's stream, one pair per 8 consecutive half-generation
         # launches (a pair per launch adds ~3 us of marker overhead to every figure); with
         # collectives between the launches each launch gets its own pair instead
-        ens.set_timing(2 * steps, stride=1 if use_pg else 8)
-        sync()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            sh.generation(nt_r)
-        sync()
-        el_r = time.perf_counter() - t0
+        ens.set_timing(min(2 * steps * blocks, 8192), stride=1 if comm else 8)
+        el_r = 0.0
+        for _ in range(blocks):
+            sync()
+            t0 = time.perf_counter()
+            ens.advance(steps, nt_r)
+            sync()
+            el_r += time.perf_counter() - t0
         kms_r, nl_r = ens.kernel_ms()
         ens.set_timing(0)
-        s1 = sh.global_stats()
-        tmax = torch.tensor([el_r], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        if use_pg:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        return float(tmax.item()), kms_r, nl_r, s0, s1
+        s1 = global_stats()
+        if comm:
+            el_r = comm.allreduce_max([el_r])[0]
+        return {"el": el_r, "kms": kms_r, "nl": nl_r, "blocks": blocks, "steps": steps,
+                "proposals": s1["proposals"] - s0["proposals"],
+                "cost_evals": s1["cost_evals"] - s0["cost_evals"],
+                "accepted": s1["accepted"] - s0["accepted"]}
 
-    el, kms, nl, st0, st1 = timed_region(nt, args.steps, args.warmup)
-    # secondary figure at SURVEY §8d's ntransitions = 16 (launch prologue, tail and -- for
-    # N > 1 -- the exchange weigh 6x more per evaluation); reported beside the headline
-    alt = None
-    if nt != NT_ALT and not args.no_alt:
-        k2 = max(20, args.steps)
-        el2, kms2, nl2, a0, a1 = timed_region(NT_ALT, k2, 5)
-        alt = (el2, kms2, nl2, a1["proposals"] - a0["proposals"], k2)
+    settings = [nt_head] if args.no_alt else sorted(set(NT_SET) | {nt_head})
+    regions = {}
+    for nt_r in settings:
+        # the same K everywhere would make the nt = 1 block 100x shorter; the block count
+        # (min-seconds) evens the timed duration out instead
+        regions[nt_r] = timed_region(nt_r, args.steps, args.warmup if nt_r == nt_head else 5)
+
+    smc = None
+    if world == 1 and not args.no_smc:
+        prior, cost, kw = c4_problem(k)
+        k.smc(prior, cost, ctx=ctx, **kw)   # warm-up (module load, allocations)
+        walls, r = [], None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            r = k.smc(prior, cost, ctx=ctx, return_array=True, **kw)
+            walls.append(time.perf_counter() - t0)
+        w = sorted(walls)[len(walls) // 2]
+        Bs = 32 * SMC_D + 33
+        ups = r.info["proposals"] / w
+        smc = {"workload": "smc C4: 32768 particles x 16-param hierarchical Gaussian sim, "
+                           "alpha=0.95 epstol=0.05 seed=1 (BASELINE.json configs[3])",
+               "wall_ms": w * 1e3, "wall_ms_all": [x * 1e3 for x in walls],
+               "iterations": r.info["iterations"], "eps": r.eps,
+               "particle_updates": r.info["proposals"], "particle_updates_per_s": ups,
+               "cost_evals": r.info["cost_evals"],
+               "roofline": {"bound": "hbm", "bytes_per_update": Bs,
+                            "achieved": ups * Bs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": ups * Bs / 1e9 / HBM_PEAK_GBS,
+                            "note": "end to end (select + propose/accept + control), wall clock"},
+               "mcmc_kernel_avg_ms": r.info["kernel_ms_mcmc"]}
+        if cpu and isinstance(cpu.get("smc_c4"), dict) and "wall_s" in cpu["smc_c4"]:
+            smc["cpu_baseline"] = cpu["smc_c4"]
+            smc["vs_cpu_port_1core"] = cpu["smc_c4"]["wall_s"] / w
 
     # RCCL prints a version banner to the C stdout of every rank when its communicator
     # comes up; push it out now so that the JSON below is the LAST line of the job
@@ -185,56 +270,83 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    if use_pg:
-        dist.barrier()
+    if comm:
+        comm.barrier()
     if rank == 0:
-        proposals = st1["proposals"] - st0["proposals"]
-        cost_evals = st1["cost_evals"] - st0["cost_evals"]
-        assert proposals == n_total * nt * args.steps, (proposals, n_total * nt * args.steps)
         bytes_per_eval = 8 * (3 * D + 4)
         rows = WALKERS_PER_GPU // 2
-        alg_bytes_launch = rows * nt * bytes_per_eval
-        achieved = alg_bytes_launch / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        pmc_file, pmc = _pmc_table()
+
+        def summarise(nt_r, reg):
+            assert reg["proposals"] == n_total * nt_r * reg["steps"] * reg["blocks"], reg
+            alg = rows * nt_r * bytes_per_eval
+            kms = reg["kms"]
+            ach = alg / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+            valu = None
+            vi = (pmc.get(str(nt_r)) or {}).get("SQ_INSTS_VALU")
+            if vi and kms > 0:
+                valu = vi * 4.0 / (SIMDS * CLOCK_HZ * kms * 1e-3)
+            return {"value": reg["proposals"] / reg["el"], "unit": "evals/s",
+                    "steps": reg["steps"], "blocks": reg["blocks"], "timed_s": reg["el"],
+                    "ms_per_step": reg["el"] / (reg["steps"] * reg["blocks"]) * 1e3,
+                    "kernel_avg_us": kms * 1e3, "kernel_launches_timed": reg["nl"],
+                    "algorithmic_bytes_per_launch": alg, "roofline_achieved_GBps": ach,
+                    "roofline_frac": ach / HBM_PEAK_GBS, "valu_frac": valu,
+                    "valu_wave_insts_per_launch": vi,
+                    "cost_evals_per_s": reg["cost_evals"] / reg["el"],
+                    "accept_rate": reg["accepted"] / max(1, reg["proposals"])}
+
+        by_nt = {str(nt_r): summarise(nt_r, reg) for nt_r, reg in regions.items()}
+        h = by_nt[str(nt_head)]
         # HBM bytes per launch from PMC counters are collected in separate rocprofv3
         # passes (FETCH_SIZE / WRITE_SIZE cannot share a pass); the committed summary
         # of that run is reported here when it was taken on this very workload.
         traffic = None
-        tf = os.path.join(ROOT, "profiles", f"r01_pmc_traffic_nt{nt}.json")
-        if os.path.exists(tf):
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_nt{nt_head}.json"))):
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
         out = {
             "metric": "walker proposal+cost evals/sec at N=65536 walkers, D=8",
-            "value": proposals / el, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "value": h["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": h["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "AIS C3: 65536 walkers/GPU x 8-param Rosenbrock-like cost, "
                                    "Uniform(-5,5)^8 prior, kernelized scale 1.0",
                        "walkers_per_gpu": WALKERS_PER_GPU, "walkers_total": n_total, "D": D,
-                       "ntransitions": nt, "evals_per_step": n_total * nt, "seed": SEED,
-                       "parallelism": f"walker-sharded x{world}, 1 all-gather per half-generation"
+                       "ntransitions": nt_head,
+                       "ntransitions_note": "headline = the reference's own setting (README.md:57, "
+                                            "BASELINE.json configs[0]); SURVEY 8d's {1, 16} are "
+                                            "under by_ntransitions",
+                       "evals_per_step": n_total * nt_head, "seed": SEED,
+                       "timed_blocks": h["blocks"], "timed_seconds": h["timed_s"],
+                       "parallelism": f"walker-sharded x{world}, 1 RCCL all-gather per "
+                                      f"half-generation issued by libkabc_hip (no torch.distributed)"
                        if world > 1 else "single GPU"},
-            "cost_evals_per_s": cost_evals / el,
-            "accept_rate": (st1["accepted"] - st0["accepted"]) / max(1, proposals),
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "ais_half_kernel<8, rosenbrock>",
-                         "kernel_avg_ms": kms, "kernel_launches_timed": nl,
-                         "algorithmic_bytes_per_launch": alg_bytes_launch},
+            "cost_evals_per_s": h["cost_evals_per_s"], "accept_rate": h["accept_rate"],
+            "roofline": {"bound": "hbm", "achieved": h["roofline_achieved_GBps"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h["roofline_frac"],
+                         "traffic": traffic,
+                         "kernel": "ais_half_kernel<8, rosenbrock, BOX, kernelized>",
+                         "kernel_avg_ms": h["kernel_avg_us"] / 1e3,
+                         "kernel_launches_timed": h["kernel_launches_timed"],
+                         "algorithmic_bytes_per_launch": h["algorithmic_bytes_per_launch"],
+                         "valu": {"frac": h["valu_frac"],
+                                  "wave_insts_per_launch": h["valu_wave_insts_per_launch"],
+                                  "formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x "
+                                             "kernel time): the binding resource (state is "
+                                             "register-resident, HBM traffic is ~3 % of the "
+                                             "algorithmic bytes)",
+                                  "source": pmc_file}},
+            "by_ntransitions": by_nt,
         }
-        if alt is not None:
-            el2, kms2, nl2, prop2, k2 = alt
-            ach2 = rows * NT_ALT * bytes_per_eval / (kms2 * 1e-3) / 1e9 if kms2 > 0 else 0.0
-            out[f"also_at_ntransitions_{NT_ALT}"] = {
-                "value": prop2 / el2, "unit": "evals/s", "steps": k2, "ms_per_step": el2 / k2 * 1e3,
-                "kernel_avg_ms": kms2, "roofline_achieved_GBps": ach2,
-                "roofline_frac": ach2 / HBM_PEAK_GBS,
-                "why": "SURVEY 8d times C3 at ntransitions = 16 as well"}
+        if smc is not None:
+            out["smc_c4"] = smc
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if use_pg:
-        dist.destroy_process_group()
+    ens.close()
+    if comm:
+        comm.close()
 
 
 if __name__ == "__main__":

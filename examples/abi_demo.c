@@ -10,6 +10,8 @@
  *    with cost = ||x - (1, -0.5)||: the posterior is Gaussian with mean c * 2500/2501
  *     -- prints the sample mean.
  * 2. smc(prior, cost; nparticles = 2000, alpha = 0.9, epstol = 0.05) on the same cost.
+ * 3. the same AIS ensemble sharded over two ranks driven from this one process
+ *    (kabc_comm_init_all + kabc_ais_create_dist + kabc_ais_*_multi).
  * Prints one line of key=value pairs; tests/test_gpu_abi_demo.py compares it with the
  * Python mirror's result for the same seeds (bit-identical). */
 #include <stdio.h>
@@ -90,9 +92,41 @@ int main(void) {
     double s0 = 0.0;
     for (int i = 0; i < 2000; ++i) s0 += r.theta[2 * i];
 
-    printf("version=%d proposals=%llu accepted=%llu mean0=%.17g mean1=%.17g last0=%.17g last1=%.17g "
+    /* ---- walker-sharded AIS: two ranks in ONE process (here both on device 0, exchange by
+     * the P2P pull kernel; with dev = {0, 1} and KABC_COMM_RCCL the same calls drive two
+     * GPUs over RCCL).  The sharded trajectory equals the single-handle one bit for bit. */
+    int sharded_equal = 0;
+    {
+        const int32_t devs[2] = {0, 0};
+        kabc_ctx_t* cx[2];
+        kabc_comm_t* cm[2];
+        kabc_ais_t* sh[2];
+        kabc_ais_t* one = NULL;
+        kabc_stats_t st2;
+        double* xa = (double*)malloc(sizeof(double) * (size_t)N * 2);
+        double* xb = (double*)malloc(sizeof(double) * (size_t)N * 2);
+        memset(&st2, 0, sizeof st2);
+        CHECK(kabc_comm_init_all(2, devs, KABC_COMM_P2P, cx, cm));
+        for (int rk = 0; rk < 2; ++rk) CHECK(kabc_ais_create_dist(cm[rk], &model, N, 7u, &sh[rk]));
+        CHECK(kabc_ais_init_multi(sh, 2, 100));
+        CHECK(kabc_ais_advance_multi(sh, 2, 50, 3, &st2));
+        CHECK(kabc_ais_get_ensemble(sh[1], xa));
+        CHECK(kabc_ais_create(ctx, &model, N, 7u, &one));
+        CHECK(kabc_ais_init(one, 100));
+        CHECK(kabc_ais_advance(one, 50, 3, NULL, NULL));
+        CHECK(kabc_ais_get_ensemble(one, xb));
+        sharded_equal = memcmp(xa, xb, sizeof(double) * (size_t)N * 2) == 0 &&
+                        st2.proposals == (uint64_t)N * 150u;
+        CHECK(kabc_ais_destroy(one));
+        for (int rk = 0; rk < 2; ++rk) CHECK(kabc_ais_destroy(sh[rk]));
+        for (int rk = 0; rk < 2; ++rk) CHECK(kabc_comm_destroy(cm[rk]));
+        free(xa);
+        free(xb);
+    }
+
+    printf("version=%d sharded_equal=%d proposals=%llu accepted=%llu mean0=%.17g mean1=%.17g last0=%.17g last1=%.17g "
            "smc_eps=%.17g smc_iterations=%lld smc_alive=%lld smc_sum0=%.17g\n",
-           (int)kabc_version(), (unsigned long long)stats.proposals,
+           (int)kabc_version(), sharded_equal, (unsigned long long)stats.proposals,
            (unsigned long long)stats.accepted, m0, m1, last0, last1, r.eps,
            (long long)r.iterations, (long long)r.n_alive, s0);
     free(r.theta);

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KABC_VERSION 101 /* 0.1.1 */
+#define KABC_VERSION 200 /* 0.2.0 */
 #define KABC_MAX_DIM 16  /* compile-time upper bound on length(prior) on the device path */
 
 typedef enum kabc_status {
@@ -236,6 +236,76 @@ kabc_status_t kabc_ais_set_debug(kabc_ais_t* h, int32_t ntransitions);
 kabc_status_t kabc_ais_get_debug(kabc_ais_t* h, int32_t* out, int64_t n_int32);
 kabc_status_t kabc_ais_destroy(kabc_ais_t* h);
 
+/* ---- multi-GPU: walker-sharded AIS with ONE all-gather per half-generation ----------
+ *
+ * The reference has no device-to-device path: its only parallel legs are independent
+ * chains (MCMCThreads / MCMCDistributed, src/KissABC.jl:9,108-109,175) and the threaded
+ * cost loop of smc (src/smc.jl:120-123,168).  What follows is therefore new API, shaped
+ * after the north star: the host (Julia `ccall`, C, Python ctypes) owns process
+ * placement; the LIBRARY owns the collective -- RCCL (ncclAllGather over xGMI) loaded
+ * from librccl.so at first use, issued on the context stream right behind the kernels.
+ *
+ * Walkers shard by row range: rank r owns rows [r*per_h, min((r+1)*per_h, rows_h)) of
+ * each half, per_h = ceil(rows_h / world).  A half-generation needs no communication
+ * (partners come from the frozen complementary half, which every rank holds in full);
+ * afterwards the freshly updated rows are all-gathered in place so that the next
+ * half-generation can draw partners from them.  Draws are keyed by GLOBAL walker id:
+ * the trajectory is bit-identical for every world size.  Log-densities never travel.
+ *
+ * Two ways to form the communicator:
+ *   one process per GPU   kabc_comm_unique_id on rank 0 -> the host ships the 128 bytes
+ *                         to the other ranks (Julia: Distributed/MPI.bcast, a file, a
+ *                         socket) -> kabc_comm_init_rank everywhere (ncclCommInitRank)
+ *   one process, n GPUs   kabc_comm_init_all: n contexts + n communicators at once
+ *                         (ncclCommInitAll), driven with the *_multi entry points
+ *                         (ncclGroupStart/End around the n all-gathers).
+ * KABC_COMM_P2P (kabc_comm_init_all only) replaces RCCL by a pull kernel: every GPU
+ * reads the peers' fresh rows straight over its xGMI links (peer-mapped pointers, all
+ * links busy at once, one launch per half-generation).  It accepts repeated device ids,
+ * which is how the test-suite runs 8 ranks on a 1-GPU box. */
+typedef struct kabc_comm kabc_comm_t;
+#define KABC_COMM_ID_BYTES 128
+#define KABC_COMM_MAX_WORLD 16
+typedef enum kabc_comm_backend {
+    KABC_COMM_RCCL = 1,
+    KABC_COMM_P2P = 2
+} kabc_comm_backend_t;
+
+kabc_status_t kabc_comm_unique_id(uint8_t id[KABC_COMM_ID_BYTES]);
+/* collective over all ranks; ctx selects the GPU and the stream the collectives run on */
+kabc_status_t kabc_comm_init_rank(kabc_ctx_t* ctx, const uint8_t id[KABC_COMM_ID_BYTES],
+                                  int32_t rank, int32_t world, kabc_comm_t** out);
+/* single process: ctxs[ndev] and comms[ndev] receive one context (private stream) and
+ * one communicator per entry of dev_ids */
+kabc_status_t kabc_comm_init_all(int32_t ndev, const int32_t* dev_ids, int32_t backend,
+                                 kabc_ctx_t** ctxs, kabc_comm_t** comms);
+int32_t kabc_comm_rank(const kabc_comm_t* c);
+int32_t kabc_comm_world(const kabc_comm_t* c);
+kabc_ctx_t* kabc_comm_ctx(const kabc_comm_t* c);
+/* host-value reductions over the ranks (blocking; RCCL communicators of the
+ * one-process-per-GPU kind): used for counters, wall-clock maxima and as a barrier */
+kabc_status_t kabc_comm_allreduce_sum_u64(kabc_comm_t* c, uint64_t* inout, int32_t n);
+kabc_status_t kabc_comm_allreduce_max_f64(kabc_comm_t* c, double* inout, int32_t n);
+kabc_status_t kabc_comm_barrier(kabc_comm_t* c);
+/* destroys the communicator (and the context when kabc_comm_init_all created it) */
+kabc_status_t kabc_comm_destroy(kabc_comm_t* c);
+
+/* AIS(nparticles) sharded over the communicator's ranks; the library owns the (padded)
+ * global half buffers.  Any nparticles >= length(model)+5 is accepted (shards may be
+ * uneven or empty).  kabc_ais_init then also gathers both halves, and kabc_ais_advance
+ * issues the all-gather after every half-generation (out_samples must be NULL: the
+ * trace of a sharded ensemble is read with kabc_ais_get_ensemble). */
+kabc_status_t kabc_ais_create_dist(kabc_comm_t* comm, const kabc_model_t* model,
+                                   int64_t nparticles, uint64_t seed, kabc_ais_t** out);
+/* the whole ensemble as this rank sees it after the last all-gather: x[N][D], walker-id
+ * order, push_p NOT applied (identical on every rank) */
+kabc_status_t kabc_ais_get_ensemble(kabc_ais_t* h, double* x);
+/* single-process drivers for the n handles created on the n communicators of one
+ * kabc_comm_init_all call (hs[i] on comms[i], every rank present exactly once) */
+kabc_status_t kabc_ais_init_multi(kabc_ais_t** hs, int32_t n, int32_t retry_sampling);
+kabc_status_t kabc_ais_advance_multi(kabc_ais_t** hs, int32_t n, int64_t ngenerations,
+                                     int32_t ntransitions, kabc_stats_t* stats);
+
 /* ---- smc(prior, cost; kwargs...) -- src/smc.jl:92-206 -------------------- */
 typedef struct kabc_smc_opts {
     int64_t nparticles;  /* 100   */
@@ -321,7 +391,7 @@ typedef struct kabc_pfilter_opts {
     double eff_tol;         /* 0.1   */
     double epstol;          /* -Inf  */
     double proposal_width;  /* 0.75  */
-    int64_t max_iters;      /* Inf -> pass <= 0 for "no limit" */
+    int64_t max_iters;      /* Inf -> pass -1 (any negative); 0 stops after the first iteration */
     int32_t verbose;
     int32_t reserved;
     uint64_t seed;

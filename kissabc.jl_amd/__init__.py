@@ -10,6 +10,8 @@ from ._lib import Context, KabcError, LIB_PATH, default_context
 from .api import (ABCDE, AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity,
                   MCMCThreads, pfilter,
                   Particles, sample, smc)
+from . import comm
+from .comm import Comm, EnsembleGroup
 from .costs import DeviceCost
 from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, LogNormal,
                             NegativeBinomial, Normal, Truncated, TruncatedNormal, Uniform,
@@ -21,5 +23,5 @@ __all__ = [
     "Particles", "sample", "smc", "DeviceCost", "costs", "Factored", "Uniform", "Normal",
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
     "Exponential", "Gamma", "LogNormal", "Context", "KabcError", "default_context", "LIB_PATH",
-    "KABC_MAX_DIM",
+    "KABC_MAX_DIM", "comm", "Comm", "EnsembleGroup",
 ]

@@ -6,7 +6,10 @@ oracle's test binding (oracle/oracle.py).  Nothing here computes anything.
 import ctypes as C
 
 KABC_MAX_DIM = 16
-KABC_VERSION = 101   # include/kabc.h
+KABC_VERSION = 200   # include/kabc.h
+KABC_COMM_ID_BYTES = 128
+KABC_COMM_MAX_WORLD = 16
+COMM_RCCL, COMM_P2P = 1, 2
 
 # kabc_status_t
 KABC_OK, KABC_ERR_INVALID_ARG, KABC_ERR_RETRY_EXHAUSTED, KABC_ERR_INVALID_STATE, \
@@ -129,6 +132,24 @@ PROTOTYPES = {
     "kabc_ais_set_debug": (C.c_int, [VP, C.c_int32]),
     "kabc_ais_get_debug": (C.c_int, [VP, C.POINTER(C.c_int32), C.c_int64]),
     "kabc_ais_destroy": (C.c_int, [VP]),
+    "kabc_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "kabc_comm_init_rank": (C.c_int, [VP, C.POINTER(C.c_uint8), C.c_int32, C.c_int32,
+                                      C.POINTER(VP)]),
+    "kabc_comm_init_all": (C.c_int, [C.c_int32, C.POINTER(C.c_int32), C.c_int32, C.POINTER(VP),
+                                     C.POINTER(VP)]),
+    "kabc_comm_rank": (C.c_int32, [VP]),
+    "kabc_comm_world": (C.c_int32, [VP]),
+    "kabc_comm_ctx": (VP, [VP]),
+    "kabc_comm_allreduce_sum_u64": (C.c_int, [VP, C.POINTER(C.c_uint64), C.c_int32]),
+    "kabc_comm_allreduce_max_f64": (C.c_int, [VP, c_double_p, C.c_int32]),
+    "kabc_comm_barrier": (C.c_int, [VP]),
+    "kabc_comm_destroy": (C.c_int, [VP]),
+    "kabc_ais_create_dist": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_uint64,
+                                       C.POINTER(VP)]),
+    "kabc_ais_get_ensemble": (C.c_int, [VP, c_double_p]),
+    "kabc_ais_init_multi": (C.c_int, [C.POINTER(VP), C.c_int32, C.c_int32]),
+    "kabc_ais_advance_multi": (C.c_int, [C.POINTER(VP), C.c_int32, C.c_int64, C.c_int32,
+                                         C.POINTER(Stats)]),
     "kabc_smc_default_opts": (None, [C.POINTER(SmcOpts)]),
     "kabc_abcde_default_opts": (None, [C.POINTER(AbcdeOpts)]),
     "kabc_abcde_run": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),

@@ -27,6 +27,14 @@ class KabcError(RuntimeError):
 
 
 def _preload_torch_hip():
+    # KABC_NO_TORCH_PRELOAD=1: hosts that never import torch (bench.py, the RCCL tests) keep
+    # the process on the system ROCm runtime alone
+    if os.environ.get("KABC_NO_TORCH_PRELOAD") == "1":
+        return
+    _preload_torch_hip_impl()
+
+
+def _preload_torch_hip_impl():
     """PyTorch wheels bundle their own ROCm runtime (libamdhip64 & co).  If this
     library pulls in the system libamdhip64 first, a later `import torch` binds to a
     mixed set of ROCm libraries and reports "No HIP GPUs are available".  Loading
@@ -67,11 +75,15 @@ def check(status):
 class Context:
     """kabc_ctx_t: one GPU + one HIP stream."""
 
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, _borrowed=None):
         lib = load()
-        self._h = C.c_void_p()
-        check(lib.kabc_ctx_create(int(device), C.c_void_p(stream) if stream else None,
-                                  C.byref(self._h)))
+        self._owned = _borrowed is None
+        if _borrowed is not None:   # a context owned by a communicator (kabc_comm_init_all)
+            self._h = C.c_void_p(_borrowed)
+        else:
+            self._h = C.c_void_p()
+            check(lib.kabc_ctx_create(int(device), C.c_void_p(stream) if stream else None,
+                                      C.byref(self._h)))
         self.device = device
 
     @property
@@ -82,9 +94,9 @@ class Context:
         check(load().kabc_ctx_synchronize(self._h))
 
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             load().kabc_ctx_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:

@@ -130,15 +130,20 @@ class MCMCThreads:
 class AisEnsemble:
     """kabc_ais_t: the device-resident AISState (src/KissABC.jl:25-33)."""
 
-    def __init__(self, model, nparticles, seed=0, ctx=None, sharded=None):
+    def __init__(self, model, nparticles, seed=0, ctx=None, sharded=None, comm=None):
         self.model = model
-        self.ctx = ctx or _lib.default_context()
+        self.comm = comm
+        self.ctx = comm.ctx if comm is not None else (ctx or _lib.default_context())
         self.N = int(nparticles)
         self.D = len(model)
         self._cmodel = model.to_c()
         self._h = C.c_void_p()
         lib = _lib.load()
-        if sharded is None:
+        if comm is not None:
+            # walker-sharded over the communicator's ranks; the library owns the exchange
+            _lib.check(lib.kabc_ais_create_dist(comm.handle, C.byref(self._cmodel), self.N,
+                                                int(seed), C.byref(self._h)))
+        elif sharded is None:
             _lib.check(lib.kabc_ais_create(self.ctx.handle, C.byref(self._cmodel), self.N,
                                            int(seed), C.byref(self._h)))
         else:
@@ -203,6 +208,13 @@ class AisEnsemble:
         st = cd.Stats()
         _lib.check(_lib.load().kabc_ais_get_stats(self._h, C.byref(st)))
         return {"proposals": st.proposals, "cost_evals": st.cost_evals, "accepted": st.accepted}
+
+    def ensemble(self):
+        """[N][D] unrounded positions of ALL walkers in walker-id order (for a sharded
+        handle: this rank's copy after the last all-gather)."""
+        x = np.empty((self.N, self.D))
+        _lib.check(_lib.load().kabc_ais_get_ensemble(self._h, x.ctypes.data_as(cd.c_double_p)))
+        return x
 
     def set_timing(self, max_launches, stride=1):
         _lib.check(_lib.load().kabc_ais_set_timing(self._h, int(max_launches)))
@@ -403,7 +415,7 @@ def pfilter(prior, cost, N, *, q=0.7, eff_tol=0.1, epstol=-math.inf, max_iters=m
     lib.kabc_pfilter_default_opts(C.byref(o))
     o.nparticles, o.q, o.eff_tol, o.epstol = int(N), float(q), float(eff_tol), float(epstol)
     o.proposal_width, o.verbose, o.seed = float(proposal_width), int(bool(verbose)), int(seed)
-    o.max_iters = 0 if math.isinf(max_iters) else int(max_iters)
+    o.max_iters = -1 if math.isinf(max_iters) else int(math.floor(max_iters))
     D = len(fac)
     n_eff = lib.kabc_pfilter_nparticles(int(N), float(q), D)
     theta = np.empty((n_eff, D))

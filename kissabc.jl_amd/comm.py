@@ -1,0 +1,208 @@
+"""Communicators of the walker-sharded path: ctypes mirror of the `kabc_comm_*` /
+`kabc_ais_*_multi` entry points of include/kabc.h.  The collective (RCCL all-gather,
+or the P2P pull kernel) is issued INSIDE the library; nothing here needs torch.
+
+The reference has no counterpart (its MCMCThreads / MCMCDistributed run independent
+chains, src/KissABC.jl:9,108-109,175).
+
+    one process per GPU (torchrun / mpirun / Distributed.jl style launch):
+        comm = Comm.from_env()                   # RANK / WORLD_SIZE / LOCAL_RANK
+        ens = AisEnsemble(model, N, seed=1, comm=comm).init()
+        ens.advance(gens, ntransitions)          # kernels + ncclAllGather per half
+
+    one process, several GPUs:
+        grp = EnsembleGroup(model, N, seed=1, devices=[0, 1, 2, 3])   # RCCL, or backend="p2p"
+        grp.init(); grp.advance(gens, ntransitions)
+"""
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import _cdefs as cd
+from . import _lib
+from .api import AisEnsemble
+
+
+def unique_id():
+    buf = (C.c_uint8 * cd.KABC_COMM_ID_BYTES)()
+    _lib.check(_lib.load().kabc_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def exchange_unique_id(rank, world, key=None, directory=None, timeout=300.0):
+    """Ship rank 0's RCCL unique id to the other ranks of ONE node through a file
+    (the id is 128 opaque bytes; any channel the host owns would do -- a Julia host
+    would use Distributed or MPI.bcast).  `key` defaults to the launcher's rendezvous
+    (MASTER_ADDR, MASTER_PORT, TORCHELASTIC_RUN_ID), so concurrent jobs do not collide."""
+    if world == 1:
+        return unique_id()
+    directory = directory or os.environ.get("KABC_RDZV_DIR") or "/tmp"
+    if key is None:
+        key = "_".join(str(os.environ.get(v, "")) for v in
+                       ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                        "TORCHELASTIC_RESTART_COUNT"))
+        key = "".join(ch if ch.isalnum() else "-" for ch in key) + f"_w{world}"
+    path = os.path.join(directory, f"kabc_uid_{os.getuid()}_{key}.bin")
+    if rank == 0:
+        uid = unique_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)   # atomic: readers see all 128 bytes or no file
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            # only a file written after this job started counts (a stale one from an earlier
+            # job with the same rendezvous would hang ncclCommInitRank)
+            if os.path.getmtime(path) >= _JOB_START - 5.0:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == cd.KABC_COMM_ID_BYTES:
+                    return uid
+        except OSError:
+            pass
+        if time.time() - t0 > timeout:
+            raise TimeoutError(f"rank {rank}: no unique id at {path} after {timeout:.0f}s")
+        time.sleep(0.02)
+
+
+_JOB_START = time.time()
+
+
+class Comm:
+    """kabc_comm_t"""
+
+    def __init__(self, handle, ctx, owner=True):
+        self._h = C.c_void_p(handle)
+        self.ctx = ctx
+        self._owner = owner
+        lib = _lib.load()
+        self.rank = lib.kabc_comm_rank(self._h)
+        self.world = lib.kabc_comm_world(self._h)
+
+    @property
+    def handle(self):
+        return self._h
+
+    @classmethod
+    def init_rank(cls, uid, rank, world, device=0, ctx=None):
+        ctx = ctx or _lib.Context(device)
+        h = C.c_void_p()
+        buf = (C.c_uint8 * cd.KABC_COMM_ID_BYTES).from_buffer_copy(uid)
+        _lib.check(_lib.load().kabc_comm_init_rank(ctx.handle, buf, int(rank), int(world),
+                                                   C.byref(h)))
+        return cls(h.value, ctx)
+
+    @classmethod
+    def from_env(cls, device=None):
+        """One process per GPU under torchrun-style variables; the unique id travels
+        through exchange_unique_id."""
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        return cls.init_rank(exchange_unique_id(rank, world), rank, world, device)
+
+    def allreduce_sum(self, values):
+        a = (C.c_uint64 * len(values))(*[int(v) for v in values])
+        _lib.check(_lib.load().kabc_comm_allreduce_sum_u64(self._h, a, len(values)))
+        return list(a)
+
+    def allreduce_max(self, values):
+        a = (C.c_double * len(values))(*[float(v) for v in values])
+        _lib.check(_lib.load().kabc_comm_allreduce_max_f64(self._h, a, len(values)))
+        return list(a)
+
+    def barrier(self):
+        _lib.check(_lib.load().kabc_comm_barrier(self._h))
+
+    def close(self):
+        if self._h and self._owner:
+            _lib.load().kabc_comm_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+BACKENDS = {"rccl": cd.COMM_RCCL, "p2p": cd.COMM_P2P}
+
+
+def init_all(devices, backend="rccl"):
+    """kabc_comm_init_all: one context + one communicator per entry of `devices`."""
+    n = len(devices)
+    devs = (C.c_int32 * n)(*[int(d) for d in devices])
+    ctxs = (C.c_void_p * n)()
+    comms = (C.c_void_p * n)()
+    _lib.check(_lib.load().kabc_comm_init_all(n, devs, BACKENDS[backend], ctxs, comms))
+    return [Comm(comms[i], _lib.Context(devices[i], _borrowed=ctxs[i])) for i in range(n)]
+
+
+class EnsembleGroup:
+    """The n shards of one AIS ensemble driven from ONE process
+    (kabc_ais_init_multi / kabc_ais_advance_multi)."""
+
+    def __init__(self, model, nparticles, seed=0, devices=(0,), backend="rccl"):
+        self.comms = init_all(list(devices), backend)
+        self.shards = [AisEnsemble(model, nparticles, seed=seed, comm=c) for c in self.comms]
+        self.N, self.D = int(nparticles), len(model)
+        self._hs = (C.c_void_p * len(self.shards))(*[s._h.value for s in self.shards])
+
+    def init(self, retry_sampling=100):
+        _lib.check(_lib.load().kabc_ais_init_multi(self._hs, len(self.shards), int(retry_sampling)))
+        return self
+
+    def advance(self, ngenerations, ntransitions=1):
+        st = cd.Stats()
+        _lib.check(_lib.load().kabc_ais_advance_multi(self._hs, len(self.shards),
+                                                      int(ngenerations), int(ntransitions),
+                                                      C.byref(st)))
+        self.last_stats = {"proposals": st.proposals, "cost_evals": st.cost_evals,
+                           "accepted": st.accepted}
+        return self
+
+    def ensemble(self, rank=0):
+        return self.shards[rank].ensemble()
+
+    def state(self):
+        """(x, logprior, loglik) of all walkers in walker-id order, assembled from the
+        owners (log-densities live with the owner only)."""
+        n0 = (self.N + 1) // 2
+        x = np.empty((self.N, self.D))
+        lp = np.empty(self.N)
+        ll = np.empty(self.N)
+        lib = _lib.load()
+        for s in self.shards:
+            xs, lps, lls, _ = s.state()
+            o0, o1 = s.owned
+            per0 = -(-n0 // len(self.shards))
+            per1 = -(-(self.N - n0) // len(self.shards))
+            r = s.comm.rank
+            a0, a1 = min(r * per0, n0), n0 + min(r * per1, self.N - n0)
+            x[a0:a0 + o0], lp[a0:a0 + o0], ll[a0:a0 + o0] = xs[:o0], lps[:o0], lls[:o0]
+            x[a1:a1 + o1], lp[a1:a1 + o1], ll[a1:a1 + o1] = xs[o0:], lps[o0:], lls[o0:]
+        return x, lp, ll
+
+    def stats(self):
+        tot = {"proposals": 0, "cost_evals": 0, "accepted": 0}
+        for s in self.shards:
+            for kk, v in s.stats().items():
+                tot[kk] += v
+        return tot
+
+    def synchronize(self):
+        for c in self.comms:
+            c.ctx.synchronize()
+
+    def close(self):
+        for s in self.shards:
+            s.close()
+        for c in self.comms:
+            c.close()
+        self.shards, self.comms = [], []

@@ -90,6 +90,8 @@ struct kabc_ais {
     int64_t rows[2];       // global rows per half
     int64_t row_first[2];  // first owned row per half
     int64_t rows_owned[2];
+    int64_t per[2];        // rows per rank segment of each half (all-gather count / D)
+    kabc_comm_t* comm;     // library-owned exchange (kabc_ais_create_dist), else NULL
     uint32_t id_base[2];   // global walker id of row 0 of each half
     double* d_half[2];     // global halves [rows[h]][D]
     bool own_halves;
@@ -129,9 +131,47 @@ static kabc_status_t check_handle(const kabc_ais_t* h) {
     return KABC_OK;
 }
 
+static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0, void* ext1) {
+    kabc_ctx_t* ctx = h->ctx;
+    const int world = h->world;
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    if (m->cost.nparams > 0) {
+        KABC_HIP_CHECK(hipMalloc(&h->d_cost_params, sizeof(double) * m->cost.nparams));
+        KABC_HIP_CHECK(hipMemcpyAsync(h->d_cost_params, m->cost.params,
+                                      sizeof(double) * m->cost.nparams, hipMemcpyHostToDevice, s));
+    }
+    if (m->cost.ndata > 0) {
+        KABC_HIP_CHECK(hipMalloc(&h->d_cost_data, sizeof(double) * m->cost.ndata));
+        KABC_HIP_CHECK(hipMemcpyAsync(h->d_cost_data, m->cost.data, sizeof(double) * m->cost.ndata,
+                                      hipMemcpyHostToDevice, s));
+    }
+    for (int hf = 0; hf < 2; ++hf) {
+        if (h->own_halves) {
+            // padded to world equal segments so that the in-place all-gather has one count
+            const size_t nb = sizeof(double) * (size_t)(h->per[hf] * world) * h->D;
+            KABC_HIP_CHECK(hipMalloc(&h->d_half[hf], nb));
+            KABC_HIP_CHECK(hipMemsetAsync(h->d_half[hf], 0, nb, s));
+        } else {
+            h->d_half[hf] = (double*)(hf == 0 ? ext0 : ext1);
+        }
+        const size_t nb = sizeof(double) * (size_t)(h->rows_owned[hf] > 0 ? h->rows_owned[hf] : 1);
+        KABC_HIP_CHECK(hipMalloc(&h->d_lp[hf], nb));
+        KABC_HIP_CHECK(hipMalloc(&h->d_ll[hf], nb));
+    }
+    KABC_HIP_CHECK(hipMalloc(&h->d_counters, sizeof(DevCounters)));
+    KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
+    KABC_HIP_CHECK(hipMalloc(&h->d_prior, sizeof(PriorSet)));
+    KABC_HIP_CHECK(hipMemcpyAsync(h->d_prior, &h->prior, sizeof(PriorSet), hipMemcpyHostToDevice, s));
+    KABC_HIP_CHECK(hipMalloc(&h->d_slots, sizeof(unsigned long long) * kCounterSlots * 8));
+    KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
+    KABC_HIP_CHECK(hipStreamSynchronize(s));
+    return KABC_OK;
+}
+
 static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, int64_t n_total,
                                        int32_t rank, int32_t world, uint64_t seed, void* ext0,
-                                       void* ext1, kabc_ais_t** out) {
+                                       void* ext1, kabc_comm_t* comm, kabc_ais_t** out) {
     if (!ctx || !m || !out || !m->prior) {
         set_error("kabc_ais_create: NULL argument");
         return KABC_ERR_INVALID_ARG;
@@ -156,7 +196,8 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         set_error("unknown posterior kind %d", m->posterior);
         return KABC_ERR_INVALID_ARG;
     }
-    if (world < 1 || rank < 0 || rank >= world || (world > 1 && n_total % (2 * world) != 0)) {
+    if (world < 1 || rank < 0 || rank >= world ||
+        (!comm && world > 1 && n_total % (2 * world) != 0)) {
         set_error("sharded AIS needs nparticles divisible by 2*world (got %lld, world %d)",
                   (long long)n_total, world);
         return KABC_ERR_INVALID_ARG;
@@ -202,15 +243,17 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->id_base[1] = (uint32_t)h->rows[0];
     h->rank = rank;
     h->world = world;
+    h->comm = comm;
     for (int hf = 0; hf < 2; ++hf) {
-        if (world == 1) {
-            h->row_first[hf] = 0;
-            h->rows_owned[hf] = h->rows[hf];
-        } else {
-            const int64_t per = h->rows[hf] / world;
-            h->row_first[hf] = per * rank;
-            h->rows_owned[hf] = per;
-        }
+        // caller-lent buffers: equal shards (n_total % (2 world) == 0 was checked); library-
+        // owned exchange: ceil shards, the last ranks may own fewer rows or none
+        const int64_t per = comm ? (h->rows[hf] + world - 1) / world : h->rows[hf] / world;
+        int64_t lo = per * rank, hi = per * (rank + 1);
+        lo = lo < h->rows[hf] ? lo : h->rows[hf];
+        hi = hi < h->rows[hf] ? hi : h->rows[hf];
+        h->per[hf] = per;
+        h->row_first[hf] = lo;
+        h->rows_owned[hf] = hi - lo;
     }
     h->seed = seed;
     h->t = 0;
@@ -232,36 +275,11 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->cost_ndata = m->cost.ndata;
     h->own_halves = (ext0 == nullptr);
 
-    KABC_HIP_CHECK(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
-    if (m->cost.nparams > 0) {
-        KABC_HIP_CHECK(hipMalloc(&h->d_cost_params, sizeof(double) * m->cost.nparams));
-        KABC_HIP_CHECK(hipMemcpyAsync(h->d_cost_params, m->cost.params,
-                                      sizeof(double) * m->cost.nparams, hipMemcpyHostToDevice, s));
+    // every early return below releases what was allocated so far
+    if (kabc_status_t st = ais_alloc(h, m, ext0, ext1)) {
+        (void)kabc_ais_destroy(h);
+        return st;
     }
-    if (m->cost.ndata > 0) {
-        KABC_HIP_CHECK(hipMalloc(&h->d_cost_data, sizeof(double) * m->cost.ndata));
-        KABC_HIP_CHECK(hipMemcpyAsync(h->d_cost_data, m->cost.data, sizeof(double) * m->cost.ndata,
-                                      hipMemcpyHostToDevice, s));
-    }
-    for (int hf = 0; hf < 2; ++hf) {
-        if (h->own_halves) {
-            KABC_HIP_CHECK(hipMalloc(&h->d_half[hf], sizeof(double) * h->rows[hf] * h->D));
-            KABC_HIP_CHECK(hipMemsetAsync(h->d_half[hf], 0, sizeof(double) * h->rows[hf] * h->D, s));
-        } else {
-            h->d_half[hf] = (double*)(hf == 0 ? ext0 : ext1);
-        }
-        const size_t nb = sizeof(double) * (size_t)(h->rows_owned[hf] > 0 ? h->rows_owned[hf] : 1);
-        KABC_HIP_CHECK(hipMalloc(&h->d_lp[hf], nb));
-        KABC_HIP_CHECK(hipMalloc(&h->d_ll[hf], nb));
-    }
-    KABC_HIP_CHECK(hipMalloc(&h->d_counters, sizeof(DevCounters)));
-    KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
-    KABC_HIP_CHECK(hipMalloc(&h->d_prior, sizeof(PriorSet)));
-    KABC_HIP_CHECK(hipMemcpyAsync(h->d_prior, &h->prior, sizeof(PriorSet), hipMemcpyHostToDevice, s));
-    KABC_HIP_CHECK(hipMalloc(&h->d_slots, sizeof(unsigned long long) * kCounterSlots * 8));
-    KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
-    KABC_HIP_CHECK(hipStreamSynchronize(s));
     *out = h;
     return KABC_OK;
 }
@@ -299,7 +317,7 @@ extern "C" {
 
 kabc_status_t kabc_ais_create(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t nparticles,
                               uint64_t seed, kabc_ais_t** out) {
-    return ais_create_common(ctx, model, nparticles, 0, 1, seed, nullptr, nullptr, out);
+    return ais_create_common(ctx, model, nparticles, 0, 1, seed, nullptr, nullptr, nullptr, out);
 }
 
 kabc_status_t kabc_ais_create_sharded(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t n_total,
@@ -309,10 +327,22 @@ kabc_status_t kabc_ais_create_sharded(kabc_ctx_t* ctx, const kabc_model_t* model
         set_error("kabc_ais_create_sharded: device half buffers must be provided");
         return KABC_ERR_INVALID_ARG;
     }
-    return ais_create_common(ctx, model, n_total, rank, world, seed, dev_half0, dev_half1, out);
+    return ais_create_common(ctx, model, n_total, rank, world, seed, dev_half0, dev_half1, nullptr,
+                             out);
 }
 
-kabc_status_t kabc_ais_init(kabc_ais_t* h, int32_t retry_sampling) {
+kabc_status_t kabc_ais_create_dist(kabc_comm_t* comm, const kabc_model_t* model,
+                                   int64_t nparticles, uint64_t seed, kabc_ais_t** out) {
+    if (!comm) {
+        set_error("kabc_ais_create_dist: communicator is NULL");
+        return KABC_ERR_INVALID_ARG;
+    }
+    return ais_create_common(comm->ctx, model, nparticles, comm->rank, comm->world, seed, nullptr,
+                             nullptr, comm, out);
+}
+
+// step(init) of one handle, enqueued on its stream (no read-back)
+static kabc_status_t ais_init_enqueue(kabc_ais_t* h, int32_t retry_sampling) {
     if (check_handle(h)) return KABC_ERR_INVALID_ARG;
     if (retry_sampling < 0) {
         set_error("retry_sampling must be >= 0");
@@ -347,16 +377,95 @@ kabc_status_t kabc_ais_init(kabc_ais_t* h, int32_t retry_sampling) {
         launch_ais_init(h->D, a, s);
         KABC_HIP_CHECK(hipGetLastError());
     }
-    DevCounters c;
-    if (read_counters(h, &c)) return KABC_ERR_DEVICE;
-    if (c.init_failed) {
-        // src/KissABC.jl:58-59
-        set_error("Prior leads to ∞ costs too often, tune the prior or increase `retry_sampling`.");
-        return KABC_ERR_RETRY_EXHAUSTED;
-    }
+    return KABC_OK;
+}
+
+static kabc_status_t ais_init_failed() {
+    // src/KissABC.jl:58-59
+    set_error("Prior leads to ∞ costs too often, tune the prior or increase `retry_sampling`.");
+    return KABC_ERR_RETRY_EXHAUSTED;
+}
+
+static void ais_mark_initialised(kabc_ais_t* h) {
     h->t = 0;
     h->initialised = true;
     h->last = kabc_stats_t{0, 0, 0};
+}
+
+kabc_status_t kabc_ais_init(kabc_ais_t* h, int32_t retry_sampling) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    if (h->comm && h->comm->single_process) {
+        set_error("this handle belongs to a single-process group: use kabc_ais_init_multi");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (kabc_status_t st = ais_init_enqueue(h, retry_sampling)) return st;
+    DevCounters c;
+    if (read_counters(h, &c)) return KABC_ERR_DEVICE;
+    uint64_t failed = c.init_failed ? 1u : 0u;
+    if (h->comm) {
+        // every rank takes part in the exchange whatever its own outcome, and every rank
+        // reports the failure of any (the reference's retry budget is per ensemble)
+        for (int hf = 0; hf < 2; ++hf)
+            if (kabc_status_t st = comm_allgather_inplace(h->comm, h->d_half[hf],
+                                                          (size_t)h->per[hf] * h->D))
+                return st;
+        if (kabc_status_t st = kabc_comm_allreduce_sum_u64(h->comm, &failed, 1)) return st;
+    }
+    if (failed) return ais_init_failed();
+    ais_mark_initialised(h);
+    return KABC_OK;
+}
+
+static kabc_status_t check_group(kabc_ais_t** hs, int32_t n, const char* who) {
+    if (!hs || n < 1 || n > KABC_COMM_MAX_WORLD) {
+        set_error("%s: bad handle array", who);
+        return KABC_ERR_INVALID_ARG;
+    }
+    unsigned seen = 0;
+    for (int i = 0; i < n; ++i) {
+        kabc_ais_t* h = hs[i];
+        if (!h || !h->comm || !h->comm->single_process || h->comm->world != n ||
+            h->comm->backend != hs[0]->comm->backend || h->comm->grp != hs[0]->comm->grp ||
+            h->N != hs[0]->N || h->D != hs[0]->D || h->seed != hs[0]->seed) {
+            set_error("%s: the handles must be the %d shards of one ensemble, created with "
+                      "kabc_ais_create_dist on the communicators of one kabc_comm_init_all call",
+                      who, n);
+            return KABC_ERR_INVALID_ARG;
+        }
+        seen |= 1u << h->comm->rank;
+    }
+    if (seen != (n >= 32 ? ~0u : (1u << n) - 1u)) {
+        set_error("%s: every rank must be present exactly once", who);
+        return KABC_ERR_INVALID_ARG;
+    }
+    return KABC_OK;
+}
+
+static kabc_status_t gather_multi(kabc_ais_t** hs, int32_t n, int half) {
+    kabc_comm_t* comms[KABC_COMM_MAX_WORLD];
+    double* bases[KABC_COMM_MAX_WORLD];
+    for (int i = 0; i < n; ++i) {
+        comms[i] = hs[i]->comm;
+        bases[i] = hs[i]->d_half[half];
+    }
+    return comm_allgather_inplace_multi(comms, bases, n, (size_t)hs[0]->per[half] * hs[0]->D);
+}
+
+kabc_status_t kabc_ais_init_multi(kabc_ais_t** hs, int32_t n, int32_t retry_sampling) {
+    if (kabc_status_t st = check_group(hs, n, "kabc_ais_init_multi")) return st;
+    for (int i = 0; i < n; ++i)
+        if (kabc_status_t st = ais_init_enqueue(hs[i], retry_sampling)) return st;
+    for (int hf = 0; hf < 2; ++hf)
+        if (kabc_status_t st = gather_multi(hs, n, hf)) return st;
+    bool failed = false;
+    for (int i = 0; i < n; ++i) {
+        KABC_HIP_CHECK(hipSetDevice(hs[i]->ctx->device));
+        DevCounters c;
+        if (read_counters(hs[i], &c)) return KABC_ERR_DEVICE;
+        failed = failed || c.init_failed;
+    }
+    if (failed) return ais_init_failed();
+    for (int i = 0; i < n; ++i) ais_mark_initialised(hs[i]);
     return KABC_OK;
 }
 
@@ -439,9 +548,18 @@ kabc_status_t kabc_ais_end_generation(kabc_ais_t* h, int32_t ntransitions) {
 kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntransitions,
                                double* out_samples, kabc_stats_t* stats) {
     if (check_handle(h)) return KABC_ERR_INVALID_ARG;
-    if (h->world != 1) {
-        set_error("kabc_ais_advance drives single-process handles; sharded handles are driven "
-                  "with kabc_ais_half_generation + an all-gather per half");
+    if (h->world != 1 && !h->comm) {
+        set_error("kabc_ais_advance drives single-process handles and kabc_ais_create_dist handles; "
+                  "handles on caller-lent buffers are driven with kabc_ais_half_generation + the "
+                  "caller's all-gather per half");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (h->comm && h->comm->single_process) {
+        set_error("this handle belongs to a single-process group: use kabc_ais_advance_multi");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (h->comm && out_samples) {
+        set_error("a sharded ensemble has no streamed trace: read it with kabc_ais_get_ensemble");
         return KABC_ERR_INVALID_ARG;
     }
     if (ngenerations < 0 || ntransitions < 1) {
@@ -458,10 +576,13 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
     const size_t gen_bytes = sizeof(double) * (size_t)gen_elems;
     if (!out_samples || ngenerations == 0) {
         for (int64_t g = 0; g < ngenerations; ++g) {
-            kabc_status_t st = kabc_ais_half_generation(h, 0, ntransitions, nullptr);
-            if (st) return st;
-            st = kabc_ais_half_generation(h, 1, ntransitions, nullptr);
-            if (st) return st;
+            for (int hf = 0; hf < 2; ++hf) {
+                kabc_status_t st = kabc_ais_half_generation(h, hf, ntransitions, nullptr);
+                // the one collective of the design: rebuild half hf on every rank
+                if (st == KABC_OK && h->comm)
+                    st = comm_allgather_inplace(h->comm, h->d_half[hf], (size_t)h->per[hf] * h->D);
+                if (st) return st;
+            }
             h->t += (uint64_t)ntransitions;
         }
     } else {
@@ -573,6 +694,55 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
     h->last.proposals = c.proposals;
     h->last.cost_evals = c.cost_evals;
     h->last.accepted = c.accepted;
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_advance_multi(kabc_ais_t** hs, int32_t n, int64_t ngenerations,
+                                     int32_t ntransitions, kabc_stats_t* stats) {
+    if (kabc_status_t st = check_group(hs, n, "kabc_ais_advance_multi")) return st;
+    if (ngenerations < 0 || ntransitions < 1) {
+        set_error("ngenerations must be >= 0 and ntransitions >= 1");
+        return KABC_ERR_INVALID_ARG;
+    }
+    for (int64_t g = 0; g < ngenerations; ++g) {
+        for (int hf = 0; hf < 2; ++hf) {
+            for (int i = 0; i < n; ++i) {
+                KABC_HIP_CHECK(hipSetDevice(hs[i]->ctx->device));
+                if (kabc_status_t st = kabc_ais_half_generation(hs[i], hf, ntransitions, nullptr))
+                    return st;
+            }
+            if (kabc_status_t st = gather_multi(hs, n, hf)) return st;
+        }
+        for (int i = 0; i < n; ++i) hs[i]->t += (uint64_t)ntransitions;
+    }
+    for (int i = 0; i < n; ++i) {
+        kabc_ais_t* h = hs[i];
+        KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+        DevCounters c;
+        if (read_counters(h, &c)) return KABC_ERR_DEVICE;
+        if (kabc_status_t st = check_device_error(h, c)) return st;
+        if (stats) {
+            stats->proposals += c.proposals - h->last.proposals;
+            stats->cost_evals += c.cost_evals - h->last.cost_evals;
+            stats->accepted += c.accepted - h->last.accepted;
+        }
+        h->last.proposals = c.proposals;
+        h->last.cost_evals = c.cost_evals;
+        h->last.accepted = c.accepted;
+    }
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_get_ensemble(kabc_ais_t* h, double* x) {
+    if (check_handle(h) || !x) return KABC_ERR_INVALID_ARG;
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    hipStream_t s = h->ctx->stream;
+    KABC_HIP_CHECK(hipMemcpyAsync(x, h->d_half[0], sizeof(double) * h->rows[0] * h->D,
+                                  hipMemcpyDeviceToHost, s));
+    if (h->rows[1] > 0)
+        KABC_HIP_CHECK(hipMemcpyAsync(x + h->rows[0] * h->D, h->d_half[1],
+                                      sizeof(double) * h->rows[1] * h->D, hipMemcpyDeviceToHost, s));
+    KABC_HIP_CHECK(hipStreamSynchronize(s));
     return KABC_OK;
 }
 

@@ -232,9 +232,16 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         KABC_HIP_CHECK(hipMemcpyAsync(d_data, cost->data, sizeof(double) * cost->ndata,
                                       hipMemcpyHostToDevice, s));
     }
-    hipEvent_t ev0, ev1;
-    KABC_HIP_CHECK(hipEventCreate(&ev0));
-    KABC_HIP_CHECK(hipEventCreate(&ev1));
+    struct EvPair {  // released on every return path
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EvPair() {
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+        }
+    } evp;
+    KABC_HIP_CHECK(hipEventCreate(&evp.a));
+    KABC_HIP_CHECK(hipEventCreate(&evp.b));
+    const hipEvent_t ev0 = evp.a, ev1 = evp.b;
     double mcmc_ms = 0.0;
     int64_t mcmc_timed = 0;
 
@@ -412,8 +419,6 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
                     (double)st[0] / st[7], (double)st[1] / st[7], (double)st[2] / st[7], (double)st[3] / st[7],
                     (double)st[4] / st[7], (double)st[5] / st[7], st[7]);
     }
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
     return rc;
 }
 
@@ -426,7 +431,7 @@ void kabc_pfilter_default_opts(kabc_pfilter_opts_t* o) {
     o->eff_tol = 0.1;
     o->epstol = -INFINITY;
     o->proposal_width = 0.75;
-    o->max_iters = 0;
+    o->max_iters = -1;
     o->verbose = 0;
     o->reserved = 0;
     o->seed = 0;
@@ -640,7 +645,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
             fprintf(stderr, "(iters, ϵ, eff) = (%lld, %.17g, %.17g)\n", (long long)iters, eps, eff);
         if (eff < o->eff_tol) break;
         if (eps < o->epstol) break;
-        if (o->max_iters > 0 && iters > o->max_iters) break;
+        if (o->max_iters >= 0 && iters > o->max_iters) break;  // src/smc.jl:332; < 0 = Inf
         if (!(hp.nreps > 0)) break;  // nothing left to refresh: eff is NaN forever
     }
     SmcFinalArgs fa;

@@ -38,3 +38,26 @@ struct kabc_ctx {
     hipStream_t stream;
     bool own_stream;
 };
+
+// ---- communicators (capi_comm.hip) ------------------------------------------------
+namespace kabc {
+struct P2PGroup;  // single-process peer group shared by the communicators of one init_all
+}
+struct kabc_comm {
+    kabc_ctx_t* ctx;
+    int32_t rank, world, backend;
+    bool own_ctx;
+    bool single_process;   // created by kabc_comm_init_all
+    void* nccl;            // ncclComm_t (RCCL backend)
+    kabc::P2PGroup* grp;   // P2P backend
+    void* d_scratch;       // small device buffer for the host-value reductions
+};
+
+namespace kabc {
+// in-place all-gather of `count` doubles per rank inside `base` ([world][count]) on the
+// communicator's stream; one-process-per-GPU RCCL communicators only
+kabc_status_t comm_allgather_inplace(kabc_comm* c, double* base, size_t count);
+// the same for the n communicators of one kabc_comm_init_all call: bases[i] is the buffer of
+// comms[i]; RCCL: one ncclGroup; P2P: every rank pulls the peers' segments after their kernels
+kabc_status_t comm_allgather_inplace_multi(kabc_comm** comms, double** bases, int n, size_t count);
+}  // namespace kabc

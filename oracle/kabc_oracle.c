@@ -1156,7 +1156,7 @@ int32_t orc_pfilter_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t*
         eff = (double)nbad / (double)nreps;
         if (eff < o->eff_tol) break;
         if (eps < o->epstol) break;
-        if (o->max_iters > 0 && iters > o->max_iters) break;
+        if (o->max_iters >= 0 && iters > o->max_iters) break;  /* :332; < 0 = Inf */
         if (!(nreps > 0)) break;
     }
     for (int64_t i = 0; i < N; ++i) {

@@ -333,13 +333,14 @@ def abcde(prior, cost, eps_target, *, nparticles=50, generations=20, alpha=0.0, 
             "generations_run": r.generations_run, "nsims": r.nsims}
 
 
-def pfilter(prior, cost, N, *, q=0.7, eff_tol=0.1, epstol=-math.inf, max_iters=0,
+def pfilter(prior, cost, N, *, q=0.7, eff_tol=0.1, epstol=-math.inf, max_iters=math.inf,
             proposal_width=0.75, seed=0):
     """CPU restatement of pfilter (src/smc.jl:275-340); returns dict."""
     fac = as_factored(prior)
     o = cd.PfilterOpts()
     o.nparticles, o.q, o.eff_tol, o.epstol = int(N), q, eff_tol, epstol
-    o.proposal_width, o.max_iters, o.verbose, o.seed = proposal_width, int(max_iters), 0, seed
+    o.proposal_width, o.verbose, o.seed = proposal_width, 0, seed
+    o.max_iters = -1 if math.isinf(max_iters) else int(math.floor(max_iters))
     D = len(fac)
     n_eff = load().orc_pfilter_nparticles(int(N), q, D)
     theta = np.empty((n_eff, D))

@@ -1,0 +1,163 @@
+"""The library-owned exchange of the walker-sharded path (include/kabc.h "multi-GPU"):
+kabc_comm_* + kabc_ais_create_dist + the *_multi drivers.
+
+A 1-GPU box cannot host two RCCL ranks, so the multi-rank logic (row ownership with
+uneven / empty shards, global walker ids, partner draws over the GLOBAL complementary
+half, the in-place all-gather layout, event ordering) runs on the P2P backend with
+every rank on device 0 -- each rank owns its own copy of the global half buffers, so a
+missing or misplaced exchange shows up as a mismatch against the single-process oracle.
+The RCCL backend itself is exercised at world size 1 (communicator set-up from a
+unique id, ncclAllGather in place on the context stream, the host-value reductions)
+in a torch-free child process."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(k, D=8):
+    return k.ApproxKernelizedPosterior(k.Factored(*[k.Uniform(-5, 5)] * D), k.costs.Rosenbrock(), 1.0)
+
+
+@pytest.mark.parametrize("world,N,D,nt,gens", [(2, 2048, 8, 5, 3), (3, 1001, 4, 3, 4),
+                                                (8, 523, 8, 2, 3), (5, 13, 8, 4, 2)])
+def test_p2p_emulated_ranks_match_oracle(k, orc, gpu_ctx, world, N, D, nt, gens):
+    model = _model(k, D)
+    grp = k.EnsembleGroup(model, N, seed=17, devices=[0] * world, backend="p2p").init()
+    o = orc.OracleAIS(model, N, seed=17).init()
+    assert np.array_equal(grp.ensemble(0), o.state()[0])           # init + first gather
+    grp.advance(gens, nt)
+    o.generations_sync(gens, nt, collect=False)
+    xo, lpo, llo, _ = o.state()
+    for r in range(world):                                         # every rank holds everything
+        assert np.array_equal(grp.ensemble(r), xo), f"rank {r}"
+    x, lp, ll = grp.state()
+    assert np.array_equal(x, xo) and np.array_equal(lp, lpo) and np.array_equal(ll, llo)
+    assert grp.stats() == o.stats()
+    assert grp.last_stats["proposals"] == N * nt * gens
+    grp.close()
+
+
+def test_c5_eight_emulated_ranks_full_size(k, orc, gpu_ctx):
+    """BASELINE.json configs[4] (C5): 524 288 walkers, D = 8, sharded 8 ways, at its full
+    size -- 8 ranks on one GPU, exchange by the pull kernel, ntransitions = 16, two
+    generations, bit-exact against the oracle."""
+    model = _model(k, 8)
+    N, nt, gens = 524288, 16, 2
+    grp = k.EnsembleGroup(model, N, seed=1, devices=[0] * 8, backend="p2p").init()
+    grp.advance(gens, nt)
+    o = orc.OracleAIS(model, N, seed=1).init()
+    o.generations_sync(gens, nt, collect=False)
+    xo, lpo, llo, _ = o.state()
+    assert np.array_equal(grp.ensemble(7), xo) and np.array_equal(grp.ensemble(0), xo)
+    x, lp, ll = grp.state()
+    assert np.array_equal(lp, lpo) and np.array_equal(ll, llo)
+    assert grp.stats() == o.stats()
+    assert [s.owned for s in grp.shards] == [(32768, 32768)] * 8
+    grp.close()
+
+
+def test_group_argument_checks(k, gpu_ctx):
+    model = _model(k, 4)
+    grp = k.EnsembleGroup(model, 64, seed=1, devices=[0, 0], backend="p2p")
+    with pytest.raises(k.KabcError, match="kabc_ais_init_multi"):
+        grp.shards[0].init()
+    grp.init()
+    with pytest.raises(k.KabcError, match="kabc_ais_advance_multi"):
+        grp.shards[1].advance(1, 1)
+    grp.close()
+    with pytest.raises(k.KabcError):
+        k.comm.init_all([0] * 17, "p2p")
+
+
+CHILD = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, {root!r})
+import kissabc_jl_amd as k
+assert "torch" not in sys.modules
+model = k.ApproxKernelizedPosterior(k.Factored(*[k.Uniform(-5, 5)] * 4), k.costs.Rosenbrock(), 1.0)
+mode = {mode!r}
+if mode == "rank":          # one process per GPU: unique id -> ncclCommInitRank
+    comm = k.Comm.from_env()
+    ens = k.AisEnsemble(model, 1024, seed=11, comm=comm).init()
+    ens.advance(5, 7)
+    x = ens.ensemble()
+    st = ens.stats()
+    red = comm.allreduce_sum([st["proposals"], 3])
+    mx = comm.allreduce_max([1.5, -2.0])
+    comm.barrier()
+    ens.close(); comm.close()
+    extra = {{"red": red, "mx": mx}}
+elif mode == "all":         # one process: ncclCommInitAll + grouped all-gather
+    grp = k.EnsembleGroup(model, 1024, seed=11, devices=[0], backend="rccl").init()
+    grp.advance(5, 7)
+    x = grp.ensemble(0)
+    st = grp.stats()
+    grp.close()
+    extra = {{}}
+else:                       # no communicator at all
+    ens = k.AisEnsemble(model, 1024, seed=11).init()
+    ens.advance(5, 7)
+    x = ens.ensemble()
+    st = ens.stats()
+    extra = {{}}
+assert "torch" not in sys.modules
+np.save({out!r}, x)
+import ctypes
+ctypes.CDLL(None).fflush(None)   # RCCL's start-up banner sits in the C stdout buffer
+print(json.dumps(dict(st, **extra)), flush=True)
+"""
+
+
+def _run_child(tmp_path, mode):
+    out = str(tmp_path / f"x_{mode}.npy")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", KABC_NO_TORCH_PRELOAD="1")
+    r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out, mode=mode)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out), json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_rccl_world1_through_the_c_abi(tmp_path):
+    x0, s0 = _run_child(tmp_path, "plain")
+    x1, s1 = _run_child(tmp_path, "rank")
+    assert np.array_equal(x1, x0)
+    assert s1["proposals"] == s0["proposals"] == 1024 * 5 * 7 and s1["accepted"] == s0["accepted"]
+    assert s1["red"] == [1024 * 5 * 7, 3] and s1["mx"] == [1.5, -2.0]
+    x2, s2 = _run_child(tmp_path, "all")
+    assert np.array_equal(x2, x0) and s2["accepted"] == s0["accepted"]
+
+
+def _bench(extra_env, launcher):
+    env = dict(os.environ, KABC_FORCE_COLLECTIVE="1", **extra_env)
+    cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1",
+                      "--no-cpu-baseline", "--min-seconds", "0.05"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and r.stdout.strip().splitlines()[-1] == lines[0], r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_with_communicator_env_launch():
+    d = _bench(dict(MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0", LOCAL_RANK="0",
+                    WORLD_SIZE="1"), [sys.executable])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0
+    assert set(d["by_ntransitions"]) == {"1", "16", "100"} and d["config"]["ntransitions"] == 100
+    assert d["smc_c4"]["iterations"] > 100 and d["smc_c4"]["wall_ms"] > 0
+
+
+def test_bench_under_the_drivers_launcher():
+    """Launched exactly as the driver launches N > 1 (python -m torch.distributed.run ...),
+    here with one rank: the ranks' rendezvous variables come from the launcher."""
+    d = _bench({}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                    "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29571"])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0

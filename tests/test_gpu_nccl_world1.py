@@ -1,6 +1,7 @@
-"""The RCCL leg of the walker-sharded path on ONE GPU: bench.py and ShardedAIS with
-KABC_FORCE_COLLECTIVE=1 issue their all-gathers / barrier / all-reduce through a real
-"nccl" process group of world size 1.  Multi-GPU boxes are not available to the test
+"""The torch.distributed variant of the walker-sharded path (sharded.ShardedAIS on
+caller-lent torch buffers) on ONE GPU: with KABC_FORCE_COLLECTIVE=1 it issues its
+all-gathers / barrier / all-reduce through a real "nccl" process group of world size 1.
+(The library-owned exchange -- kabc_comm_*, what bench.py uses -- is in test_gpu_comm.py.)  Multi-GPU boxes are not available to the test
 suite; this pins what can be pinned here -- process-group set-up on the explicit
 stream, the in-place all_gather_into_tensor on the lent half buffers, ordering
 against the kernels -- and checks the trajectory is still the single-process one."""
@@ -55,14 +56,3 @@ def test_forced_collective_matches_plain(tmp_path):
     x0, s0 = _run_child(tmp_path, False)
     assert np.array_equal(x1, x0)
     assert s1 == s0 and s1["proposals"] == 1024 * 5 * 7
-
-
-def test_bench_with_process_group(tmp_path):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29534", RANK="0",
-               LOCAL_RANK="0", WORLD_SIZE="1", KABC_FORCE_COLLECTIVE="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps",
-                        "5", "--warmup", "1", "--no-cpu-baseline", "--no-alt"], env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 1 and line["value"] > 0 and line["roofline"]["frac"] > 0
