@@ -171,6 +171,15 @@ kabc_status_t kabc_register_cost_plugin(const char* path, int32_t* out_cost_id);
 kabc_status_t kabc_ais_create(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t nparticles,
                               uint64_t seed, kabc_ais_t** out);
 
+/* sample(model, AIS(N), MCMCThreads(), Ns, Nc) -- src/KissABC.jl:96-104,108: `nchains`
+ * INDEPENDENT ensembles of nparticles walkers each in one handle, chain = a grid dimension of
+ * every launch (50 x AIS(12) is 50 workgroups of one launch instead of 50 runs one after the
+ * other).  Chain c uses seeds[c] and is bit-identical to a kabc_ais_create handle with that
+ * seed.  Host layouts gain a leading chain axis: kabc_ais_advance's out_samples is
+ * [ngenerations][nchains][N][D]; get/set_state and get_ensemble use [nchains][N][...]. */
+kabc_status_t kabc_ais_create_batch(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t nparticles,
+                                    int32_t nchains, const uint64_t* seeds, kabc_ais_t** out);
+
 /* Sharded variant: this process owns rows [rank*rows_h/world, (rank+1)*rows_h/world)
  * of each half of an ensemble of n_total walkers (n_total divisible by 2*world).
  * dev_half0 / dev_half1 are caller-provided DEVICE buffers of n_total/2 * D

@@ -97,6 +97,11 @@ KABC_HD uint64_t kabc_hi64(kabc_u128_t b) { return ((uint64_t)b.w[3] << 32) | b.
 /* RNG service handed to a (stochastic) cost function: sequential slots of one
  * (walker, t, domain) stream.  This is what replaces the cost closure's use of
  * Julia's global RNG (e.g. README.md:45 `randn(1000)`, test/runtests.jl:109). */
+/* every hipcc translation unit (library, plugins) gets the prefetch fields below; the plain-C
+ * oracle build does not */
+#if defined(__HIPCC__) && !defined(KABC_RNG_PREFETCH)
+#define KABC_RNG_PREFETCH 1
+#endif
 typedef struct kabc_cost_rng {
     uint64_t seed;
     uint64_t t;
@@ -111,6 +116,15 @@ typedef struct kabc_cost_rng {
     /* copy of kabc_log_tab the normals should look their logs up in (a kernel's LDS copy:
      * a per-lane gather from LDS instead of global memory); NULL = kabc_log_tab */
     const double* logtab;
+#ifdef KABC_RNG_PREFETCH
+    /* The first pre_n blocks of the stream, already expanded into normal pairs
+     * (pre[2 s], pre[2 s + 1] = the pair of block s): a kernel computes them while its
+     * loads are in flight -- the draws are counter-based, so when they are computed changes
+     * nothing.  Only for costs whose first pre_n blocks ARE normal pairs (kabc_device.hpp
+     * cost_pre_blocks).  Compiled into the translation units that define KABC_RNG_PREFETCH. */
+    const double* pre;
+    uint32_t pre_n;
+#endif
 } kabc_cost_rng_t;
 
 KABC_HD kabc_u128_t kabc_cost_rng_next(kabc_cost_rng_t* g) {
@@ -118,6 +132,14 @@ KABC_HD kabc_u128_t kabc_cost_rng_next(kabc_cost_rng_t* g) {
 }
 /* two N(0,1) per block */
 KABC_HD void kabc_cost_rng_normal2(kabc_cost_rng_t* g, double* z0, double* z1) {
+#ifdef KABC_RNG_PREFETCH
+    if (g->pre && g->slot < g->pre_n) {
+        *z0 = g->pre[2u * g->slot];
+        *z1 = g->pre[2u * g->slot + 1u];
+        g->slot++;
+        return;
+    }
+#endif
     kabc_u128_t b = kabc_cost_rng_next(g);
     kabc_normal_pair_tab(kabc_lo64(b), kabc_hi64(b), z0, z1, g->logtab ? g->logtab : kabc_log_tab);
 }

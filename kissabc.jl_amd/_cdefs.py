@@ -115,6 +115,8 @@ PROTOTYPES = {
                                      C.c_int64, C.c_int64, C.c_uint64, c_double_p]),
     "kabc_register_cost_plugin": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "kabc_ais_create": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_uint64, C.POINTER(VP)]),
+    "kabc_ais_create_batch": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_int32,
+                                        C.POINTER(C.c_uint64), C.POINTER(VP)]),
     "kabc_ais_create_sharded": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_int32, C.c_int32,
                                           C.c_uint64, VP, VP, C.POINTER(VP)]),
     "kabc_ais_init": (C.c_int, [VP, C.c_int32]),

@@ -10,10 +10,10 @@
 namespace kabc {
 
 template <int D, int COST, int PC, int PK>
-static void launch_half(const AisArgs& a, hipStream_t s) {
+static void launch_half(const AisArgs& a, hipStream_t s, unsigned nchains) {
     const unsigned grid = (unsigned)((a.rows_owned + kBatch - 1) / kBatch);
     if (grid == 0) return;
-    hipLaunchKernelGGL((ais_half_kernel<D, COST, PC, PK>), dim3(grid), dim3(kAisBlock), 0, s, a);
+    hipLaunchKernelGGL((ais_half_kernel<D, COST, PC, PK>), dim3(grid, nchains), dim3(kAisBlock), 0, s, a);
 }
 
 template <int COST, int D, int PCX>

@@ -39,6 +39,12 @@ struct AisArgs {
     double box_lp;          // prior class BOX: the in-support log-density (ordered sum of c0)
     int32_t ablate;         // PROBES=1 builds only (KABC_ABLATE): 1 no consumer, 2 no producers, 64 HW_ID, 128 barrier time
     const PriorDev* prior;  // [D] prepared components, device memory (scalar-loaded)
+    // batched independent chains (MCMCThreads, src/KissABC.jl:96-104,108): blockIdx.y = chain.
+    // Chain c works on x_act + c * stride_act, x_comp + c * stride_comp, lp/ll + c * stride_own,
+    // trace + c * stride_trace with the seed seeds[c]; walker ids are per chain, so every chain
+    // is bit-identical to a single-chain run with its seed.  seeds == NULL: one chain.
+    const uint64_t* seeds;
+    int64_t stride_act, stride_comp, stride_own, stride_trace;
 };
 
 constexpr int kLateFrom = 10;  // D above this: the consumer keeps ONE set of partner-row registers
@@ -62,6 +68,10 @@ struct InitArgs {
     unsigned long long retry_budget;  // retry_sampling * nparticles (src/KissABC.jl:52)
     PriorSet prior;
     kabc_prior_t raw[KABC_MAX_DIM];
+    // batched chains (blockIdx.y = chain), see AisArgs; the retry budget is per chain
+    const uint64_t* seeds;
+    unsigned long long* chain_retries;  // [nchains]
+    int64_t stride_act, stride_own;
 };
 
 constexpr int kInitBlock = 64;
@@ -328,7 +338,17 @@ __device__ __forceinline__ void prepare_cost_aux(const AisArgs& A, uint64_t t, u
 // loglike/accept and the SGPRs to feed them -- 8 % of the launch.
 template <int D, int COST, int PC, int PK>
 __global__ void __launch_bounds__(kAisBlock) __attribute__((amdgpu_waves_per_eu(2, 2)))
-ais_half_kernel(const AisArgs A) {
+ais_half_kernel(const AisArgs A0) {
+    AisArgs A = A0;
+    if (A0.seeds) {  // wave-uniform: one chain of a batch per blockIdx.y
+        const int64_t c = (int64_t)blockIdx.y;
+        A.seed = A0.seeds[c];
+        A.x_act += c * A0.stride_act;
+        A.x_comp += c * A0.stride_comp;
+        A.lp += c * A0.stride_own;
+        A.ll += c * A0.stride_own;
+        if (A0.trace) A.trace += c * A0.stride_trace;
+    }
     __shared__ ChunkRec<D> rec[2];
     __shared__ uint8_t listB[kChunk][kBatch];
     // prepared prior components: read by the consumer with wave-uniform LDS
@@ -601,7 +621,8 @@ ais_half_kernel(const AisArgs A) {
         const unsigned long long se = wave_sum(n_eval);
         const unsigned long long sa = wave_sum(n_acc);
         if (lane == 0) {
-            unsigned long long* sl = A.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 8;
+            unsigned long long* sl =
+                A.slots + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1)) * 8;
             atomicAdd(&sl[0], (unsigned long long)n_active * (unsigned long long)A.nt);
             atomicAdd(&sl[1], se);
             atomicAdd(&sl[2], sa);
@@ -618,17 +639,23 @@ __global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) 
     if (r >= A.rows_owned) return;
     const int64_t row = A.row_first + r;
     const uint32_t w = A.id_base + (uint32_t)row;
+    const int64_t chain = (int64_t)blockIdx.y;
+    const uint64_t seed = A.seeds ? A.seeds[chain] : A.seed;
+    unsigned long long* retries = A.seeds ? A.chain_retries + chain : &A.counters->retries;
+    double* x_act = A.x_act + (A.seeds ? chain * A.stride_act : 0);
+    double* lp_out = A.lp + (A.seeds ? chain * A.stride_own : 0);
+    double* ll_out = A.ll + (A.seeds ? chain * A.stride_own : 0);
     double x[D], xp[D];
     double lp = 0.0, ll = 0.0;
     uint64_t attempt = 0;
     while (true) {
         for (int k = 0; k < D; ++k) {
-            kabc_slotwin_t win = {A.seed, attempt, w, KABC_DOM_AIS_INIT,
+            kabc_slotwin_t win = {seed, attempt, w, KABC_DOM_AIS_INIT,
                                   (uint32_t)k * KABC_SLOTS_PER_DIM};
             x[k] = kabc_sample_prior(&A.raw[k], &win);
         }
         lp = factored_logpdf_push<D>(A.prior, x, xp);
-        kabc_cost_rng_t rng = {A.seed, attempt, w, KABC_DOM_AIS_INIT_COST, 0u};
+        kabc_cost_rng_t rng = {seed, attempt, w, KABC_DOM_AIS_INIT_COST, 0u};
         if (A.posterior == KABC_POSTERIOR_COMMON) {
             lp = 0.0;
             ll = kabc_cost_eval(A.cost_id, x, D, A.cost_params, A.cost_data, A.cost_ndata, &rng);
@@ -647,23 +674,24 @@ __global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) 
                                     &rng);
         }
         if (ld_valid(A.posterior, lp, ll)) break;
-        const unsigned long long used = atomicAdd(&A.counters->retries, 1ull) + 1ull;
+        const unsigned long long used = atomicAdd(retries, 1ull) + 1ull;
         if (used > A.retry_budget) {
             A.counters->init_failed = 1;
             break;
         }
         ++attempt;
     }
-    store_row<D>(A.x_act + row * D, x);
-    A.lp[r] = lp;
-    A.ll[r] = ll;
+    store_row<D>(x_act + row * D, x);
+    lp_out[r] = lp;
+    ll_out[r] = ll;
 }
 
 // launchers (defined by the instantiation units)
-using AisLaunchFn = void (*)(const AisArgs&, hipStream_t);
+// nchains = gridDim.y
+using AisLaunchFn = void (*)(const AisArgs&, hipStream_t, unsigned nchains);
 // pcx = prior class + 3 * (posterior kind - 1)
 AisLaunchFn find_ais_kernel(int cost_id, int D, int pcx);
 constexpr int kAisVariants = 9;
-void launch_ais_init(int D, const InitArgs& a, hipStream_t s);
+void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains);
 
 }  // namespace kabc

@@ -48,27 +48,27 @@ AisLaunchFn find_ais_kernel(int cost_id, int D, int pc) {
 }
 
 template <int D>
-static void launch_init_d(const InitArgs& a, hipStream_t s) {
+static void launch_init_d(const InitArgs& a, hipStream_t s, unsigned nchains) {
     const unsigned grid = (unsigned)((a.rows_owned + kInitBlock - 1) / kInitBlock);
     if (grid == 0) return;
-    hipLaunchKernelGGL((ais_init_kernel<D>), dim3(grid), dim3(kInitBlock), 0, s, a);
+    hipLaunchKernelGGL((ais_init_kernel<D>), dim3(grid, nchains), dim3(kInitBlock), 0, s, a);
 }
 
 template <int... Ds>
-static void launch_init_table(int D, const InitArgs& a, hipStream_t s,
+static void launch_init_table(int D, const InitArgs& a, hipStream_t s, unsigned nchains,
                               std::integer_sequence<int, Ds...>) {
-    using Fn = void (*)(const InitArgs&, hipStream_t);
+    using Fn = void (*)(const InitArgs&, hipStream_t, unsigned);
     static const Fn fns[] = {&launch_init_d<Ds + 1>...};
-    fns[D - 1](a, s);
+    fns[D - 1](a, s, nchains);
 }
 
-void launch_ais_init(int D, const InitArgs& a, hipStream_t s) {
+void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains) {
     if (const CostPlugin* p = find_plugin(a.cost_id)) {
-        using Fn = void (*)(const InitArgs&, hipStream_t);
-        if (Fn f = (Fn)p->ais_init(D)) f(a, s);
+        using Fn = void (*)(const InitArgs&, hipStream_t, unsigned);
+        if (Fn f = (Fn)p->ais_init(D)) f(a, s, nchains);
         return;
     }
-    launch_init_table(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+    launch_init_table(D, a, s, nchains, std::make_integer_sequence<int, KABC_MAX_DIM>{});
 }
 
 }  // namespace kabc
@@ -92,6 +92,9 @@ struct kabc_ais {
     int64_t rows_owned[2];
     int64_t per[2];        // rows per rank segment of each half (all-gather count / D)
     kabc_comm_t* comm;     // library-owned exchange (kabc_ais_create_dist), else NULL
+    int32_t nchains;       // independent ensembles in this handle (kabc_ais_create_batch), else 1
+    uint64_t* d_seeds;     // [nchains] (batch handles)
+    unsigned long long* d_chain_retries;  // [nchains]
     uint32_t id_base[2];   // global walker id of row 0 of each half
     double* d_half[2];     // global halves [rows[h]][D]
     bool own_halves;
@@ -131,9 +134,11 @@ static kabc_status_t check_handle(const kabc_ais_t* h) {
     return KABC_OK;
 }
 
-static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0, void* ext1) {
+static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0, void* ext1,
+                               const uint64_t* seeds) {
     kabc_ctx_t* ctx = h->ctx;
     const int world = h->world;
+    const size_t nch = (size_t)h->nchains;
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     if (m->cost.nparams > 0) {
@@ -149,15 +154,20 @@ static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0,
     for (int hf = 0; hf < 2; ++hf) {
         if (h->own_halves) {
             // padded to world equal segments so that the in-place all-gather has one count
-            const size_t nb = sizeof(double) * (size_t)(h->per[hf] * world) * h->D;
+            const size_t nb = sizeof(double) * (size_t)(h->per[hf] * world) * h->D * nch;
             KABC_HIP_CHECK(hipMalloc(&h->d_half[hf], nb));
             KABC_HIP_CHECK(hipMemsetAsync(h->d_half[hf], 0, nb, s));
         } else {
             h->d_half[hf] = (double*)(hf == 0 ? ext0 : ext1);
         }
-        const size_t nb = sizeof(double) * (size_t)(h->rows_owned[hf] > 0 ? h->rows_owned[hf] : 1);
+        const size_t nb = sizeof(double) * (size_t)(h->rows_owned[hf] > 0 ? h->rows_owned[hf] : 1) * nch;
         KABC_HIP_CHECK(hipMalloc(&h->d_lp[hf], nb));
         KABC_HIP_CHECK(hipMalloc(&h->d_ll[hf], nb));
+    }
+    if (seeds) {
+        KABC_HIP_CHECK(hipMalloc(&h->d_seeds, sizeof(uint64_t) * nch));
+        KABC_HIP_CHECK(hipMemcpyAsync(h->d_seeds, seeds, sizeof(uint64_t) * nch, hipMemcpyHostToDevice, s));
+        KABC_HIP_CHECK(hipMalloc(&h->d_chain_retries, sizeof(unsigned long long) * nch));
     }
     KABC_HIP_CHECK(hipMalloc(&h->d_counters, sizeof(DevCounters)));
     KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
@@ -171,7 +181,8 @@ static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0,
 
 static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, int64_t n_total,
                                        int32_t rank, int32_t world, uint64_t seed, void* ext0,
-                                       void* ext1, kabc_comm_t* comm, kabc_ais_t** out) {
+                                       void* ext1, kabc_comm_t* comm, kabc_ais_t** out,
+                                       int32_t nchains = 1, const uint64_t* seeds = nullptr) {
     if (!ctx || !m || !out || !m->prior) {
         set_error("kabc_ais_create: NULL argument");
         return KABC_ERR_INVALID_ARG;
@@ -244,6 +255,9 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->rank = rank;
     h->world = world;
     h->comm = comm;
+    h->nchains = nchains;
+    h->d_seeds = nullptr;
+    h->d_chain_retries = nullptr;
     for (int hf = 0; hf < 2; ++hf) {
         // caller-lent buffers: equal shards (n_total % (2 world) == 0 was checked); library-
         // owned exchange: ceil shards, the last ranks may own fewer rows or none
@@ -276,7 +290,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->own_halves = (ext0 == nullptr);
 
     // every early return below releases what was allocated so far
-    if (kabc_status_t st = ais_alloc(h, m, ext0, ext1)) {
+    if (kabc_status_t st = ais_alloc(h, m, ext0, ext1, seeds)) {
         (void)kabc_ais_destroy(h);
         return st;
     }
@@ -320,6 +334,16 @@ kabc_status_t kabc_ais_create(kabc_ctx_t* ctx, const kabc_model_t* model, int64_
     return ais_create_common(ctx, model, nparticles, 0, 1, seed, nullptr, nullptr, nullptr, out);
 }
 
+kabc_status_t kabc_ais_create_batch(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t nparticles,
+                                    int32_t nchains, const uint64_t* seeds, kabc_ais_t** out) {
+    if (nchains < 1 || nchains > 65535 || !seeds) {
+        set_error("kabc_ais_create_batch: nchains must be 1..65535 and seeds non-NULL");
+        return KABC_ERR_INVALID_ARG;
+    }
+    return ais_create_common(ctx, model, nparticles, 0, 1, seeds[0], nullptr, nullptr, nullptr, out,
+                             nchains, seeds);
+}
+
 kabc_status_t kabc_ais_create_sharded(kabc_ctx_t* ctx, const kabc_model_t* model, int64_t n_total,
                                       int32_t rank, int32_t world, uint64_t seed, void* dev_half0,
                                       void* dev_half1, kabc_ais_t** out) {
@@ -352,6 +376,8 @@ static kabc_status_t ais_init_enqueue(kabc_ais_t* h, int32_t retry_sampling) {
     hipStream_t s = h->ctx->stream;
     KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
     KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
+    if (h->d_chain_retries)
+        KABC_HIP_CHECK(hipMemsetAsync(h->d_chain_retries, 0, sizeof(unsigned long long) * h->nchains, s));
     for (int hf = 0; hf < 2; ++hf) {
         InitArgs a;
         std::memset(&a, 0, sizeof a);
@@ -374,7 +400,11 @@ static kabc_status_t ais_init_enqueue(kabc_ais_t* h, int32_t retry_sampling) {
                          (unsigned long long)(h->rows_owned[0] + h->rows_owned[1]);
         a.prior = h->prior;
         std::memcpy(a.raw, h->raw, sizeof a.raw);
-        launch_ais_init(h->D, a, s);
+        a.seeds = h->d_seeds;
+        a.chain_retries = h->d_chain_retries;
+        a.stride_act = h->rows[hf] * h->D;
+        a.stride_own = h->rows_owned[hf];
+        launch_ais_init(h->D, a, s, (unsigned)h->nchains);
         KABC_HIP_CHECK(hipGetLastError());
     }
     return KABC_OK;
@@ -511,6 +541,11 @@ kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntra
     a.reps = (h->posterior == KABC_POSTERIOR_COMMON) ? 1.0 : 1.0 / h->eps;
     a.box_lp = h->box_lp;
     a.prior = h->d_prior;
+    a.seeds = h->d_seeds;
+    a.stride_act = h->rows[half] * h->D;
+    a.stride_comp = h->rows[1 - half] * h->D;
+    a.stride_own = h->rows_owned[half];
+    a.stride_trace = h->N * h->D;
     {
         static const int ab = [] {
             const char* e = getenv("KABC_ABLATE");
@@ -530,7 +565,7 @@ kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntra
     const int64_t li = h->launch_index++;
     const bool t_on = h->timing && (h->ev_used + 2 <= h->ev.size());
     if (t_on && li % h->timing_stride == 0) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
-    h->launch(a, s);
+    h->launch(a, s, (unsigned)h->nchains);
     if (t_on && li % h->timing_stride == h->timing_stride - 1) {
         KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], s));
         h->ev_used += 2;
@@ -572,7 +607,7 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
     }
     KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
-    const int64_t gen_elems = h->N * h->D;
+    const int64_t gen_elems = h->N * h->D * h->nchains;  // [chain][N][D] per generation
     const size_t gen_bytes = sizeof(double) * (size_t)gen_elems;
     if (!out_samples || ngenerations == 0) {
         for (int64_t g = 0; g < ngenerations; ++g) {
@@ -737,11 +772,15 @@ kabc_status_t kabc_ais_get_ensemble(kabc_ais_t* h, double* x) {
     if (check_handle(h) || !x) return KABC_ERR_INVALID_ARG;
     KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
-    KABC_HIP_CHECK(hipMemcpyAsync(x, h->d_half[0], sizeof(double) * h->rows[0] * h->D,
-                                  hipMemcpyDeviceToHost, s));
+    const size_t W = sizeof(double), nch = (size_t)h->nchains;
+    // device pitch per chain: the (padded, for sharded handles) half buffer
+    const size_t p0 = W * (h->comm ? h->per[0] * h->world : h->rows[0]) * h->D;
+    const size_t p1 = W * (h->comm ? h->per[1] * h->world : h->rows[1]) * h->D;
+    KABC_HIP_CHECK(hipMemcpy2DAsync(x, W * h->N * h->D, h->d_half[0], p0, W * h->rows[0] * h->D, nch,
+                                    hipMemcpyDeviceToHost, s));
     if (h->rows[1] > 0)
-        KABC_HIP_CHECK(hipMemcpyAsync(x + h->rows[0] * h->D, h->d_half[1],
-                                      sizeof(double) * h->rows[1] * h->D, hipMemcpyDeviceToHost, s));
+        KABC_HIP_CHECK(hipMemcpy2DAsync(x + h->rows[0] * h->D, W * h->N * h->D, h->d_half[1], p1,
+                                        W * h->rows[1] * h->D, nch, hipMemcpyDeviceToHost, s));
     KABC_HIP_CHECK(hipStreamSynchronize(s));
     return KABC_OK;
 }
@@ -751,20 +790,25 @@ kabc_status_t kabc_ais_get_state(kabc_ais_t* h, double* x, double* logprior, dou
     if (check_handle(h)) return KABC_ERR_INVALID_ARG;
     KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
+    // one strided copy per half and array; height = chains (1 for an ordinary handle).  Host
+    // layout per chain: owned rows of half 0, then of half 1.
+    const size_t nch = (size_t)h->nchains, W = sizeof(double);
+    const int64_t n_own = h->rows_owned[0] + h->rows_owned[1];
     int64_t off = 0;
     for (int hf = 0; hf < 2; ++hf) {
         const int64_t n = h->rows_owned[hf];
         if (n > 0) {
             if (x)
-                KABC_HIP_CHECK(hipMemcpyAsync(x + off * h->D,
-                                              h->d_half[hf] + h->row_first[hf] * h->D,
-                                              sizeof(double) * n * h->D, hipMemcpyDeviceToHost, s));
+                KABC_HIP_CHECK(hipMemcpy2DAsync(x + off * h->D, W * n_own * h->D,
+                                                h->d_half[hf] + h->row_first[hf] * h->D,
+                                                W * h->rows[hf] * h->D, W * n * h->D, nch,
+                                                hipMemcpyDeviceToHost, s));
             if (logprior)
-                KABC_HIP_CHECK(hipMemcpyAsync(logprior + off, h->d_lp[hf], sizeof(double) * n,
-                                              hipMemcpyDeviceToHost, s));
+                KABC_HIP_CHECK(hipMemcpy2DAsync(logprior + off, W * n_own, h->d_lp[hf], W * n, W * n,
+                                                nch, hipMemcpyDeviceToHost, s));
             if (loglik)
-                KABC_HIP_CHECK(hipMemcpyAsync(loglik + off, h->d_ll[hf], sizeof(double) * n,
-                                              hipMemcpyDeviceToHost, s));
+                KABC_HIP_CHECK(hipMemcpy2DAsync(loglik + off, W * n_own, h->d_ll[hf], W * n, W * n,
+                                                nch, hipMemcpyDeviceToHost, s));
         }
         off += n;
     }
@@ -784,16 +828,19 @@ kabc_status_t kabc_ais_set_state(kabc_ais_t* h, const double* x, const double* l
     }
     KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
     hipStream_t s = h->ctx->stream;
+    const size_t nch = (size_t)h->nchains, W = sizeof(double);
+    const int64_t n_own = h->rows_owned[0] + h->rows_owned[1];
     int64_t off = 0;
     for (int hf = 0; hf < 2; ++hf) {
         const int64_t n = h->rows_owned[hf];
         if (n > 0) {
-            KABC_HIP_CHECK(hipMemcpyAsync(h->d_half[hf] + h->row_first[hf] * h->D, x + off * h->D,
-                                          sizeof(double) * n * h->D, hipMemcpyHostToDevice, s));
-            KABC_HIP_CHECK(hipMemcpyAsync(h->d_lp[hf], logprior + off, sizeof(double) * n,
-                                          hipMemcpyHostToDevice, s));
-            KABC_HIP_CHECK(hipMemcpyAsync(h->d_ll[hf], loglik + off, sizeof(double) * n,
-                                          hipMemcpyHostToDevice, s));
+            KABC_HIP_CHECK(hipMemcpy2DAsync(h->d_half[hf] + h->row_first[hf] * h->D,
+                                            W * h->rows[hf] * h->D, x + off * h->D, W * n_own * h->D,
+                                            W * n * h->D, nch, hipMemcpyHostToDevice, s));
+            KABC_HIP_CHECK(hipMemcpy2DAsync(h->d_lp[hf], W * n, logprior + off, W * n_own, W * n, nch,
+                                            hipMemcpyHostToDevice, s));
+            KABC_HIP_CHECK(hipMemcpy2DAsync(h->d_ll[hf], W * n, loglik + off, W * n_own, W * n, nch,
+                                            hipMemcpyHostToDevice, s));
         }
         off += n;
     }
@@ -863,6 +910,10 @@ double kabc_ais_kernel_ms(kabc_ais_t* h, int64_t* nlaunches) {
 
 kabc_status_t kabc_ais_set_debug(kabc_ais_t* h, int32_t ntransitions) {
     if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    if (h->nchains != 1 && ntransitions > 0) {
+        set_error("debug records are for single-chain handles");
+        return KABC_ERR_INVALID_ARG;
+    }
     KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
     if (h->d_dbg) (void)hipFree(h->d_dbg);
     h->d_dbg = nullptr;
@@ -901,6 +952,8 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h) {
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->d_prior) (void)hipFree(h->d_prior);
+    if (h->d_seeds) (void)hipFree(h->d_seeds);
+    if (h->d_chain_retries) (void)hipFree(h->d_chain_retries);
     for (int b = 0; b < kTraceBufs; ++b) {
         if (h->d_trace[b]) (void)hipFree(h->d_trace[b]);
         if (h->ev_filled[b]) (void)hipEventDestroy(h->ev_filled[b]);

@@ -8,7 +8,7 @@
 #define KABC_SMC_SINGLE_UNIT 1
 #include "host_common.hpp"
 #include "plugin_registry.hpp"
-#include "smc_kernels.hpp"
+#include "smc_loop_kernel.hpp"
 #include "abcde_kernels.hpp"
 #include "pfilter_kernels.hpp"
 
@@ -26,6 +26,39 @@ KABC_DECL_COST(8)
 KABC_DECL_COST(9)
 KABC_DECL_COST(10)
 KABC_DECL_COST(11)
+
+#define KABC_DECL_LOOP(id) SmcLoopLaunchFn find_smc_loop_kernel_cost_##id(int D, bool simple);
+KABC_DECL_LOOP(1)
+KABC_DECL_LOOP(2)
+KABC_DECL_LOOP(3)
+KABC_DECL_LOOP(4)
+KABC_DECL_LOOP(5)
+KABC_DECL_LOOP(6)
+KABC_DECL_LOOP(7)
+KABC_DECL_LOOP(8)
+KABC_DECL_LOOP(9)
+KABC_DECL_LOOP(10)
+KABC_DECL_LOOP(11)
+
+SmcLoopLaunchFn find_smc_loop_kernel(int cost_id, int D, bool simple) {
+    switch (cost_id) {
+        case 1: return find_smc_loop_kernel_cost_1(D, simple);
+        case 2: return find_smc_loop_kernel_cost_2(D, simple);
+        case 3: return find_smc_loop_kernel_cost_3(D, simple);
+        case 4: return find_smc_loop_kernel_cost_4(D, simple);
+        case 5: return find_smc_loop_kernel_cost_5(D, simple);
+        case 6: return find_smc_loop_kernel_cost_6(D, simple);
+        case 7: return find_smc_loop_kernel_cost_7(D, simple);
+        case 8: return find_smc_loop_kernel_cost_8(D, simple);
+        case 9: return find_smc_loop_kernel_cost_9(D, simple);
+        case 10: return find_smc_loop_kernel_cost_10(D, simple);
+        case 11: return find_smc_loop_kernel_cost_11(D, simple);
+        default: {
+            const CostPlugin* p = find_plugin(cost_id);
+            return (p && p->smc_loop) ? (SmcLoopLaunchFn)p->smc_loop(D, simple ? 1 : 0) : nullptr;
+        }
+    }
+}
 
 SmcLaunchFn find_smc_kernel(int cost_id, int D, bool simple) {
     switch (cost_id) {
@@ -316,17 +349,96 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     lpz.r_epstol = r_epstol;
     lpz.max_iterations = o->max_iterations > 0 ? o->max_iterations : 100000;
 
-    // The ε-loop is decided on the device (smc_pass_end_kernel / smc_iter_end_kernel);
-    // the host enqueues kBatch iterations and then reads the 128-byte control block
-    // once.  Kernels enqueued past the end of the loop are no-ops.
-    const int R = 1 + o->mcmc_retrys;
-    const int kGroup = 4;                        // retry passes enqueued between host checks
-    const int kBatch = (R <= kGroup) ? 16 : 1;   // iterations per host sync
     SmcCtrl hc;
     std::memset(&hc, 0, sizeof hc);
     kabc_status_t rc = KABC_OK;
+    const int R = 1 + o->mcmc_retrys;
+
+    // Path 1: the whole ε-loop as ONE persistent cooperative kernel (smc_loop_kernel.hpp) --
+    // one thread per particle, for ensembles whose alive mask fits in LDS.  KABC_SMC_LOOP=0
+    // selects the multi-kernel path below (also taken when the grid cannot be co-resident).
+    bool looped = false;
+    {
+        const char* env = std::getenv("KABC_SMC_LOOP");  // read per call: tests flip it
+        const bool allow = !(env && env[0] == '0');
+        const unsigned G = (unsigned)((N + kLoopBlock - 1) / kLoopBlock);
+        SmcLoopLaunchFn loop_fn =
+            (allow && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple) : nullptr;
+        if (loop_fn) {
+            SmcLoopScratch* lsc;
+            KABC_HIP_CHECK(bufs.alloc(&lsc, 1));
+            KABC_HIP_CHECK(hipMemsetAsync(lsc, 0, sizeof(SmcLoopScratch), s));
+            SmcLoopArgs la;
+            std::memset(&la, 0, sizeof la);
+            for (int b = 0; b < 2; ++b) {
+                la.theta[b] = th[b];
+                la.X[b] = X[b];
+                la.lpi[b] = lp[b];
+            }
+            la.alive = alive;
+            la.ctrl = ctrl;
+            la.scratch = lsc;
+            la.log = d_log;
+            la.log_cap = log_cap;
+            la.cost_params = d_params;
+            la.cost_data = d_data;
+            la.cost_ndata = cost->ndata;
+            la.N = N;
+            la.seed = o->seed;
+            la.max_stretch = o->max_stretch;
+            la.alpha = alpha;
+            la.min_r_ess = min_r_ess;
+            la.loop = lpz;
+            la.retry_n = R;
+            PriorDev* d_prior;
+            KABC_HIP_CHECK(bufs.alloc(&d_prior, (size_t)KABC_MAX_DIM));
+            KABC_HIP_CHECK(hipMemcpyAsync(d_prior, &P, sizeof(PriorSet), hipMemcpyHostToDevice, s));
+            la.prior = d_prior;
+            la.stamps = nullptr;
+            if (getenv("KABC_SMC_STAMPS")) {
+                KABC_HIP_CHECK(bufs.alloc(&la.stamps, 24));
+                KABC_HIP_CHECK(hipMemsetAsync(la.stamps, 0, 192, s));
+            }
+            KABC_HIP_CHECK(hipEventRecord(ev0, s));
+            const hipError_t le = loop_fn(la, G, s);
+            if (le == hipSuccess) {
+                KABC_HIP_CHECK(hipEventRecord(ev1, s));
+                KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+                KABC_HIP_CHECK(hipStreamSynchronize(s));
+                float ms = 0.f;
+                if (hc.pass > 0 && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+                    mcmc_ms = ms / (double)hc.pass;  // the whole loop per pass: there is no
+                    mcmc_timed = 1;                  // separate propose+accept kernel here
+                }
+                looped = true;
+                unsigned long long st[24];
+                if (la.stamps && hipMemcpy(st, la.stamps, 192, hipMemcpyDeviceToHost) == hipSuccess && st[8])
+                    fprintf(stderr, "[kabc smc loop, 10 ns ticks per iteration] publish %.0f B1 %.0f fold %.0f "
+                            "rounds %.0f gather %.0f B2 %.0f eps+mask %.0f mcmc %.0f | iterations %llu "
+                            "cand/iter %.1f predicted %llu barriers %.2f/iter | eps+mask split: loads+fold %.0f rank %.0f patch+scan %.0f | mcmc split: philox+select %.0f issue+pre %.0f wait %.0f logpdf %.0f cost+accept %.0f tail %.0f\n",
+                            (double)st[0] / st[8], (double)st[1] / st[8], (double)st[2] / st[8],
+                            (double)st[3] / st[8], (double)st[4] / st[8], (double)st[5] / st[8],
+                            (double)st[6] / st[8], (double)st[7] / st[8], st[8], (double)st[9] / st[8],
+                            st[10], (double)st[11] / st[8] / ((double)st[8] + 1) * 2.0, (double)st[12] / st[8],
+                            (double)st[13] / st[8], (double)st[14] / st[8], (double)st[16] / st[8], (double)st[17] / st[8],
+                            (double)st[18] / st[8], (double)st[19] / st[8], (double)st[20] / st[8], (double)st[7] / st[8]);
+            } else if (le != hipErrorCooperativeLaunchTooLarge) {
+                set_error("cooperative launch of the smc loop kernel failed: %s", hipGetErrorString(le));
+                return KABC_ERR_DEVICE;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+
+    // Path 2: one ε-iteration = select kernel + 1..R propose/accept kernels + a pass-end kernel.
+    // The ε-loop is decided on the device (smc_pass_end_kernel / smc_iter_end_kernel);
+    // the host enqueues kBatch iterations and then reads the 128-byte control block
+    // once.  Kernels enqueued past the end of the loop are no-ops.
+    const int kGroup = 4;                        // retry passes enqueued between host checks
+    const int kBatch = (R <= kGroup) ? 16 : 1;   // iterations per host sync
     bool first = true;
-    while (true) {
+    while (!looped) {
         for (int it = 0; it < kBatch; ++it) {
             KABC_HIP_CHECK(launch_select(sa, selG, s));
             bool ended = false;  // the iteration's end rode on the last pass_end launch
@@ -366,6 +478,14 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         if (hc.error == 1) {
             set_error("quantiles are undefined in presence of NaNs");
             rc = KABC_ERR_NAN_COST;
+        } else if (hc.error == 3) {
+            set_error("smc loop kernel: device-wide barrier timed out (the cooperative grid lost "
+                      "residency or the device is wedged)");
+            rc = KABC_ERR_DEVICE;
+        } else if (hc.error == 4) {
+            set_error("smc loop kernel: internal capacity exceeded (candidate list); rerun with "
+                      "KABC_SMC_LOOP=0");
+            rc = KABC_ERR_DEVICE;
         } else {
             set_error("collection must be non-empty");
             rc = KABC_ERR_INVALID_STATE;

@@ -134,13 +134,16 @@ inline bool prior_is_simple(int kind) {
 // push_p (src/types.jl:27-32) followed by logpdf(d::Factored, x) = left-to-right
 // sum over components (src/priors.jl:30-36).  xp receives push_p(x).
 // P: the prepared components (in LDS on the hot path).
-template <int D, bool SIMPLE = false>
+// FENCED: a scheduling fence per component (the AIS consumer needs it to stay inside its
+// register budget); without it the compiler hoists the components' parameter reads and their
+// latencies overlap (smc_loop_kernel: 2.3 -> ... us for 16 components read from LDS)
+template <int D, bool SIMPLE = false, bool FENCED = true>
 __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restrict__ P,
                                                        const double* x, double* xp) {
     double s = 0.0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);
         const PriorDev& q = P[k];
         // the prior is the same for every lane: kind / discrete as SCALARS make the family
         // dispatch a uniform branch instead of an exec-masked walk through every case
@@ -169,6 +172,15 @@ constexpr int cost_aux_c(int cost) {
     return cost == KABC_COST_NORMAL_MEANSTD_SIM ? 2 : cost >= KABC_COST_USER ? KABC_USER_AUX_WORDS_OR_0 : 0;
 }
 static_assert(KABC_USER_AUX_WORDS_OR_0 <= KABC_COST_MAX_AUX, "KABC_USER_AUX_WORDS too large");
+
+// leading blocks of a cost's stream that are consumed as normal pairs (kabc_cost_rng_normal2)
+// whatever the parameters: these can be expanded ahead of the cost evaluation
+// (KABC_RNG_PREFETCH, include/kabc_philox.h)
+constexpr int cost_pre_blocks(int cost, int D) {
+    return cost == KABC_COST_HIER_GAUSS_SIM ? (D - 2 + 1) / 2
+         : (cost == KABC_COST_NOISY_QUAD_DU || cost == KABC_COST_MIXTURE ||
+            cost == KABC_COST_NOISY_BANANA) ? 1 : 0;
+}
 
 // compile-time cost dispatch on the DeviceCost id (formulas: include/kabc_costs.h)
 template <int COST, int D>

@@ -31,9 +31,18 @@ def _cases(k):
     }
 
 
+@pytest.fixture(params=["loop", "kernels"])
+def smc_path(request, monkeypatch):
+    """Both device drivers of the ε-loop: the persistent cooperative kernel
+    (csrc/smc_loop_kernel.hpp, the default up to 65 536 particles) and the
+    kernel-per-phase path (KABC_SMC_LOOP=0; larger ensembles)."""
+    monkeypatch.setenv("KABC_SMC_LOOP", "1" if request.param == "loop" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["banana", "banana_inf", "dirac", "defaults_du",
                                   "mixture_retrys", "C4_hier16_small", "gauss_d2_minress"])
-def test_smc_bit_exact(k, orc, gpu_ctx, name):
+def test_smc_bit_exact(k, orc, gpu_ctx, name, smc_path):
     prior, cost, kw = _cases(k)[name]
     got = k.smc(prior, cost, seed=5, return_array=True, **kw)
     ref = orc.smc(prior, cost, seed=5, **kw)
@@ -63,12 +72,15 @@ def test_smc_argument_errors_match_reference(k, gpu_ctx):
         assert str(e.value) == msg
 
 
-@pytest.mark.parametrize("blocks", [None, "1", "32"])
-def test_c4_full_size_bit_exact(k, orc, gpu_ctx, monkeypatch, blocks):
+@pytest.mark.parametrize("path,blocks", [("loop", None), ("kernels", None), ("kernels", "1"),
+                                         ("kernels", "32")])
+def test_c4_full_size_bit_exact(k, orc, gpu_ctx, monkeypatch, path, blocks):
     """BASELINE.json configs[3] at full size (32 768 particles, D = 16, hierarchical
     Gaussian simulator, ~190 ε-iterations): θ of every particle, ε and the iteration
-    log equal the oracle's bit for bit -- with the select kernel on its default 16
-    workgroups, on one, and on 32."""
+    log equal the oracle's bit for bit -- on the persistent loop kernel, and on the
+    kernel-per-phase path with the select kernel on its default 16 workgroups, on one,
+    and on 32."""
+    monkeypatch.setenv("KABC_SMC_LOOP", "1" if path == "loop" else "0")
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -85,6 +97,36 @@ def test_c4_full_size_bit_exact(k, orc, gpu_ctx, monkeypatch, blocks):
     assert r.eps == ro["eps"] and np.array_equal(r.info["theta_all"], ro["theta_all"])
     assert [it["eps"] for it in r.info["log"]] == [it["eps"] for it in ro["log"]]
     assert [it["ess"] for it in r.info["log"]] == [it["ess"] for it in ro["log"]]
+    assert np.array_equal(r.info["alive"], ro["alive"]) and np.array_equal(r.C, ro["C"])
+    assert r.info["cost_evals"] == ro["cost_evals"] and r.info["proposals"] == ro["proposals"]
+
+
+def test_loop_kernel_many_sizes(k, orc, gpu_ctx, monkeypatch):
+    """The persistent kernel's selection machinery away from the happy path: particle
+    counts that are not multiples of 256 or 64, one workgroup, heavy ties (discrete
+    costs), α small (large resample ratios), no resampling at all."""
+    monkeypatch.setenv("KABC_SMC_LOOP", "1")
+    N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    du = k.Factored(k.DiscreteUniform(-20, 20), k.DiscreteUniform(-20, 20))
+    cases = [
+        (N2, k.costs.GaussDist([1.0, -0.5]), dict(nparticles=37, alpha=0.9, epstol=0.05)),
+        (N2, k.costs.GaussDist([1.0, -0.5]), dict(nparticles=257, alpha=0.5, min_r_ess=0.2, epstol=0.05)),
+        (N2, k.costs.GaussDist([1.0, -0.5]), dict(nparticles=5000, alpha=0.3, min_r_ess=0.05, epstol=0.01)),
+        (N2, k.costs.GaussDist([1.0, -0.5]), dict(nparticles=65536, alpha=0.95, epstol=0.2)),
+        (du, k.costs.GaussDist([3.0, -2.0]), dict(nparticles=9001, alpha=0.8, epstol=0.5)),
+        (du, k.costs.GaussDist([3.0, -2.0]), dict(nparticles=1000, alpha=0.99, min_r_ess=0.01, epstol=0.5)),
+        (N2, k.costs.NoisyBanana(0.5), dict(nparticles=777, alpha=0.9, epstol=0.01, mcmc_retrys=3,
+                                            mcmc_tol=0.3)),
+    ]
+    for prior, cost, kw in cases:
+        for seed in (1, 2):
+            got = k.smc(prior, cost, seed=seed, return_array=True, **kw)
+            ref = orc.smc(prior, cost, seed=seed, **kw)
+            assert got.info["log"] == ref["log"], (kw, seed)
+            assert got.eps == ref["eps"] and np.array_equal(got.info["alive"], ref["alive"])
+            assert np.array_equal(got.info["theta_all"], ref["theta_all"])
+            assert np.array_equal(got.C, ref["C"])
+            assert got.info["cost_evals"] == ref["cost_evals"]
 
 
 _C4_ORACLE = {}
