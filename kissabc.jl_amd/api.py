@@ -124,22 +124,31 @@ class AIS:
 class MCMCThreads:
     """Tag for independent chains (AbstractMCMC.MCMCThreads, re-exported at
     src/KissABC.jl:9,175).  On this path chains are independent ensembles with
-    distinct seeds run one after the other on the device."""
+    distinct seeds advanced TOGETHER: chain is a grid dimension of every launch."""
 
 
 class AisEnsemble:
     """kabc_ais_t: the device-resident AISState (src/KissABC.jl:25-33)."""
 
-    def __init__(self, model, nparticles, seed=0, ctx=None, sharded=None, comm=None):
+    def __init__(self, model, nparticles, seed=0, ctx=None, sharded=None, comm=None, seeds=None):
+        """`seeds` (a sequence) makes a BATCH handle: len(seeds) independent ensembles of
+        `nparticles` walkers, chain = a grid dimension of every launch (kabc_ais_create_batch);
+        state / trace arrays gain a leading chain axis."""
         self.model = model
         self.comm = comm
+        self.nchains = 1 if seeds is None else len(seeds)
+        self.batched = seeds is not None
         self.ctx = comm.ctx if comm is not None else (ctx or _lib.default_context())
         self.N = int(nparticles)
         self.D = len(model)
         self._cmodel = model.to_c()
         self._h = C.c_void_p()
         lib = _lib.load()
-        if comm is not None:
+        if seeds is not None:
+            arr = (C.c_uint64 * len(seeds))(*[int(v) & (2 ** 64 - 1) for v in seeds])
+            _lib.check(lib.kabc_ais_create_batch(self.ctx.handle, C.byref(self._cmodel), self.N,
+                                                 len(seeds), arr, C.byref(self._h)))
+        elif comm is not None:
             # walker-sharded over the communicator's ranks; the library owns the exchange
             _lib.check(lib.kabc_ais_create_dist(comm.handle, C.byref(self._cmodel), self.N,
                                                 int(seed), C.byref(self._h)))
@@ -160,12 +169,14 @@ class AisEnsemble:
 
     # step(rng, model, spl, state; ntransitions) x N x ngenerations -- src/KissABC.jl:66-80
     def advance(self, ngenerations, ntransitions=1, collect=False, out=None):
-        """`collect=True` returns the sample trace [generation][walker][D]; `out` may
-        supply its buffer (C-contiguous float64, e.g. from _lib.pinned_empty)."""
+        """`collect=True` returns the sample trace [generation][walker][D]
+        ([generation][chain][walker][D] for a batch handle); `out` may supply its buffer
+        (C-contiguous float64, e.g. from _lib.pinned_empty)."""
         lib = _lib.load()
         ptr = None
         if collect or out is not None:
-            shape = (int(ngenerations), self.N, self.D)
+            shape = ((int(ngenerations), self.nchains, self.N, self.D) if self.batched
+                     else (int(ngenerations), self.N, self.D))
             if out is None:
                 out = _lib.pinned_empty(shape)
             if out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous:
@@ -187,9 +198,10 @@ class AisEnsemble:
 
     def state(self):
         n = self.owned[0] + self.owned[1]
-        x = np.empty((n, self.D))
-        lp = np.empty(n)
-        ll = np.empty(n)
+        lead = (self.nchains,) if self.batched else ()
+        x = np.empty(lead + (n, self.D))
+        lp = np.empty(lead + (n,))
+        ll = np.empty(lead + (n,))
         t = C.c_uint64()
         _lib.check(_lib.load().kabc_ais_get_state(
             self._h, x.ctypes.data_as(cd.c_double_p), lp.ctypes.data_as(cd.c_double_p),
@@ -212,7 +224,7 @@ class AisEnsemble:
     def ensemble(self):
         """[N][D] unrounded positions of ALL walkers in walker-id order (for a sharded
         handle: this rank's copy after the last all-gather)."""
-        x = np.empty((self.N, self.D))
+        x = np.empty(((self.nchains,) if self.batched else ()) + (self.N, self.D))
         _lib.check(_lib.load().kabc_ais_get_ensemble(self._h, x.ctypes.data_as(cd.c_double_p)))
         return x
 
@@ -247,6 +259,12 @@ class AisEnsemble:
             pass
 
 
+def chain_seeds(seed, nchains):
+    """The per-chain seeds sample(..., MCMCThreads(), Ns, Nc) derives from `seed`
+    (AbstractMCMC seeds each chain from the parent rng; here: a golden-ratio stride)."""
+    return [(int(seed) + 0x9E3779B97F4A7C15 * (c + 1)) % (1 << 63) for c in range(int(nchains))]
+
+
 def _bundle(samples, scalar):
     """bundle_samples (src/KissABC.jl:82-94): [Ns][D] -> one Particles per parameter."""
     P = [Particles(samples[:, k]) for k in range(samples.shape[1])]
@@ -265,12 +283,27 @@ def sample(model, spl, *args, ntransitions=1, discard_initial=0, retry_sampling=
     if not isinstance(spl, AIS):
         raise TypeError("sampler must be AIS(nparticles)")
     if args and isinstance(args[0], MCMCThreads):
+        # chains are a grid dimension of ONE device handle: every launch advances all Nc
+        # ensembles (kabc_ais_create_batch); chain c is bit-identical to a single-chain run
+        # with its seed
         _, Ns, Nc = args
-        chains = [sample(model, spl, int(Ns), ntransitions=ntransitions,
-                         discard_initial=discard_initial, retry_sampling=retry_sampling,
-                         seed=int(seed) + 0x9E3779B97F4A7C15 * (c + 1) % (1 << 63), ctx=ctx,
-                         return_array=True) for c in range(int(Nc))]
-        stacked = np.concatenate(chains, axis=0)  # chainsstack, src/KissABC.jl:96-104
+        Ns, Nc, N, D = int(Ns), int(Nc), spl.nparticles, len(model)
+        seeds = chain_seeds(seed, Nc)
+        ens = AisEnsemble(model, N, ctx=ctx, seeds=seeds)
+        gk = max(1, -(-Ns // N))
+        pool = concurrent.futures.ThreadPoolExecutor(1)
+        buf = pool.submit(_lib.pinned_empty, (gk, Nc, N, D))
+        try:
+            ens.init(retry_sampling)
+            gd = -(-int(discard_initial) // N)
+            if gd:
+                ens.advance(gd, ntransitions)
+            tr = ens.advance(gk, ntransitions, out=buf.result())        # [gk][Nc][N][D]
+            chains = np.ascontiguousarray(tr.transpose(1, 0, 2, 3)).reshape(Nc, gk * N, D)[:, :Ns]
+        finally:
+            pool.shutdown(wait=True)
+            ens.close()
+        stacked = chains.reshape(Nc * Ns, D)  # chainsstack, src/KissABC.jl:96-104
         return stacked if return_array else _bundle(stacked, model.scalar)
     (Ns,) = args
     Ns = int(Ns)
