@@ -1,0 +1,109 @@
+"""BASELINE.md §3 / north star: "posterior means within 1e-3 of the reference" on C3
+(65 536 walkers x 8-param Rosenbrock-like cost, ApproxKernelizedPosterior scale 1.0).
+
+Left : the device path (red/black generation schedule), 65 536 walkers.
+Right: `ref_serial`, the oracle's faithful restatement of the reference's SERIAL schedule
+       (src/KissABC.jl:66-80 + src/transition.jl), as independent chains of 2048 walkers on
+       the host cores of the GPU box (the MCMCThreads analogue; the stretch move is exact
+       for any ensemble size, so a smaller ensemble only mixes differently).
+The two run different schedules on different random streams: agreement of the posterior
+means in every coordinate is a statement about the sampled distribution.
+
+This posterior is slow: started from the prior the last coordinate needs ~40 000
+transitions per walker to equilibrate, and the mean of all 65 536 walkers over 16 000
+transitions still fluctuates by 1.5e-3.  A comparison at 1e-3 therefore costs ~6e10
+serial transitions -- ten minutes of this box's host (its ~150 M transitions/s against the
+device's 20 G/s):
+
+  * KABC_LONG_TESTS=1: both sides from the prior, 40 000 transitions discarded, 200 000
+    (serial) / 600 000 (device) kept; tolerance 1e-3 flat.  The round-2 run is committed as
+    profiles/r02_c3_vs_ref_serial.txt: max |diff| 2.8e-4.
+  * default (~1.5 min): the device equilibrates the ensemble (40 000 transitions, 0.15 s)
+    and hands each serial chain a disjoint slice of it as its starting AISState, so the
+    serial side spends everything on sampling (25 000 transitions per walker); each
+    coordinate must agree within max(1e-3, 3.5 standard errors of the difference), the
+    standard errors estimated from the spread of the chain means / device block means
+    (~4e-4 for the slowest coordinate, so the bound is 1e-3 for most and ~1.4e-3 for it)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LONG = os.environ.get("KABC_LONG_TESTS") == "1"
+
+WORKER = r"""
+import sys, json
+import numpy as np
+sys.path.insert(0, {root!r})
+import kissabc_jl_amd as k
+from oracle import oracle as orc
+model = k.ApproxKernelizedPosterior(k.Factored(*[k.Uniform(-5, 5)] * 8), k.costs.Rosenbrock(), 1.0)
+Nw, nt, seed, sweeps, burn, start = 2048, 100, {seed}, {sweeps}, {burn}, {start!r}
+o = orc.OracleAIS(model, Nw, seed=seed).init()
+if start:
+    st = np.load(start)
+    o.set_state(st["x"], st["lp"], st["ll"], 0)
+if burn:
+    o.steps_serial(Nw * burn, nt, collect=False)
+tot = np.zeros(8); n = 0
+for _ in range(sweeps):
+    s = o.steps_serial(Nw, nt)
+    tot += s.sum(0); n += s.shape[0]
+print(json.dumps(dict(sum=tot.tolist(), n=n)))
+"""
+
+
+def test_c3_posterior_means_match_ref_serial(k, gpu_ctx, tmp_path):
+    procs = max(4, min(128, len(os.sched_getaffinity(0))))
+    model = k.ApproxKernelizedPosterior(k.Factored(*[k.Uniform(-5, 5)] * 8), k.costs.Rosenbrock(), 1.0)
+    N, nt, Nw = 65536, 100, 2048
+    ens = k.AisEnsemble(model, N, seed=1).init()
+    ens.advance(400, nt)                                   # 40 000 transitions per walker discarded
+    starts = [""] * procs
+    if not LONG:
+        x, lp, ll, _ = ens.state()
+        x, lp, ll = (np.concatenate([a] * (-(-procs * Nw // N))) for a in (x, lp, ll))
+        perm = np.random.default_rng(5).permutation(N)     # a chain = a random subset of the ensemble
+        x[:N], lp[:N], ll[:N] = x[perm], lp[perm], ll[perm]
+        for p in range(procs):
+            starts[p] = str(tmp_path / f"start{p}.npz")
+            sl = slice(p * Nw, (p + 1) * Nw)
+            np.savez(starts[p], x=x[sl], lp=lp[sl], ll=ll[sl])
+    sweeps, burn = (2000, 400) if LONG else (250, 0)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    ws = [subprocess.Popen([sys.executable, "-c",
+                            WORKER.format(root=ROOT, seed=1000 + p, sweeps=sweeps, burn=burn, start=starts[p])],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+          for p in range(procs)]
+    # the device side samples while the host chains work: every 10th generation is kept
+    blocks = []
+    for _ in range(60 if LONG else 30):
+        s = np.zeros(8)
+        for _ in range(10):
+            ens.advance(9, nt)
+            s += ens.advance(1, nt, collect=True).reshape(-1, 8).mean(0)
+        blocks.append(s / 10)
+    ens.close()
+    blocks = np.array(blocks)
+    dev_mean, dev_se = blocks.mean(0), blocks.std(0, ddof=1) / np.sqrt(len(blocks))
+    chain_means, ref_n = [], 0
+    for w in ws:
+        out, err = w.communicate(timeout=3000)
+        assert w.returncode == 0, err[-2000:]
+        d = json.loads(out.strip().splitlines()[-1])
+        chain_means.append(np.array(d["sum"]) / d["n"])
+        ref_n += d["n"]
+    chain_means = np.array(chain_means)
+    ref_mean, ref_se = chain_means.mean(0), chain_means.std(0, ddof=1) / np.sqrt(procs)
+    se = np.sqrt(dev_se ** 2 + ref_se ** 2)
+    tol = np.full(8, 1e-3) if LONG else np.maximum(1e-3, 3.5 * se)
+    diff = dev_mean - ref_mean
+    print(f"device mean {dev_mean}\nserial mean {ref_mean}\ndiff {diff}\nse of diff {se}\ntolerance {tol}\n"
+          f"({procs} host chains x {sweeps} sweeps = {ref_n} serial samples)")
+    assert ref_n == procs * sweeps * Nw
+    assert np.all(np.abs(diff) < tol)

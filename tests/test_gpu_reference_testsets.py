@@ -1,6 +1,7 @@
 """-m gpu: the reference's own statistical testsets (test/runtests.jl), run through the
 product API on the device.  `x ≈ c` is MonteCarloMeasurements' comparison,
-|mean - c| < 2 std (Particles.isapprox)."""
+|mean - c| < 2 std (Particles.isapprox) -- the reference's criterion, nothing weaker.  (The
+same testsets on the reference's SERIAL schedule: tests/test_oracle_reference_testsets_serial.py.)"""
 import numpy as np
 import pytest
 
@@ -12,7 +13,7 @@ def test_normal_to_dirac(k, gpu_ctx):
     abc = k.ApproxKernelizedPosterior(k.Normal(1, 0.2), k.costs.DiracSq(1.5), 0.001)
     res = k.sample(abc, k.AIS(12), 500, discard_initial=1000, seed=1)
     sim = k.Particles(np.asarray(res) ** 2 + 1)
-    assert sim.isapprox(1.5) or abs(sim.mean() - 1.5) < 5e-3
+    assert sim.isapprox(1.5)
     P = k.smc(k.Normal(1, 0.2), k.costs.DiracSq(1.5), epstol=0.1, seed=1).P
     assert P.isapprox(0.707)
 
@@ -24,7 +25,7 @@ def test_normal_plus_discrete_uniform(k, gpu_ctx):
     res = k.sample(model, k.AIS(100), 1000, discard_initial=10000, seed=1, return_array=True)
     assert np.array_equal(res[:, 1], np.rint(res[:, 1]))
     sim = k.Particles((res[:, 0] ** 2 + res[:, 1]) * res[:, 0])
-    assert sim.isapprox(5.5) or abs(sim.mean() - 5.5) < 0.02
+    assert sim.isapprox(5.5)
     assert k.smc(pri, k.costs.NoisyQuadDU(5.5), seed=1).P[1].isapprox(5)
 
 
@@ -64,7 +65,7 @@ def test_issue_10(k, gpu_ctx):
     # test/runtests.jl:177-182
     plan = k.ApproxPosterior(k.Normal(0, 1), k.costs.AbsDiff(1.5), 0.01)
     res = k.sample(plan, k.AIS(20), 100, discard_initial=2000, seed=1)
-    assert res.isapprox(1.5) or abs(res.mean() - 1.5) < 0.01
+    assert res.isapprox(1.5)
 
 
 def test_four_dim_shell_with_chains(k, gpu_ctx):
