@@ -128,17 +128,16 @@ static unsigned select_blocks(int64_t N) {
     if (g > kSelMaxBlocks) g = kSelMaxBlocks;
     return g < 1 ? 1u : (unsigned)g;
 }
-// The kernel's device-wide barrier needs its G <= 32 workgroups resident at the same
-// time.  They are launched as an ordinary grid: on this stream the previous kernel has
-// completed, 32 workgroups occupy 16 of 256 CUs, and a workgroup that has to wait for a
-// CU held by another stream's kernel only delays the barrier (that kernel does not wait
-// for us).  hipLaunchCooperativeKernel would guarantee residency but costs ~20 us per
-// launch here (measured: C4 went from 14.2 to 16.1 ms with it); KABC_SMC_COOPERATIVE=1
-// selects it anyway.
+// The kernel's device-wide barrier needs its G <= 32 workgroups resident at the same time:
+// for G > 1 it is launched with hipLaunchCooperativeKernel, which guarantees co-residency or
+// fails with an error (another process / stream holding the CUs cannot leave the grid half
+// resident and spinning).  The guarantee costs ~20 us per launch (measured: C4 on this path
+// 14.2 -> 16.1 ms); KABC_SMC_COOPERATIVE=0 selects an ordinary launch for timing experiments
+// -- the barrier's spin is bounded either way (sel_grid_barrier).
 static hipError_t launch_select(const SmcSelectArgs& sa, unsigned G, hipStream_t s) {
     static const bool coop = [] {
         const char* e = std::getenv("KABC_SMC_COOPERATIVE");
-        return e && e[0] == '1';
+        return !(e && e[0] == '0');
     }();
     if (G <= 1u || !coop) {
         hipLaunchKernelGGL(smc_select_kernel, dim3(G), dim3(kSelBlock), 0, s, sa);
@@ -479,8 +478,8 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
             set_error("quantiles are undefined in presence of NaNs");
             rc = KABC_ERR_NAN_COST;
         } else if (hc.error == 3) {
-            set_error("smc loop kernel: device-wide barrier timed out (the cooperative grid lost "
-                      "residency or the device is wedged)");
+            set_error("smc: a device-wide barrier timed out (the cooperative grid lost residency "
+                      "or the device is wedged)");
             rc = KABC_ERR_DEVICE;
         } else if (hc.error == 4) {
             set_error("smc loop kernel: internal capacity exceeded (candidate list); rerun with "
@@ -747,6 +746,11 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
             KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipMemcpyAsync(&hsel, sel, sizeof hsel, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipStreamSynchronize(s));
+            if (hsel.error == 3) {
+                set_error("pfilter: a device-wide barrier timed out (the cooperative grid lost "
+                          "residency or the device is wedged)");
+                return KABC_ERR_DEVICE;
+            }
             if (hsel.error) {
                 set_error("pfilter: quantile of the costs is undefined (NaN or empty)");
                 return KABC_ERR_NAN_COST;

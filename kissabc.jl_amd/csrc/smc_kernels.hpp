@@ -73,6 +73,7 @@ constexpr int kSelMaxBlocks = 32;   // workgroups of the select kernel
 struct SmcSelScratch {
     unsigned int bar_count, pad0[31];
     unsigned int bar_gen, pad1[31];
+    unsigned int bar_abort, pad3[31];
     unsigned int ncand, pad2[31];
     unsigned int hist[kSelRounds][kSelBins];
     unsigned long long part_stats[kSelMaxBlocks][4];
@@ -252,11 +253,18 @@ __device__ __forceinline__ void for_each_alive(const uint8_t* __restrict__ alive
 // them are resident).  Sense-reversing: one atomic per workgroup, thread 0 spins on the
 // generation word; 2.4 us at 32 x 1024 threads, about a kernel boundary (cooperative
 // groups' grid.sync() is 5.1 us; tools/gridsync_probe.hip).  G == 1: __syncthreads.
-__device__ __forceinline__ void sel_grid_barrier(SmcSelScratch* g, unsigned G) {
+// Residency: launch_select (capi_smc.hip) uses hipLaunchCooperativeKernel whenever G > 1, so
+// all G workgroups are co-resident or the launch fails with an error.  The spin is bounded all
+// the same (5 s of s_memrealtime): on time-out the abort word is set, every workgroup leaves
+// the kernel, and kabc_smc_run / kabc_pfilter_run return KABC_ERR_DEVICE instead of hanging.
+__device__ __forceinline__ bool sel_grid_barrier(SmcSelScratch* g, unsigned G) {
+    __shared__ int s_ok;
     __syncthreads();
     if (G > 1u) {
         if (threadIdx.x == 0) {
+            int ok = 1;
             volatile unsigned* gen = &g->bar_gen;
+            volatile unsigned* ab = &g->bar_abort;
             const unsigned my = *gen;
             __threadfence();
             if (atomicAdd(&g->bar_count, 1u) == G - 1u) {
@@ -264,13 +272,36 @@ __device__ __forceinline__ void sel_grid_barrier(SmcSelScratch* g, unsigned G) {
                 __threadfence();
                 atomicAdd(&g->bar_gen, 1u);
             } else {
-                while (*gen == my) __builtin_amdgcn_s_sleep(1);
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                unsigned spins = 0;
+                while (*gen == my) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023u) == 0u &&
+                        (*ab || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull)) {  // 5 s @ 100 MHz
+                        atomicExch(&g->bar_abort, 1u);
+                        ok = 0;
+                        break;
+                    }
+                }
             }
+            if (*ab) ok = 0;
             __threadfence();
+            s_ok = ok;
         }
         __syncthreads();
+        return s_ok != 0;
     }
+    return true;
 }
+// every use: a timed-out barrier ends the kernel (uniformly: all workgroups see the abort word)
+#define KABC_SEL_BARRIER(g, G)                                   \
+    if (!sel_grid_barrier(g, G)) {                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {               \
+            A.ctrl->error = 3;                                   \
+            A.ctrl->done = 1;                                    \
+        }                                                        \
+        return;                                                  \
+    }
 
 // ε-selection, alive mask, ESS, resample decision and index -- G workgroups of 1024
 // (G = 1 for small N).  Every pass over the particles is split by contiguous slices;
@@ -375,7 +406,7 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
             p[2] = kmin;
             p[3] = kmaxn;
         }
-        sel_grid_barrier(g, G);
+        KABC_SEL_BARRIER(g, G)
         n = nn = 0;
         kmin = kmaxn = ~0ull;
         for (unsigned b = 0; b < G; ++b) {  // G <= 32: every thread reads them all
@@ -433,7 +464,7 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         unsigned c = hist[tid];
         if (G > 1u) {  // fold the workgroups' histograms in global scratch (pre-zeroed)
             if (c) atomicAdd(&g->hist[round][tid], c);
-            sel_grid_barrier(g, G);
+            KABC_SEL_BARRIER(g, G)
             c = g->hist[round][tid];
         }
         rounds_used = round + 1;
@@ -488,7 +519,7 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
             if (tid == 0) s_base = mine ? atomicAdd(&g->ncand, mine) : 0u;
             __syncthreads();
             for (unsigned q = tid; q < mine; q += kSelBlock) g->cand[s_base + q] = cand[q];
-            sel_grid_barrier(g, G);
+            KABC_SEL_BARRIER(g, G)
             const unsigned all = g->ncand;  // == s_nrange <= kSelCand
             for (unsigned q = tid; q < all; q += kSelBlock) cand[q] = g->cand[q];
             if (tid == 0) s_ncand = all;
@@ -601,7 +632,7 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
             kgt = block_min_u64(kgt, sh_u);
             if (G > 1u) {
                 if (tid == 0) g->part_kgt[bid] = kgt;
-                sel_grid_barrier(g, G);
+                KABC_SEL_BARRIER(g, G)
                 kgt = ~0ull;
                 for (unsigned b = 0; b < G; ++b) kgt = g->part_kgt[b] < kgt ? g->part_kgt[b] : kgt;
             }
@@ -637,7 +668,7 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
     long long base = 0, ESS = mycnt;
     if (G > 1u) {
         if (tid == 0) g->slice_cnt[bid] = (unsigned)mycnt;
-        sel_grid_barrier(g, G);
+        KABC_SEL_BARRIER(g, G)
         ESS = 0;
         for (unsigned b = 0; b < G; ++b) {
             const long long cb = (long long)g->slice_cnt[b];
