@@ -28,7 +28,12 @@ extern "C" {
 #endif
 
 #define KABC_VERSION 200 /* 0.2.0 */
-#define KABC_MAX_DIM 16  /* compile-time upper bound on length(prior) on the device path */
+#define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
+/* AIS accepts length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM a run-time-dimension
+ * kernel keeps the walker rows in memory (several times slower per evaluation, same results).
+ * smc / ABCDE / pfilter and user cost plugins stop at KABC_MAX_DIM.  The reference has no
+ * bound (src/priors.jl:10-13). */
+#define KABC_MAX_DIM_DYN 256
 
 typedef enum kabc_status {
     KABC_OK = 0,
@@ -83,7 +88,7 @@ typedef enum kabc_posterior_kind {
 /* ApproxKernelizedPosterior(prior, cost, scale) / ApproxPosterior(prior, cost, maxcost) */
 typedef struct kabc_model {
     const kabc_prior_t* prior; /* D components */
-    int32_t D;                 /* length(prior), 1..KABC_MAX_DIM */
+    int32_t D;                 /* length(prior), 1..KABC_MAX_DIM (AIS: ..KABC_MAX_DIM_DYN) */
     int32_t posterior;         /* kabc_posterior_kind_t */
     double eps;                /* scale (kernelized) or maxcost (threshold) */
     kabc_cost_t cost;

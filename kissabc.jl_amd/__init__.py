@@ -14,14 +14,14 @@ from . import comm
 from .comm import Comm, EnsembleGroup
 from .costs import DeviceCost
 from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, LogNormal,
-                            NegativeBinomial, Normal, Truncated, TruncatedNormal, Uniform,
-                            truncated)
+                            MultivariateNormal, MvNormal, NegativeBinomial, Normal, Product, Truncated,
+                            TruncatedNormal, Uniform, truncated)
 
 __all__ = [
     "ABCDE", "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "CommonLogDensity",
     "MCMCThreads", "pfilter",
     "Particles", "sample", "smc", "DeviceCost", "costs", "Factored", "Uniform", "Normal",
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
-    "Exponential", "Gamma", "LogNormal", "Context", "KabcError", "default_context", "LIB_PATH",
+    "Exponential", "Gamma", "LogNormal", "Product", "MvNormal", "MultivariateNormal", "Context", "KabcError", "default_context", "LIB_PATH",
     "KABC_MAX_DIM", "comm", "Comm", "EnsembleGroup",
 ]

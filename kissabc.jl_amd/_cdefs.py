@@ -6,6 +6,7 @@ oracle's test binding (oracle/oracle.py).  Nothing here computes anything.
 import ctypes as C
 
 KABC_MAX_DIM = 16
+KABC_MAX_DIM_DYN = 256   # AIS only: run-time-dimension kernels beyond KABC_MAX_DIM
 KABC_VERSION = 200   # include/kabc.h
 KABC_COMM_ID_BYTES = 128
 KABC_COMM_MAX_WORLD = 16

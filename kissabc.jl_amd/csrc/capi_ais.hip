@@ -8,7 +8,7 @@
 #include <thread>
 #include <vector>
 
-#include "ais_kernels.hpp"
+#include "ais_dyn_kernels.hpp"
 #include "host_common.hpp"
 #include "plugin_registry.hpp"
 
@@ -26,6 +26,8 @@ KABC_DECL_COST(8)
 KABC_DECL_COST(9)
 KABC_DECL_COST(10)
 KABC_DECL_COST(11)
+
+AisDynLaunchFn find_ais_dyn_kernel();
 
 AisLaunchFn find_ais_kernel(int cost_id, int D, int pc) {
     switch (cost_id) {
@@ -92,6 +94,12 @@ struct kabc_ais {
     int64_t rows_owned[2];
     int64_t per[2];        // rows per rank segment of each half (all-gather count / D)
     kabc_comm_t* comm;     // library-owned exchange (kabc_ais_create_dist), else NULL
+    // length(prior) > KABC_MAX_DIM: run-time-dimension kernels (ais_dyn_kernels.hpp)
+    AisDynLaunchFn dyn;
+    std::vector<kabc_prior_t> raw_dyn;
+    std::vector<PriorDev> prior_dyn;
+    kabc_prior_t* d_raw;   // [D] raw components (dyn)
+    double* d_scratch;     // [max rows_owned][2][D] (dyn)
     int32_t nchains;       // independent ensembles in this handle (kabc_ais_create_batch), else 1
     uint64_t* d_seeds;     // [nchains] (batch handles)
     unsigned long long* d_chain_retries;  // [nchains]
@@ -171,8 +179,20 @@ static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0,
     }
     KABC_HIP_CHECK(hipMalloc(&h->d_counters, sizeof(DevCounters)));
     KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
-    KABC_HIP_CHECK(hipMalloc(&h->d_prior, sizeof(PriorSet)));
-    KABC_HIP_CHECK(hipMemcpyAsync(h->d_prior, &h->prior, sizeof(PriorSet), hipMemcpyHostToDevice, s));
+    if (h->dyn) {
+        const size_t D = (size_t)h->D;
+        const size_t rmax = (size_t)(h->rows_owned[0] > h->rows_owned[1] ? h->rows_owned[0] : h->rows_owned[1]);
+        KABC_HIP_CHECK(hipMalloc(&h->d_prior, sizeof(PriorDev) * D));
+        KABC_HIP_CHECK(hipMemcpyAsync(h->d_prior, h->prior_dyn.data(), sizeof(PriorDev) * D,
+                                      hipMemcpyHostToDevice, s));
+        KABC_HIP_CHECK(hipMalloc(&h->d_raw, sizeof(kabc_prior_t) * D));
+        KABC_HIP_CHECK(hipMemcpyAsync(h->d_raw, h->raw_dyn.data(), sizeof(kabc_prior_t) * D,
+                                      hipMemcpyHostToDevice, s));
+        KABC_HIP_CHECK(hipMalloc(&h->d_scratch, sizeof(double) * (rmax ? rmax : 1) * 2 * D));
+    } else {
+        KABC_HIP_CHECK(hipMalloc(&h->d_prior, sizeof(PriorSet)));
+        KABC_HIP_CHECK(hipMemcpyAsync(h->d_prior, &h->prior, sizeof(PriorSet), hipMemcpyHostToDevice, s));
+    }
     KABC_HIP_CHECK(hipMalloc(&h->d_slots, sizeof(unsigned long long) * kCounterSlots * 8));
     KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
     KABC_HIP_CHECK(hipStreamSynchronize(s));
@@ -187,9 +207,15 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         set_error("kabc_ais_create: NULL argument");
         return KABC_ERR_INVALID_ARG;
     }
-    if (m->D < 1 || m->D > KABC_MAX_DIM) {
+    if (m->D < 1 || m->D > KABC_MAX_DIM_DYN) {
         set_error("length(prior) = %d is outside the device path's range 1..%d", m->D,
-                  KABC_MAX_DIM);
+                  KABC_MAX_DIM_DYN);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    const bool dyn = m->D > KABC_MAX_DIM;
+    if (dyn && (nchains != 1 || m->cost.id >= KABC_COST_USER)) {
+        set_error("length(prior) = %d > %d runs on the run-time-dimension kernels: built-in "
+                  "DeviceCosts, one chain per handle", m->D, KABC_MAX_DIM);
         return KABC_ERR_UNSUPPORTED;
     }
     // src/KissABC.jl:43-48
@@ -224,8 +250,8 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
                           m->prior[k].kind == KABC_PRIOR_DISCRETE_UNIFORM);
     }
     const int pc = isbox ? kPriorBox : simple ? kPriorSimple : kPriorGeneral;
-    AisLaunchFn fn = find_ais_kernel(m->cost.id, m->D, pc + 3 * (m->posterior - 1));
-    if (!fn) {
+    AisLaunchFn fn = dyn ? nullptr : find_ais_kernel(m->cost.id, m->D, pc + 3 * (m->posterior - 1));
+    if (!fn && !dyn) {
         set_error("no gfx950 kernel instantiated for cost id %d, D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
     }
@@ -236,8 +262,21 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->cost_id = m->cost.id;
     h->eps = m->eps;
     std::memset(h->raw, 0, sizeof h->raw);
-    std::memcpy(h->raw, m->prior, sizeof(kabc_prior_t) * m->D);
-    if (!prepare_priors(h->raw, h->D, h->prior)) {
+    std::memset(&h->prior, 0, sizeof h->prior);
+    h->dyn = dyn ? find_ais_dyn_kernel() : nullptr;
+    h->d_raw = nullptr;
+    h->d_scratch = nullptr;
+    bool prior_ok = true;
+    if (dyn) {
+        h->raw_dyn.assign(m->prior, m->prior + m->D);
+        h->prior_dyn.resize((size_t)m->D);
+        for (int k = 0; k < m->D && prior_ok; ++k)
+            prior_ok = prepare_prior(h->raw_dyn[k], h->prior_dyn[k]);
+    } else {
+        std::memcpy(h->raw, m->prior, sizeof(kabc_prior_t) * m->D);
+        prior_ok = prepare_priors(h->raw, h->D, h->prior);
+    }
+    if (!prior_ok) {
         delete h;
         set_error("invalid prior parameters");
         return KABC_ERR_INVALID_ARG;
@@ -246,7 +285,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     // BOX class: logpdf inside the box = c0_1 + ... + c0_D, summed left to right
     // exactly as logpdf(d::Factored, x) does (src/priors.jl:30-36)
     h->box_lp = h->prior.c[0].c0;
-    for (int k = 1; k < h->D; ++k) h->box_lp += h->prior.c[k].c0;
+    for (int k = 1; k < h->D && !dyn; ++k) h->box_lp += h->prior.c[k].c0;
     h->N = n_total;
     h->rows[0] = (n_total + 1) / 2;
     h->rows[1] = n_total / 2;
@@ -365,6 +404,34 @@ kabc_status_t kabc_ais_create_dist(kabc_comm_t* comm, const kabc_model_t* model,
                              nullptr, comm, out);
 }
 
+static AisDynArgs dyn_args(kabc_ais_t* h, int half) {
+    AisDynArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.x_act = h->d_half[half];
+    a.x_comp = h->d_half[1 - half];
+    a.lp = h->d_lp[half];
+    a.ll = h->d_ll[half];
+    a.scratch = h->d_scratch;
+    a.counters = h->d_counters;
+    a.slots = h->d_slots;
+    a.cost_params = h->d_cost_params;
+    a.cost_data = h->d_cost_data;
+    a.cost_ndata = h->cost_ndata;
+    a.row_first = h->row_first[half];
+    a.rows_owned = h->rows_owned[half];
+    a.n_comp = h->rows[1 - half];
+    a.seed = h->seed;
+    a.id_base = h->id_base[half];
+    a.posterior = h->posterior;
+    a.cost_id = h->cost_id;
+    a.D = h->D;
+    a.eps = h->eps;
+    a.reps = (h->posterior == KABC_POSTERIOR_COMMON) ? 1.0 : 1.0 / h->eps;
+    a.prior = h->d_prior;
+    a.raw = h->d_raw;
+    return a;
+}
+
 // step(init) of one handle, enqueued on its stream (no read-back)
 static kabc_status_t ais_init_enqueue(kabc_ais_t* h, int32_t retry_sampling) {
     if (check_handle(h)) return KABC_ERR_INVALID_ARG;
@@ -378,7 +445,14 @@ static kabc_status_t ais_init_enqueue(kabc_ais_t* h, int32_t retry_sampling) {
     KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
     if (h->d_chain_retries)
         KABC_HIP_CHECK(hipMemsetAsync(h->d_chain_retries, 0, sizeof(unsigned long long) * h->nchains, s));
-    for (int hf = 0; hf < 2; ++hf) {
+    for (int hf = 0; hf < 2 && h->dyn; ++hf) {
+        AisDynArgs a = dyn_args(h, hf);
+        a.retry_budget = (unsigned long long)retry_sampling *
+                         (unsigned long long)(h->rows_owned[0] + h->rows_owned[1]);
+        h->dyn(a, s, 1);
+        KABC_HIP_CHECK(hipGetLastError());
+    }
+    for (int hf = 0; hf < 2 && !h->dyn; ++hf) {
         InitArgs a;
         std::memset(&a, 0, sizeof a);
         a.x_act = h->d_half[hf];
@@ -509,6 +583,27 @@ kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntra
     if ((half != 0 && half != 1) || ntransitions < 1) {
         set_error("half must be 0/1 and ntransitions >= 1");
         return KABC_ERR_INVALID_ARG;
+    }
+    if (h->dyn) {
+        AisDynArgs a = dyn_args(h, half);
+        a.trace = (double*)dev_trace_rows;
+        if (h->d_dbg) {
+            const int64_t off = (half == 0 ? 0 : h->rows_owned[0]) * (int64_t)ntransitions * 6;
+            if (off + h->rows_owned[half] * (int64_t)ntransitions * 6 <= h->dbg_cap) a.dbg = h->d_dbg + off;
+        }
+        a.t0 = h->t;
+        a.nt = ntransitions;
+        const int64_t li = h->launch_index++;
+        const bool t_on = h->timing && (h->ev_used + 2 <= h->ev.size());
+        if (t_on && li % h->timing_stride == 0)
+            KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], h->ctx->stream));
+        h->dyn(a, h->ctx->stream, 0);
+        if (t_on && li % h->timing_stride == h->timing_stride - 1) {
+            KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], h->ctx->stream));
+            h->ev_used += 2;
+        }
+        KABC_HIP_CHECK(hipGetLastError());
+        return KABC_OK;
     }
     AisArgs a;
     std::memset(&a, 0, sizeof a);
@@ -952,6 +1047,8 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h) {
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->d_slots) (void)hipFree(h->d_slots);
     if (h->d_prior) (void)hipFree(h->d_prior);
+    if (h->d_raw) (void)hipFree(h->d_raw);
+    if (h->d_scratch) (void)hipFree(h->d_scratch);
     if (h->d_seeds) (void)hipFree(h->d_seeds);
     if (h->d_chain_retries) (void)hipFree(h->d_chain_retries);
     for (int b = 0; b < kTraceBufs; ++b) {

@@ -144,8 +144,8 @@ class Factored:
         for c in components:
             if not isinstance(c, UnivariateDistribution):
                 raise TypeError("Factored components must be univariate distributions")
-        if len(components) > cd.KABC_MAX_DIM:
-            raise ValueError(f"the device path supports length(prior) <= {cd.KABC_MAX_DIM}")
+        if len(components) > cd.KABC_MAX_DIM_DYN:
+            raise ValueError(f"the device path supports length(prior) <= {cd.KABC_MAX_DIM_DYN}")
         self.p = tuple(components)
 
     def __len__(self):  # length(p::Factored) = N, src/priors.jl:49
@@ -209,9 +209,48 @@ class Factored:
         return out[0] if n is None else out
 
 
+class Product(Factored):
+    """Product([d1, d2, ...]) of Distributions.jl (test/runtests.jl:30): a vector-valued
+    product of univariate distributions.  push_p(density::Distribution, p) broadcasts the
+    per-component projection (src/types.jl:30), logpdf is the sum of the components' --
+    i.e. exactly the Factored kernels; only the walker is a Vector instead of a Tuple."""
+    vector_valued = True
+
+    def __init__(self, components):
+        super().__init__(*list(components))
+
+    def __repr__(self):
+        return "Product([" + ", ".join(map(repr, self.p)) + "])"
+
+
+class MvNormal(Product):
+    """MultivariateNormal with a DIAGONAL covariance: MvNormal(d, σ) (zero mean, isotropic --
+    the form test/runtests.jl:186 uses), MvNormal(μ, σ) with σ a scalar or a vector of
+    standard deviations.  It is a product of Normals, so it runs on the Factored kernels; a
+    full covariance matrix would need a triangular solve per walker and is not on this path."""
+
+    def __init__(self, mu_or_dim, sigma=1.0):
+        if np.isscalar(mu_or_dim):
+            mu = np.zeros(int(mu_or_dim))
+        else:
+            mu = np.asarray(mu_or_dim, dtype=float).ravel()
+        sig = np.asarray(sigma, dtype=float)
+        if sig.ndim == 2:
+            raise TypeError("MvNormal with a full covariance matrix is not supported on the device "
+                            "path (diagonal / isotropic only)")
+        sig = np.broadcast_to(sig, mu.shape)
+        super().__init__([Normal(m, s) for m, s in zip(mu, sig)])
+
+    def __repr__(self):
+        return f"MvNormal(dim={len(self)})"
+
+
+MultivariateNormal = MvNormal
+
+
 def as_factored(prior):
     """A bare univariate prior (e.g. Normal(1, 0.2), test/runtests.jl:78) is a
-    1-component Factored on this path."""
+    1-component Factored on this path; Product / MvNormal already are Factored."""
     if isinstance(prior, Factored):
         return prior
     if isinstance(prior, UnivariateDistribution):

@@ -14,6 +14,10 @@
 #include "kabc_philox.h"
 #include "kabc_sampling.h"
 
+/* the oracle restates the reference for any length(prior) the product accepts
+ * (KABC_MAX_DIM_DYN, include/kabc.h) */
+#define ORC_MAX_DIM KABC_MAX_DIM_DYN
+
 static __thread char g_err[512];
 const char* orc_last_error(void) { return g_err; }
 static int32_t fail(int32_t code, const char* msg) {
@@ -228,7 +232,7 @@ static double factored_logpdf(const prep_t* q, int D, const double* x) {
 }
 
 static int prep_all(const kabc_prior_t* prior, int32_t D, prep_t* q) {
-    if (D < 1 || D > KABC_MAX_DIM) return 0;
+    if (D < 1 || D > ORC_MAX_DIM) return 0;
     for (int k = 0; k < D; ++k)
         if (!prepare_prior(&prior[k], &q[k])) return 0;
     return 1;
@@ -236,7 +240,7 @@ static int prep_all(const kabc_prior_t* prior, int32_t D, prep_t* q) {
 
 int32_t orc_factored_logpdf(const kabc_prior_t* prior, int32_t D, int64_t n, const double* x,
                             double* out) {
-    prep_t q[KABC_MAX_DIM];
+    prep_t q[ORC_MAX_DIM];
     if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
     for (int64_t i = 0; i < n; ++i) out[i] = factored_logpdf(q, D, x + i * D);
     return KABC_OK;
@@ -245,7 +249,7 @@ int32_t orc_factored_logpdf(const kabc_prior_t* prior, int32_t D, int64_t n, con
 /* pdf(d::Factored, x): product of component pdfs (src/priors.jl:18-24) */
 int32_t orc_factored_pdf(const kabc_prior_t* prior, int32_t D, int64_t n, const double* x,
                          double* out) {
-    prep_t q[KABC_MAX_DIM];
+    prep_t q[ORC_MAX_DIM];
     if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
     for (int64_t i = 0; i < n; ++i) {
         double s = exp(comp_logpdf(&q[0], x[i * D]));
@@ -256,7 +260,7 @@ int32_t orc_factored_pdf(const kabc_prior_t* prior, int32_t D, int64_t n, const 
 }
 
 int32_t orc_push_p(const kabc_prior_t* prior, int32_t D, int64_t n, const double* x, double* out) {
-    prep_t q[KABC_MAX_DIM];
+    prep_t q[ORC_MAX_DIM];
     if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
     for (int64_t i = 0; i < n; ++i) push_p(q, D, x + i * D, out + i * D);
     return KABC_OK;
@@ -315,8 +319,8 @@ double orc_cdf_g_inv(double u, double a) {
 struct orc_ais {
     int32_t D, posterior;
     double eps;
-    kabc_prior_t prior[KABC_MAX_DIM];
-    prep_t q[KABC_MAX_DIM];
+    kabc_prior_t prior[ORC_MAX_DIM];
+    prep_t q[ORC_MAX_DIM];
     kabc_cost_t cost;
     double* cost_params;
     double* cost_data;
@@ -380,7 +384,7 @@ static int is_valid(const orc_ais_t* h, ld_t v) {
 }
 
 int32_t orc_ais_create(const kabc_model_t* m, int64_t N, uint64_t seed, orc_ais_t** out) {
-    if (!m || !out || m->D < 1 || m->D > KABC_MAX_DIM)
+    if (!m || !out || m->D < 1 || m->D > ORC_MAX_DIM)
         return fail(KABC_ERR_INVALID_ARG, "invalid model");
     if (N < m->D + 5) { /* src/KissABC.jl:43-48 */
         snprintf(g_err, sizeof g_err,
@@ -432,7 +436,7 @@ void orc_ais_destroy(orc_ais_t* h) {
 int32_t orc_ais_init(orc_ais_t* h, int32_t retry_sampling) {
     const int D = h->D;
     int64_t retrys = (int64_t)retry_sampling * h->N; /* :52 */
-    double xp[KABC_MAX_DIM];
+    double xp[ORC_MAX_DIM];
     for (int64_t i = 0; i < h->N; ++i) { /* :50-51, attempt 0 */
         uint64_t attempt = 0;
         int ev;
@@ -497,7 +501,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
     const int D = h->D;
     const uint32_t w = (uint32_t)i;
     const double* xi = h->x + i * D;
-    double y[KABC_MAX_DIM], yp[KABC_MAX_DIM];
+    double y[ORC_MAX_DIM], yp[ORC_MAX_DIM];
     double corr;
 
     blk_t B0 = stream(h->seed, w, t, 0, KABC_DOM_AIS_MOVE);
@@ -523,7 +527,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
         blk_t B2 = stream(h->seed, w, t, 2, KABC_DOM_AIS_MOVE);
         b = draw_partner(B2.lo, ps, &a, 1);
         const double* xb = h->x + b * D;
-        double z[KABC_MAX_DIM + 2];
+        double z[ORC_MAX_DIM + 2];
         for (int j = 0; j < (D + 2) / 2; ++j) {
             blk_t Bn = stream(h->seed, w, t, 3 + j, KABC_DOM_AIS_MOVE);
             kabc_normal_pair(Bn.lo, Bn.hi, &z[2 * j], &z[2 * j + 1]);
@@ -764,7 +768,7 @@ int32_t orc_smc_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cos
     if (!(r_epstol >= 0)) return fail(KABC_ERR_INVALID_ARG, "r_epstol must be >= 0");
     if (!(o->mcmc_tol >= 0)) return fail(KABC_ERR_INVALID_ARG, "mcmc_tol must be >= 0");
     if (!(o->max_stretch > 1)) return fail(KABC_ERR_INVALID_ARG, "max_stretch must be > 1");
-    prep_t q[KABC_MAX_DIM];
+    prep_t q[ORC_MAX_DIM];
     if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
     if (!cost_dim_ok_any(cost->id, D))
         return fail(KABC_ERR_UNSUPPORTED, "cost id / dimension not supported");
@@ -788,7 +792,7 @@ int32_t orc_smc_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cos
     int64_t* idx = (int64_t*)malloc(sizeof(int64_t) * N);
     double* prop = (double*)malloc(sizeof(double) * N * D); /* new_p θp */
     double* lprob = (double*)malloc(sizeof(double) * N);
-    double xp[KABC_MAX_DIM];
+    double xp[ORC_MAX_DIM];
     uint64_t cost_evals = 0, proposals = 0;
     int32_t rc = KABC_OK;
 
@@ -957,7 +961,7 @@ int32_t orc_abcde_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* c
     if (!(o->alpha >= 0 && o->alpha < 1)) return fail(KABC_ERR_INVALID_ARG, "α must be in 0 <= α < 1.");
     const int64_t N = o->nparticles;
     if (N < 3) return fail(KABC_ERR_INVALID_ARG, "nparticles must be >= 3 (and < 2^31)");
-    prep_t q[KABC_MAX_DIM];
+    prep_t q[ORC_MAX_DIM];
     if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
     if (!cost_dim_ok_any(cost->id, D)) return fail(KABC_ERR_UNSUPPORTED, "cost id / dimension not supported");
     const uint64_t seed = o->seed;
@@ -967,7 +971,7 @@ int32_t orc_abcde_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* c
     double* ndl = (double*)malloc(sizeof(double) * N);
     double* lp = (double*)malloc(sizeof(double) * N);
     double* nlp = (double*)malloc(sizeof(double) * N);
-    double xp[KABC_MAX_DIM], tp[KABC_MAX_DIM];
+    double xp[ORC_MAX_DIM], tp[ORC_MAX_DIM];
     uint64_t nsims = 0;
     int32_t rc = KABC_OK;
     /* :349-366 */
@@ -1074,7 +1078,7 @@ int64_t orc_pfilter_nparticles(int64_t N, double q, int32_t D) {
 
 int32_t orc_pfilter_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* cost,
                         const kabc_pfilter_opts_t* o, kabc_pfilter_result_t* res) {
-    prep_t q[KABC_MAX_DIM];
+    prep_t q[ORC_MAX_DIM];
     if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
     if (!cost_dim_ok_any(cost->id, D)) return fail(KABC_ERR_UNSUPPORTED, "cost id / dimension not supported");
     if (!(o->q > 0 && o->q <= 1) || o->nparticles < 1)
@@ -1087,7 +1091,7 @@ int32_t orc_pfilter_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t*
     double* tmp = (double*)malloc(sizeof(double) * N);
     int64_t* idxok = (int64_t*)malloc(sizeof(int64_t) * N);
     uint8_t* bad = (uint8_t*)malloc(N);
-    double xp[KABC_MAX_DIM], p[KABC_MAX_DIM];
+    double xp[ORC_MAX_DIM], p[ORC_MAX_DIM];
     uint64_t total_reps = 0, cost_evals = 0;
     int32_t rc = KABC_OK;
     for (int64_t i = 0; i < N; ++i) { /* :280-294 */

@@ -1,0 +1,72 @@
+"""length(prior) > KABC_MAX_DIM = 16: the run-time-dimension AIS kernels
+(csrc/ais_dyn_kernels.hpp).  The reference has no bound on the number of parameters
+(src/priors.jl:10-13); beyond 16 the device keeps the walker rows in memory instead of
+registers.  Same draws, same operation order: bit-identical to the oracle, like the fast
+path -- state, per-transition records (move, accept, partners), trace and counters."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(k):
+    rng = np.random.default_rng(4)
+    return {
+        "rosen_d17_box": (k.ApproxKernelizedPosterior(k.Factored(*[k.Uniform(-5, 5)] * 17),
+                                                      k.costs.Rosenbrock(), 2.0), 300),
+        "gauss_d40_normal": (k.ApproxKernelizedPosterior(k.MvNormal(40, 3.0),
+                                                         k.costs.GaussDist(rng.normal(size=40)), 0.5), 257),
+        "shell_d24_threshold": (k.ApproxPosterior(k.Factored(*[k.Normal(0, 1)] * 24),
+                                                  k.costs.NormShell(4.0), 0.5), 128),
+        "hier_d34_mixed": (k.ApproxKernelizedPosterior(
+            k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 30, k.Gamma(2.0, 1.0),
+                       k.DiscreteUniform(-3, 3)),
+            k.costs.HierGaussSim(rng.normal(size=32)), 1.0), 100),
+        "gauss_d128": (k.ApproxPosterior(k.Product([k.Uniform(-2, 2)] * 128),
+                                         k.costs.GaussDist(np.zeros(128)), 12.0), 1000),
+    }
+
+
+@pytest.mark.parametrize("name", ["rosen_d17_box", "gauss_d40_normal", "shell_d24_threshold",
+                                  "hier_d34_mixed", "gauss_d128"])
+def test_dynamic_dimension_bit_exact(k, orc, gpu_ctx, name):
+    model, N = _models(k)[name]
+    nt, gens, seed = 6, 3, 21
+    e = k.AisEnsemble(model, N, seed=seed).init()
+    o = orc.OracleAIS(model, N, seed=seed).init()
+    for got, ref in zip(e.state()[:3], o.state()[:3]):
+        assert np.array_equal(got, ref)                      # step(init)
+    e.set_debug(nt)
+    tr = e.advance(1, nt, collect=True)
+    rec = e.get_debug(nt)
+    tro, reco = o.generations_sync(1, nt, trace=True)
+    assert np.array_equal(tr, tro)
+    n0 = (N + 1) // 2
+    ro = reco[0].copy()
+    ro[:n0, :, 2:5] = np.where(ro[:n0, :, 2:5] >= 0, ro[:n0, :, 2:5] - n0, -1)   # partner ids -> rows
+    assert np.array_equal(rec, ro)
+    e.set_debug(0)
+    tr = e.advance(gens, nt, collect=True)
+    assert np.array_equal(tr, o.generations_sync(gens, nt))
+    for got, ref in zip(e.state(), o.state()):
+        assert np.array_equal(got, ref)
+    assert e.stats() == o.stats()
+    e.close()
+
+
+def test_dynamic_dimension_limits_and_sharding(k, orc, gpu_ctx):
+    with pytest.raises(ValueError):
+        k.Factored(*[k.Normal(0, 1)] * 257)
+    big = k.Factored(*[k.Normal(0, 1)] * 20)
+    with pytest.raises(k.KabcError, match="outside the device path's range"):
+        k.smc(big, k.costs.GaussDist(np.zeros(20)), nparticles=500)
+    # walker-sharded (3 emulated ranks, P2P exchange) at D = 20
+    model = k.ApproxKernelizedPosterior(big, k.costs.GaussDist(np.ones(20)), 0.5)
+    grp = k.EnsembleGroup(model, 301, seed=9, devices=[0, 0, 0], backend="p2p").init()
+    grp.advance(3, 4)
+    o = orc.OracleAIS(model, 301, seed=9).init()
+    o.generations_sync(3, 4, collect=False)
+    x, lp, ll = grp.state()
+    xo, lpo, llo, _ = o.state()
+    assert np.array_equal(x, xo) and np.array_equal(lp, lpo) and np.array_equal(ll, llo)
+    grp.close()

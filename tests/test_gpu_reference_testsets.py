@@ -69,8 +69,8 @@ def test_issue_10(k, gpu_ctx):
 
 
 def test_four_dim_shell_with_chains(k, gpu_ctx):
-    # test/runtests.jl:184-198 (MultivariateNormal(4, 1.0) == four independent N(0,1))
-    plan = k.ApproxPosterior(k.Factored(*[k.Normal(0, 1)] * 4), k.costs.NormShell(1.5), 0.01)
+    # test/runtests.jl:184-198: vector-valued walkers from MultivariateNormal(4, 1.0)
+    plan = k.ApproxPosterior(k.MultivariateNormal(4, 1.0), k.costs.NormShell(1.5), 0.01)
     res = k.sample(plan, k.AIS(20), k.MCMCThreads(), 100, 4, discard_initial=10000, ntransitions=40,
                    seed=1, return_array=True)
     assert res.shape == (400, 4)

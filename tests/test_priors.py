@@ -31,6 +31,8 @@ def test_reference_push_testset(orc, k):
     assert orc.push_p(k.DiscreteUniform(), [1.0])[0, 0] == 1
     assert list(orc.push_p(k.Factored(k.Normal(), k.DiscreteUniform()), [2, 1.0])[0]) == [2.0, 1]
     assert list(orc.push_p(k.Factored(k.Normal(), k.Normal()), [2, 1])[0]) == [2.0, 1.0]
+    # push_p(Product([Normal(), Normal()]), [2, 1]) /′ [2.0, 1.0]  (vector-valued walker)
+    assert list(orc.push_p(k.Product([k.Normal(), k.Normal()]), [2, 1])[0]) == [2.0, 1.0]
     # round(Int, x) is ties-to-even
     assert list(orc.push_p(k.Factored(k.DiscreteUniform(0, 9), k.DiscreteUniform(0, 9)),
                            [2.5, 3.5])[0]) == [2.0, 4.0]
@@ -85,3 +87,23 @@ def test_discrete_samplers_chi2(orc, k, kind, params, ref):
     chi2 = ((obs[keep] - exp[keep]) ** 2 / exp[keep]).sum()
     assert stats.chi2(keep.sum() - 1).sf(chi2) > 1e-4
     assert abs(x.mean() - ref.mean()) < 5 * ref.std() / np.sqrt(n)
+
+
+def test_vector_valued_priors_are_products_of_their_components(orc, k):
+    """Product([...]) and the diagonal MvNormal (test/runtests.jl:30,186): logpdf = sum of the
+    components' log-densities (scipy), rand / push_p per component."""
+    from scipy import stats
+    mv = k.MvNormal(4, 1.0)                                  # MultivariateNormal(4, 1.0)
+    assert len(mv) == 4 and mv.vector_valued and isinstance(mv, k.Factored)
+    x = np.random.default_rng(0).normal(size=(50, 4)) * 2
+    ref = stats.multivariate_normal(np.zeros(4), np.eye(4)).logpdf(x)
+    assert np.allclose(orc.factored_logpdf(mv, x), ref, rtol=1e-13, atol=1e-13)
+    d = k.MvNormal([1.0, -2.0, 0.5], [0.5, 2.0, 1.5])
+    ref = stats.multivariate_normal([1.0, -2.0, 0.5], np.diag(np.array([0.5, 2.0, 1.5]) ** 2)).logpdf(x[:, :3])
+    assert np.allclose(orc.factored_logpdf(d, x[:, :3]), ref, rtol=1e-13, atol=1e-13)
+    pr = k.Product([k.Uniform(0, 2), k.DiscreteUniform(1, 4), k.Normal(0, 1)])
+    xs = orc.push_p(pr, orc.factored_rand(pr, 100, seed=2))
+    assert np.all((xs[:, 0] >= 0) & (xs[:, 0] <= 2)) and np.array_equal(xs[:, 1], np.rint(xs[:, 1]))
+    assert k.MultivariateNormal is k.MvNormal
+    with pytest.raises(TypeError, match="full covariance"):
+        k.MvNormal(np.zeros(2), np.array([[1.0, 0.3], [0.3, 1.0]]))
