@@ -110,6 +110,21 @@ def cpu_baseline(k, budget_s, with_smc):
                           f"{budget_s / 2:.0f}s each"}
     except Exception as e:  # the baseline is informational; never fail the bench on it
         out["all_cores"] = {"error": repr(e)}
+    # the reference itself, if a julia with KissABC exists on this box
+    try:
+        import shutil
+        import subprocess
+        jl = shutil.which("julia")
+        if jl:
+            r = subprocess.run([jl, "-t", "1", os.path.join(ROOT, "bench", "cpu_reference.jl"),
+                                str(WALKERS_PER_GPU), str(D), str(NT_HEADLINE), str(budget_s)],
+                               capture_output=True, text=True, timeout=600)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            out["julia_reference"] = json.loads(line[-1]) if line else {"error": r.stderr[-500:]}
+        else:
+            out["julia_reference"] = None   # no julia on this box (none in the build image either)
+    except Exception as e:
+        out["julia_reference"] = {"error": repr(e)}
     if with_smc:
         try:
             from oracle import oracle as orc

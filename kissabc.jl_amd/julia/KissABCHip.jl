@@ -1,22 +1,33 @@
 # KissABCHip.jl -- thin `ccall` layer that puts the MI355X walker-update path
-# (libkabc_hip.so, C ABI in include/kabc.h) behind KissABC.jl's own surface:
+# (libkabc_hip.so, C ABI in include/kabc.h) behind KissABC.jl's OWN surface.  Loading it
+# adds methods, it introduces no sampler type of its own: a model whose `cost` is a
+# DeviceCost runs on the GPU through the reference's calls, unchanged --
 #
-#     ApproxKernelizedPosterior(prior, cost::DeviceCost, scale)   # KissABC's type, unchanged
-#     sample(model, AISHip(N), Ns; ntransitions, discard_initial, retry_sampling)
-#     smc(prior, cost::DeviceCost; kwargs...)                      # same keywords/defaults
+#     model = ApproxKernelizedPosterior(prior, Rosenbrock(), 1.0)       # KissABC's type
+#     sample(model, AIS(65536), 10^6; ntransitions = 100, discard_initial = 10^5)
+#     sample(model, AIS(12), MCMCThreads(), 100, 50)                    # chains = one batch handle
+#     smc(prior, cost; nparticles = 32768)      ABCDE(prior, cost, ϵ)      pfilter(prior, cost, N)
+#     sample(CommonLogDensity(2, InitFrom(Factored(Normal(), Normal())), lπ::DeviceCost), AIS(50), 1000)
+#     sample_sharded(model, AIS(524288), [0,1,2,3,4,5,6,7], 10^6)       # one process, 8 GPUs, RCCL
 #
-# It contains no numerics: it lowers `Factored`/Distributions objects to
-# `kabc_prior_t`, a `DeviceCost` to `kabc_cost_t`, calls the library and wraps
-# the result in `Particles` exactly as src/KissABC.jl:82-104 and src/smc.jl:200-205 do.
+# -- and a model with an ordinary Julia closure keeps running through KissABC's CPU path.
+# Dispatch: `AbstractMCMC.step(rng, model::DeviceModel, spl::AIS; ...)` is more specific than
+# the reference's `step(rng, model::AbstractDensity, spl::AIS; ...)` (src/KissABC.jl:35-41,66-72).
 #
-# NOTE: Julia is not available in the build image of this repository, so this file
-# has been checked by eye only; the identical call sequence is exercised through
-# the Python ctypes mirror (kissabc.jl_amd/api.py) by tests/.
+# It contains no numerics: it lowers `Factored` / `Product` / diagonal `MvNormal` /
+# univariate Distributions to `kabc_prior_t`, a DeviceCost to `kabc_cost_t`, calls the library
+# and wraps the result in `Particles` exactly as src/KissABC.jl:82-104 and src/smc.jl:200-205,
+# :334-340, :425-430 do.  It mirrors kissabc.jl_amd/api.py call for call.
+#
+# STATUS: EXPERIMENTAL -- Julia is not available in the build image of this repository, so
+# this file has been checked by eye only; the identical call sequences are exercised through
+# the Python ctypes mirror (api.py, comm.py) and from plain C (examples/abi_demo.c) by tests/.
 module KissABCHip
 
-using KissABC, Random
+using KissABC, Random, LinearAlgebra, Statistics
 import AbstractMCMC
-import KissABC: Factored, ApproxKernelizedPosterior, ApproxPosterior, Particles
+import AbstractMCMC: MCMCThreads
+import KissABC: Factored, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity, AIS, Particles
 using Distributions
 
 const libkabc = get(ENV, "KABC_LIB", joinpath(@__DIR__, "..", "lib", "libkabc_hip.so"))
@@ -73,14 +84,52 @@ mutable struct KabcSmcResult
     kernel_ms_mcmc::Float64
     mcmc_launches::Int64
 end
+mutable struct KabcAbcdeOpts
+    nparticles::Int64
+    generations::Int64
+    eps_target::Float64
+    alpha::Float64
+    proposal_width::Float64
+    earlystop::Int32
+    verbose::Int32
+    seed::UInt64
+end
+mutable struct KabcAbcdeResult
+    theta::Ptr{Float64}
+    cost::Ptr{Float64}
+    reached_eps::Int32
+    reserved::Int32
+    generations_run::Int64
+    nsims::UInt64
+end
+mutable struct KabcPfilterOpts
+    nparticles::Int64
+    q::Float64
+    eff_tol::Float64
+    epstol::Float64
+    proposal_width::Float64
+    max_iters::Int64      # Inf -> -1
+    verbose::Int32
+    reserved::Int32
+    seed::UInt64
+end
+mutable struct KabcPfilterResult
+    theta::Ptr{Float64}
+    cost::Ptr{Float64}
+    eps::Float64
+    eff::Float64
+    iterations::Int64
+    nreps::UInt64
+    cost_evals::UInt64
+end
 
 check(st) = st == 0 ? nothing :
     error(unsafe_string(ccall((:kabc_last_error, libkabc), Cstring, ())))   # reference's text
 
 # ---- DeviceCost: the `cost` argument on the device path ----------------------
-# A DeviceCost is also callable on the CPU (`cpu` holds the same formula as a
-# Julia closure), so ONE model object runs through KissABC's own AIS/smc and
-# through the HIP path.  ids/formulas: include/kabc_costs.h.
+# A DeviceCost is also callable on the CPU (`cpu` holds the same formula as a Julia closure,
+# written as the reference's tests write it), so ONE model object runs through KissABC's own
+# AIS/smc and through the HIP path.  ids/formulas: include/kabc_costs.h.
 struct DeviceCost{F}
     id::Int32
     params::Vector{Float64}
@@ -88,23 +137,37 @@ struct DeviceCost{F}
     cpu::F
 end
 (c::DeviceCost)(x) = c.cpu(x)
-GaussDist(c) = DeviceCost(Int32(1), collect(Float64, c), Float64[], x -> sqrt(sum(abs2, x .- c)))
-Rosenbrock() = DeviceCost(Int32(2), Float64[], Float64[],
+devcost(id, params, data, f) = DeviceCost(Int32(id), collect(Float64, params), collect(Float64, data), f)
+
+GaussDist(c) = devcost(1, c, Float64[], x -> sqrt(sum(abs2, collect(x) .- c)))
+Rosenbrock() = devcost(2, Float64[], Float64[],
     x -> sqrt(sum(100 * (x[k+1] - x[k]^2)^2 + (1 - x[k])^2 for k in 1:length(x)-1)))
-DiracSq(t = 1.5) = DeviceCost(Int32(5), [Float64(t)], Float64[], x -> abs(x[1]^2 + 1 - t))
-AbsDiff(t) = DeviceCost(Int32(6), [Float64(t)], Float64[], x -> abs(x[1] - t))
-NormShell(t) = DeviceCost(Int32(7), [Float64(t)], Float64[], x -> abs(sqrt(sum(abs2, x)) - t))
-NoisyBanana(p = 0.0) = DeviceCost(Int32(10), [Float64(p)], Float64[],
+# θ = (m, s, z_1..z_G): ȳ_g = m + s z_g + randn/√8, cost = RMS(ȳ − ȳ_obs)   (SURVEY 8d, C4)
+HierGaussSim(ybar) = devcost(3, Float64[], ybar,
+    x -> sqrt(sum(abs2, (x[1] + x[2] * x[2+g] + randn() / sqrt(8) - ybar[g]) for g in 1:length(ybar)) / length(ybar)))
+# README.md:43-49: n draws N(μ, σ); hypot(mean − mean(tdata), 50 (std − std(tdata)))
+NormalMeanStdSim(n, m_obs, s_obs) = devcost(4, [n, m_obs, s_obs], Float64[],
+    ((μ, σ),) -> (y = μ .+ σ .* randn(Int(n)); hypot(mean(y) - m_obs, 50 * (std(y) - s_obs))))
+DiracSq(t = 1.5) = devcost(5, [t], Float64[], x -> abs(x[1]^2 + 1 - t))            # runtests.jl:79-80
+AbsDiff(t) = devcost(6, [t], Float64[], x -> abs(x[1] - t))                        # runtests.jl:178
+NormShell(t) = devcost(7, [t], Float64[], x -> abs(sqrt(sum(abs2, x)) - t))        # runtests.jl:186
+NoisyQuadDU(t = 5.5) = devcost(8, [t], Float64[],                                  # runtests.jl:108-109
+    ((n, du),) -> abs((n * n + du) * (n + randn() * 0.01) - t))
+Mixture(t = 0.0) = devcost(9, [t], Float64[],                                      # runtests.jl:145-146
+    μ -> abs(μ[1] + rand((randn() * 0.1, randn())) - t))
+NoisyBanana(p = 0.0) = devcost(10, [p], Float64[],                                 # runtests.jl:242,248
     ((x, y),) -> rand() < p ? Inf : 50 * (x + randn() * 0.01 - y^2)^2 + (y - 1 + randn() * 0.01)^2)
-# ... the remaining ids (hier_gauss_sim, normal_meanstd_sim, noisy_quad_du, mixture,
-# wiener_rms) follow the same pattern.
+WienerRms(tdata) = devcost(11, Float64[], tdata,                                   # runtests.jl:116-126
+    ((μ, σ),) -> (t = 0:length(tdata)-1;
+                  sum(abs, sqrt.(μ^2 .* t .^ 2 .+ σ^2 .* t) .* (0.95 + 0.1 * rand()) .- tdata) / length(tdata)))
 
 """
     UserCost(csrc, dims; params, data, cpu)
 A DeviceCost from a C snippet defining `kabc_user_cost` (include/kabc_costs.h,
 KABC_COST_USER): compiled with hipcc for gfx950 together with csrc/user_plugin.inc and
 registered with `kabc_register_cost_plugin`.  `cpu` is the Julia closure with the same
-formula (used when the model runs through KissABC's own AIS/smc).
+formula (used when the model runs through KissABC's own AIS/smc).  With
+posterior kind CommonLogDensity the snippet returns the log-density.
 """
 function UserCost(csrc::String, dims; params = Float64[], data = Float64[], cpu = x -> NaN)
     root = normpath(joinpath(@__DIR__, "..", ".."))
@@ -114,12 +177,12 @@ function UserCost(csrc::String, dims; params = Float64[], data = Float64[], cpu 
            "\n#define KABC_USER_COST_DEFINED 1\n#include \"user_plugin.inc\"\n"
     dir = mktempdir(); src = joinpath(dir, "user.hip"); so = joinpath(dir, "libkabc_user.so")
     write(src, text)
-    run(`/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950
+    run(`/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950
          -I $(joinpath(root, "include")) -I $(joinpath(root, "kissabc.jl_amd", "csrc"))
          -shared -o $so $src`)
     id = Ref{Int32}(0)
     check(ccall((:kabc_register_cost_plugin, libkabc), Cint, (Cstring, Ref{Int32}), so, id))
-    DeviceCost(id[], collect(Float64, params), collect(Float64, data), cpu)
+    devcost(id[], params, data, cpu)
 end
 
 # ---- Factored / Distributions -> kabc_prior_t --------------------------------
@@ -132,89 +195,235 @@ lower(d::NegativeBinomial) = KabcPrior(6, 0, (Float64(d.r), d.p, 0.0, 0.0))
 lower(d::Exponential) = KabcPrior(7, 0, (d.θ, 0.0, 0.0, 0.0))
 lower(d::Gamma) = KabcPrior(8, 0, (d.α, d.θ, 0.0, 0.0))
 lower(d::LogNormal) = KabcPrior(9, 0, (d.μ, d.σ, 0.0, 0.0))
-lower(d::Factored) = KabcPrior[lower(c) for c in d.p]
 lower_prior(d::UnivariateDistribution) = KabcPrior[lower(d)]
-lower_prior(d::Factored) = lower(d)
+lower_prior(d::Factored) = KabcPrior[lower(c) for c in d.p]
+# vector-valued walkers (test/runtests.jl:30,186): products of univariate components run on the
+# Factored kernels; only the shape of the emitted sample differs (Vector instead of Tuple)
+lower_prior(d::Product) = KabcPrior[lower(c) for c in d.v]
+function lower_prior(d::AbstractMvNormal)
+    Σ = cov(d)
+    isdiag(Σ) || error("MvNormal with a full covariance matrix is not supported on the device path " *
+                       "(diagonal / isotropic only)")
+    KabcPrior[KabcPrior(2, 0, (m, sqrt(v), 0.0, 0.0)) for (m, v) in zip(mean(d), diag(Σ))]
+end
+vector_valued(d) = d isa MultivariateDistribution && !(d isa Factored)
+
+"InitFrom(d): a `sample_init` for CommonLogDensity that is callable (reference path, src/types.jl:112-113) and lowers to a prior (device path)."
+struct InitFrom{D<:Distribution}
+    d::D
+end
+(s::InitFrom)(rng) = (x = rand(rng, s.d); x isa Tuple ? collect(Float64, x) : x)
+
+const KernelizedDev = ApproxKernelizedPosterior{<:Distribution,<:DeviceCost}
+const ThresholdDev = ApproxPosterior{<:Distribution,<:DeviceCost}
+const CommonDev = CommonLogDensity{<:Any,<:InitFrom,<:DeviceCost}
+const DeviceModel = Union{KernelizedDev,ThresholdDev,CommonDev}
 
 posterior_kind(::ApproxKernelizedPosterior) = Int32(1)
 posterior_kind(::ApproxPosterior) = Int32(2)
+posterior_kind(::CommonLogDensity) = Int32(3)
 eps_of(m::ApproxKernelizedPosterior) = Float64(m.scale)
 eps_of(m::ApproxPosterior) = Float64(m.maxcost)
+eps_of(::CommonLogDensity) = 1.0
+prior_of(m::CommonLogDensity) = m.sample_init.d
+prior_of(m) = m.prior
+cost_of(m::CommonLogDensity) = m.lπ
+cost_of(m) = m.cost
 
 # ---- context -----------------------------------------------------------------
-const CTX = Ref{Ptr{Cvoid}}(C_NULL)
-function context(device = 0)
-    if CTX[] == C_NULL
-        check(ccall((:kabc_ctx_create, libkabc), Cint, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}),
-                    device, C_NULL, CTX))
+const CTX = Dict{Int,Ptr{Cvoid}}()
+function context(device::Integer = 0)
+    get!(CTX, device) do
+        h = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:kabc_ctx_create, libkabc), Cint, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, h))
+        h[]
     end
-    CTX[]
 end
 
-# ---- AIS ---------------------------------------------------------------------
-"AISHip(N): AIS(N) executed on the GPU (src/KissABC.jl:21-23)."
-struct AISHip <: AbstractMCMC.AbstractSampler
-    nparticles::Int
-end
-
-mutable struct AISHipState           # AISState of src/KissABC.jl:25-33, device resident
-    handle::Ptr{Cvoid}
-    cache::Matrix{Float64}           # D x N samples of the last generation
-    i::Int
-end
-
-function create(model, spl::AISHip, seed::UInt64)
-    pri = lower_prior(model.prior)
-    c = model.cost::DeviceCost
-    h = Ref{Ptr{Cvoid}}(C_NULL)
+"with_model(f, model): lowers the model to a kabc_model_t that stays valid while `f` runs"
+function with_model(f, model)
+    pri = lower_prior(prior_of(model))
+    c = cost_of(model)::DeviceCost
     GC.@preserve pri c begin
         cm = KabcModel(pointer(pri), length(pri), posterior_kind(model), eps_of(model),
-                       KabcCost(c.id, length(c.params), pointer(c.params), length(c.data),
-                                pointer(c.data)))
-        check(ccall((:kabc_ais_create, libkabc), Cint,
-                    (Ptr{Cvoid}, Ref{KabcModel}, Int64, UInt64, Ref{Ptr{Cvoid}}),
-                    context(), cm, spl.nparticles, seed, h))
+                       KabcCost(c.id, length(c.params), pointer(c.params), length(c.data), pointer(c.data)))
+        f(cm)
     end
-    h[]
 end
 
+# ---- AIS: sample(model, AIS(N), Ns; ...) -------------------------------------
+mutable struct AISHipState           # AISState of src/KissABC.jl:25-33, device resident
+    handle::Ptr{Cvoid}
+    cache::Matrix{Float64}           # D x N samples (push_p'ed) of the last generation
+    i::Int                           # next column to emit; N + 1 = cache exhausted
+end
+destroy!(s::AISHipState) = (s.handle != C_NULL && ccall((:kabc_ais_destroy, libkabc), Cint, (Ptr{Cvoid},), s.handle);
+                            s.handle = C_NULL)
+
 function generation!(st::AISHipState, ntransitions)
-    check(ccall((:kabc_ais_advance, libkabc), Cint,
-                (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Cvoid}),
+    check(ccall((:kabc_ais_advance, libkabc), Cint, (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Cvoid}),
                 st.handle, 1, ntransitions, st.cache, C_NULL))
     st.i = 1
 end
 
-wrap(model, col) = KissABC.Particle(length(col) == 1 ? col[1] : Tuple(col))
-
-# step(rng, model, spl; retry_sampling) -- replaces src/KissABC.jl:35-64
-function AbstractMCMC.step(rng::Random.AbstractRNG, model::AbstractMCMC.AbstractModel,
-                           spl::AISHip; retry_sampling::Int = 100, ntransitions::Int = 1, kwargs...)
-    h = create(model, spl, rand(rng, UInt64))
-    check(ccall((:kabc_ais_init, libkabc), Cint, (Ptr{Cvoid}, Int32), h, retry_sampling))
-    st = AISHipState(h, Matrix{Float64}(undef, length(model), spl.nparticles), 1)
-    finalizer(s -> ccall((:kabc_ais_destroy, libkabc), Cint, (Ptr{Cvoid},), s.handle), st)
-    generation!(st, ntransitions)
-    wrap(model, view(st.cache, :, spl.nparticles)), st
+# the sample a walker is emitted as: scalar (univariate prior), Tuple (Factored) or Vector
+function wrap(model, col)
+    pr = prior_of(model)
+    x = pr isa UnivariateDistribution ? col[1] : vector_valued(pr) || model isa CommonLogDensity ? collect(col) : Tuple(col)
+    KissABC.Particle(model isa CommonLogDensity ? x : KissABC.push_p(pr, x))   # Int for discrete components
 end
 
-# step(rng, model, spl, state; ntransitions) -- replaces src/KissABC.jl:66-80:
-# every N-th call advances one device generation (N x ntransitions transitions),
-# the calls in between are served from the host cache.
-function AbstractMCMC.step(rng::Random.AbstractRNG, model::AbstractMCMC.AbstractModel,
-                           spl::AISHip, st::AISHipState; ntransitions::Int = 1, kwargs...)
+# step(rng, model, spl; retry_sampling) -- replaces src/KissABC.jl:35-64.  As there, the first
+# sample is the LAST initial walker and no transition has run yet.
+function AbstractMCMC.step(rng::Random.AbstractRNG, model::DeviceModel, spl::AIS;
+                           retry_sampling::Int = 100, kwargs...)
+    N, D = spl.nparticles, length(model)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    with_model(model) do cm
+        check(ccall((:kabc_ais_create, libkabc), Cint, (Ptr{Cvoid}, Ref{KabcModel}, Int64, UInt64, Ref{Ptr{Cvoid}}),
+                    context(), cm, N, rand(rng, UInt64), h))   # N < D+5 -> the reference's message
+    end
+    st = AISHipState(h[], Matrix{Float64}(undef, D, N), N + 1)
+    finalizer(destroy!, st)
+    check(ccall((:kabc_ais_init, libkabc), Cint, (Ptr{Cvoid}, Int32), st.handle, retry_sampling))
+    x = Matrix{Float64}(undef, D, N)
+    check(ccall((:kabc_ais_get_ensemble, libkabc), Cint, (Ptr{Cvoid}, Ptr{Float64}), st.handle, x))
+    wrap(model, view(x, :, N)), st
+end
+
+# step(rng, model, spl, state; ntransitions) -- replaces src/KissABC.jl:66-80: every N-th call
+# advances one device generation (every walker `ntransitions` transitions = N reference
+# step() calls), the calls in between are served from the host cache.
+function AbstractMCMC.step(rng::Random.AbstractRNG, model::DeviceModel, spl::AIS, st::AISHipState;
+                           ntransitions::Int = 1, kwargs...)
     st.i > spl.nparticles && generation!(st, ntransitions)
     s = wrap(model, view(st.cache, :, st.i))
     st.i += 1
     s, st
 end
 
-AbstractMCMC.bundle_samples(samples::Vector{<:KissABC.Particle}, m::AbstractMCMC.AbstractModel,
-                            ::AISHip, state, T::Type; kwargs...) =
-    AbstractMCMC.bundle_samples(samples, m, KissABC.AIS(1), state, T; kwargs...)
+# bundle_samples / chainsstack are the reference's own (src/KissABC.jl:82-104): the samples are
+# ordinary `Particle`s
 
-# ---- smc ---------------------------------------------------------------------
-# smc(prior, cost::DeviceCost; ...) -- replaces src/smc.jl:92-206
+# sample(model, AIS(N), MCMCThreads(), Ns, Nc) -- src/KissABC.jl:96-104,108: the chains are ONE
+# batch handle (chain = a grid dimension of every launch), not Nc tasks
+function AbstractMCMC.sample(rng::Random.AbstractRNG, model::DeviceModel, spl::AIS, ::MCMCThreads,
+                             Ns::Integer, Nc::Integer; ntransitions::Int = 1, discard_initial::Int = 0,
+                             retry_sampling::Int = 100, chain_type::Type = Any, kwargs...)
+    N, D = spl.nparticles, length(model)
+    seeds = rand(rng, UInt64, Nc)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    with_model(model) do cm
+        check(ccall((:kabc_ais_create_batch, libkabc), Cint,
+                    (Ptr{Cvoid}, Ref{KabcModel}, Int64, Int32, Ptr{UInt64}, Ref{Ptr{Cvoid}}),
+                    context(), cm, N, Nc, seeds, h))
+    end
+    try
+        check(ccall((:kabc_ais_init, libkabc), Cint, (Ptr{Cvoid}, Int32), h[], retry_sampling))
+        gd, gk = cld(discard_initial, N), max(1, cld(Ns, N))
+        gd > 0 && check(ccall((:kabc_ais_advance, libkabc), Cint, (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Cvoid}),
+                              h[], gd, ntransitions, C_NULL, C_NULL))
+        tr = Array{Float64,4}(undef, D, N, Nc, gk)             # [gen][chain][N][D], column-major
+        check(ccall((:kabc_ais_advance, libkabc), Cint, (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Cvoid}),
+                    h[], gk, ntransitions, tr, C_NULL))
+        chains = map(1:Nc) do c
+            cols = reshape(permutedims(view(tr, :, :, c, :), (1, 2, 3)), D, N * gk)
+            samples = [wrap(model, view(cols, :, j)) for j in 1:Ns]
+            AbstractMCMC.bundle_samples(samples, model, spl, nothing, chain_type)
+        end
+        return AbstractMCMC.chainsstack(AbstractMCMC.tighten_eltype(chains))
+    finally
+        ccall((:kabc_ais_destroy, libkabc), Cint, (Ptr{Cvoid},), h[])
+    end
+end
+
+# ---- walker-sharded AIS over several GPUs (include/kabc.h "multi-GPU") ---------------------
+# One process, n GPUs: kabc_comm_init_all + kabc_ais_create_dist + the *_multi drivers; the
+# all-gather after every half-generation is issued inside the library (RCCL, or the P2P pull
+# kernel with backend = :p2p).  For one process per GPU (Distributed / MPI launch) use
+# `unique_id()` on rank 0, ship the 128 bytes, `comm_init_rank(id, rank, world; device)` on
+# every rank and pass the communicator to `sample_sharded(model, spl, comm, Ns)`.
+unique_id() = (id = Vector{UInt8}(undef, 128); check(ccall((:kabc_comm_unique_id, libkabc), Cint, (Ptr{UInt8},), id)); id)
+function comm_init_rank(id::Vector{UInt8}, rank::Integer, world::Integer; device::Integer = rank)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:kabc_comm_init_rank, libkabc), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Int32, Int32, Ref{Ptr{Cvoid}}),
+                context(device), id, rank, world, c))
+    c[]
+end
+
+function sample_sharded(model::DeviceModel, spl::AIS, devices::AbstractVector{<:Integer}, Ns::Integer;
+                        rng = Random.GLOBAL_RNG, ntransitions::Int = 1, discard_initial::Int = 0,
+                        retry_sampling::Int = 100, backend::Symbol = :rccl)
+    n, N, D = length(devices), spl.nparticles, length(model)
+    ctxs, comms = fill(C_NULL, n), fill(C_NULL, n)
+    check(ccall((:kabc_comm_init_all, libkabc), Cint, (Int32, Ptr{Int32}, Int32, Ptr{Ptr{Cvoid}}, Ptr{Ptr{Cvoid}}),
+                n, Int32.(devices), backend == :p2p ? 2 : 1, ctxs, comms))
+    hs, seed = fill(C_NULL, n), rand(rng, UInt64)
+    try
+        with_model(model) do cm
+            for r in 1:n
+                h = Ref{Ptr{Cvoid}}(C_NULL)
+                check(ccall((:kabc_ais_create_dist, libkabc), Cint, (Ptr{Cvoid}, Ref{KabcModel}, Int64, UInt64, Ref{Ptr{Cvoid}}),
+                            comms[r], cm, N, seed, h))
+                hs[r] = h[]
+            end
+        end
+        check(ccall((:kabc_ais_init_multi, libkabc), Cint, (Ptr{Ptr{Cvoid}}, Int32, Int32), hs, n, retry_sampling))
+        adv(g) = check(ccall((:kabc_ais_advance_multi, libkabc), Cint, (Ptr{Ptr{Cvoid}}, Int32, Int64, Int32, Ptr{Cvoid}),
+                             hs, n, g, ntransitions, C_NULL))
+        adv(cld(discard_initial, N))
+        gk = max(1, cld(Ns, N))
+        out = Array{Float64,3}(undef, D, N, gk)
+        for g in 1:gk                                             # the ensemble after each generation
+            adv(1)
+            check(ccall((:kabc_ais_get_ensemble, libkabc), Cint, (Ptr{Cvoid}, Ptr{Float64}), hs[1], view(out, :, :, g)))
+        end
+        cols = reshape(out, D, N * gk)
+        samples = [wrap(model, view(cols, :, j)) for j in 1:Ns]
+        return AbstractMCMC.bundle_samples(samples, model, spl, nothing, Any)
+    finally
+        foreach(h -> h != C_NULL && ccall((:kabc_ais_destroy, libkabc), Cint, (Ptr{Cvoid},), h), hs)
+        foreach(c -> c != C_NULL && ccall((:kabc_comm_destroy, libkabc), Cint, (Ptr{Cvoid},), c), comms)
+    end
+end
+
+# one process per GPU: every rank calls this with its communicator (comm_init_rank); the
+# returned samples are identical on all ranks
+function sample_sharded(model::DeviceModel, spl::AIS, comm::Ptr{Cvoid}, Ns::Integer; seed::UInt64,
+                        ntransitions::Int = 1, discard_initial::Int = 0, retry_sampling::Int = 100)
+    N, D = spl.nparticles, length(model)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    with_model(model) do cm
+        check(ccall((:kabc_ais_create_dist, libkabc), Cint, (Ptr{Cvoid}, Ref{KabcModel}, Int64, UInt64, Ref{Ptr{Cvoid}}),
+                    comm, cm, N, seed, h))                      # the same seed on every rank
+    end
+    try
+        check(ccall((:kabc_ais_init, libkabc), Cint, (Ptr{Cvoid}, Int32), h[], retry_sampling))
+        adv(g) = check(ccall((:kabc_ais_advance, libkabc), Cint, (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Cvoid}),
+                             h[], g, ntransitions, C_NULL, C_NULL))
+        adv(cld(discard_initial, N))
+        gk = max(1, cld(Ns, N))
+        out = Array{Float64,3}(undef, D, N, gk)
+        for g in 1:gk
+            adv(1)
+            check(ccall((:kabc_ais_get_ensemble, libkabc), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], view(out, :, :, g)))
+        end
+        cols = reshape(out, D, N * gk)
+        return AbstractMCMC.bundle_samples([wrap(model, view(cols, :, j)) for j in 1:Ns], model, spl, nothing, Any)
+    finally
+        ccall((:kabc_ais_destroy, libkabc), Cint, (Ptr{Cvoid},), h[])
+    end
+end
+
+# ---- smc / ABCDE / pfilter ---------------------------------------------------
+particles_of(prior, theta, keep) = begin
+    D = size(theta, 1)
+    P = [Particles(theta[k, keep]) for k in 1:D]                   # src/smc.jl:203
+    length(P) == 1 ? first(P) : P
+end
+kcost(c::DeviceCost) = KabcCost(c.id, length(c.params), pointer(c.params), length(c.data), pointer(c.data))
+
+# smc(prior, cost::DeviceCost; ...) -- replaces src/smc.jl:92-206, same keywords and defaults
 function KissABC.smc(prior::Distribution, cost::DeviceCost; rng = Random.GLOBAL_RNG,
                      nparticles::Int = 100, alpha = 0.95, mcmc_retrys::Int = 0, mcmc_tol = 0.015,
                      epstol = 0.0, r_epstol = (1 - alpha)^1.5 / 50, min_r_ess = alpha^2,
@@ -228,17 +437,52 @@ function KissABC.smc(prior::Distribution, cost::DeviceCost; rng = Random.GLOBAL_
                     max_stretch, rand(rng, UInt64), 0)
     r = KabcSmcResult(pointer(theta), pointer(C), pointer(alive), 0.0, 0, 0, 0, 0, C_NULL, 0, 0.0, 0)
     GC.@preserve pri cost theta C alive begin
-        kc = KabcCost(cost.id, length(cost.params), pointer(cost.params), length(cost.data),
-                      pointer(cost.data))
         check(ccall((:kabc_smc_run, libkabc), Cint,
-                    (Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcOpts},
-                     Ref{KabcSmcResult}), context(), pri, D, kc, o, r))
+                    (Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcOpts}, Ref{KabcSmcResult}),
+                    context(), pri, D, kcost(cost), o, r))          # argument errors: the reference's messages
     end
-    keep = findall(!=(0x00), alive)
-    P = [Particles(theta[k, keep]) for k in 1:D]      # src/smc.jl:203
-    length(P) == 1 && (P = first(P))
-    (P = P, C = C, ϵ = r.eps)
+    (P = particles_of(prior, theta, findall(!=(0x00), alive)), C = C, ϵ = r.eps)   # src/smc.jl:205
 end
 
-export AISHip, DeviceCost, UserCost, GaussDist, Rosenbrock, DiracSq, AbsDiff, NormShell, NoisyBanana
+# ABCDE(prior, cost::DeviceCost, ϵ_target; ...) -- replaces src/smc.jl:347-430
+function KissABC.ABCDE(prior::Distribution, cost::DeviceCost, ϵ_target; nparticles = 50, generations = 20,
+                       α = 0, parallel = false, earlystop = false, verbose = true,
+                       rng = Random.GLOBAL_RNG, proposal_width = 1.0)
+    pri = lower_prior(prior)
+    D, N = length(pri), nparticles
+    theta = Matrix{Float64}(undef, D, N)
+    C = Vector{Float64}(undef, N)
+    o = KabcAbcdeOpts(N, generations, ϵ_target, α, proposal_width, earlystop, verbose, rand(rng, UInt64))
+    r = KabcAbcdeResult(pointer(theta), pointer(C), 0, 0, 0, 0)
+    GC.@preserve pri cost theta C begin
+        check(ccall((:kabc_abcde_run, libkabc), Cint,
+                    (Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcAbcdeOpts}, Ref{KabcAbcdeResult}),
+                    context(), pri, D, kcost(cost), o, r))
+    end
+    (P = particles_of(prior, theta, 1:N), C = Particles(C), reached_ϵ = r.reached_eps != 0)   # src/smc.jl:425-430
+end
+
+# pfilter(prior, cost::DeviceCost, N; ...) -- replaces src/smc.jl:275-340
+function KissABC.pfilter(prior::Distribution, cost::DeviceCost, N; rng = Random.GLOBAL_RNG, q = 0.7,
+                         eff_tol = 0.1, epstol = -Inf, max_iters = Inf, proposal_width = 0.75,
+                         verbose = false, parallel = false)
+    pri = lower_prior(prior)
+    D = length(pri)
+    Neff = ccall((:kabc_pfilter_nparticles, libkabc), Int64, (Int64, Float64, Int32), N, q, D)   # :276-279
+    theta = Matrix{Float64}(undef, D, Neff)
+    C = Vector{Float64}(undef, Neff)
+    o = KabcPfilterOpts(N, q, eff_tol, epstol, proposal_width, isinf(max_iters) ? -1 : floor(Int64, max_iters),
+                        verbose, 0, rand(rng, UInt64))
+    r = KabcPfilterResult(pointer(theta), pointer(C), 0.0, 0.0, 0, 0, 0)
+    GC.@preserve pri cost theta C begin
+        check(ccall((:kabc_pfilter_run, libkabc), Cint,
+                    (Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcPfilterOpts}, Ref{KabcPfilterResult}),
+                    context(), pri, D, kcost(cost), o, r))
+    end
+    (P = particles_of(prior, theta, 1:Neff), C = Particles(C))     # src/smc.jl:334-340
+end
+
+export DeviceCost, UserCost, InitFrom, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
+       AbsDiff, NormShell, NoisyQuadDU, Mixture, NoisyBanana, WienerRms, sample_sharded, unique_id,
+       comm_init_rank
 end # module
