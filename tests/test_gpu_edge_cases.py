@@ -37,8 +37,15 @@ def test_max_dimension_and_beyond(k, orc, gpu_ctx):
                                         k.costs.GaussDist(np.linspace(-1, 1, D)), 0.5)
     got = k.AisEnsemble(model, D + 5, seed=2).init().advance(3, 4, collect=True)
     assert np.array_equal(got, orc.OracleAIS(model, D + 5, seed=2).init().generations_sync(3, 4))
+    # beyond KABC_MAX_DIM the run-time-dimension kernels take over (tests/test_gpu_dyn_dim.py) ...
+    m17 = k.ApproxKernelizedPosterior(k.Factored(*[k.Normal(0, 1)] * (D + 1)),
+                                      k.costs.GaussDist(np.linspace(-1, 1, D + 1)), 0.5)
+    got = k.AisEnsemble(m17, D + 6, seed=2).init().advance(3, 4, collect=True)
+    assert np.array_equal(got, orc.OracleAIS(m17, D + 6, seed=2).init().generations_sync(3, 4))
+    # ... up to KABC_MAX_DIM_DYN
+    from kissabc_jl_amd import _cdefs
     with pytest.raises(ValueError):
-        k.Factored(*[k.Normal(0, 1)] * (D + 1))
+        k.Factored(*[k.Normal(0, 1)] * (_cdefs.KABC_MAX_DIM_DYN + 1))
 
 
 def test_smc_minimal_particles_and_all_alive_ties(k, orc, gpu_ctx):
