@@ -369,6 +369,23 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
     unsigned nx_a = 0, nx_b = 0;
     double nx_s = 0.0, nx_lprob = 0.0;
     double nx_pre[kPre > 0 ? 2 * kPre : 1];
+    constexpr int kPreA = (kPre + 1) / 2;   // blocks expanded in the shadow of B1; the rest in B2's
+    uint64_t nps = 0;
+    // the second half of the cost's normal pairs (shadow of B2, or -- on a retry pass, which has
+    // no B2 -- right before the pass)
+    auto expand_rest = [&]() __attribute__((always_inline)) {
+        if constexpr (kPre > kPreA) {
+            if (in) {
+#pragma unroll
+                for (int j = kPreA; j < kPre; ++j) {
+                    const kabc_u128_t Bn =
+                        kabc_stream_block(A.seed, (uint32_t)i, nps, (uint32_t)j, KABC_DOM_SMC_COST);
+                    kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
+                                         kabc_log_tab);
+                }
+            }
+        }
+    };
 
     while (true) {
         // ================= publish: record of this workgroup (+ histogram of the predicted window)
@@ -437,7 +454,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
         // partner indices (:163-164), the stretch normal, log(rand), and the leading normal
         // pairs of the cost's own stream.  If the loop ends instead, the work is discarded.
         if (in) {
-            const uint64_t nps = pass + (iteration > 0 ? 2u : 1u);
+            nps = pass + (iteration > 0 ? 2u : 1u);
             const uint32_t w = (uint32_t)i;
             const kabc_u128_t B0 = kabc_stream_block(A.seed, w, nps, 0u, KABC_DOM_SMC_MOVE);
             const kabc_u128_t B1 = kabc_stream_block(A.seed, w, nps, 1u, KABC_DOM_SMC_MOVE);
@@ -454,9 +471,10 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             kabc_normal_pair(kabc_lo64(B1), kabc_hi64(B1), &z0, &z1);
             nx_s = A.max_stretch * z0 / kabc_sqrt((double)D);
             nx_lprob = kabc_log(kabc_u01(kabc_lo64(B2)));
+            // the cost's normal pairs: the first half here, the rest in the shadow of B2
             if constexpr (kPre > 0) {
 #pragma unroll
-                for (int j = 0; j < kPre; ++j) {
+                for (int j = 0; j < kPreA; ++j) {
                     const kabc_u128_t Bn = kabc_stream_block(A.seed, w, nps, (uint32_t)j, KABC_DOM_SMC_COST);
                     kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
                                          kabc_log_tab);
@@ -505,6 +523,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             const bool enough = (double)acc_iter >= A.loop.mcmc_tol * (double)N;  // :192
             if (passes_iter < A.retry_n && !enough) {
                 remap_pass = 0;  // later passes of an iteration read particle j from row j
+                expand_rest();
                 goto mcmc_pass;
             }
             if (bid == 0 && tid == 0 && A.log && iteration <= A.log_cap) {
@@ -645,7 +664,9 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                 }
             }
             KABC_LSTAMP(4)
-            if (!loop_barrier(g, G, q, &s_ok)) {
+            loop_barrier_arrive(g, G, q);
+            expand_rest();
+            if (!loop_barrier_wait(g, q, &s_ok)) {
                 error = 3;
                 break;
             }
