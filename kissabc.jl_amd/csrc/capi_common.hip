@@ -203,6 +203,8 @@ kabc_status_t kabc_ctx_create(int32_t device_id, void* stream, kabc_ctx_t** out)
 kabc_status_t kabc_ctx_destroy(kabc_ctx_t* ctx) {
     if (!ctx) return KABC_OK;
     (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& e : ctx->pool) (void)hipFree(e.second);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return KABC_OK;

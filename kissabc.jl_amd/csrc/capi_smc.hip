@@ -94,15 +94,43 @@ static void launch_smc_init(int D, const SmcInitArgs& a, hipStream_t s,
 }
 
 struct DevBufs {
-    std::vector<void*> ptrs;
+    kabc_ctx_t* ctx = nullptr;                         // set: buffers come from / go back to its cache
+    std::vector<std::pair<size_t, void*>> held;
+    static constexpr size_t kPoolCap = 512ull << 20;   // bytes kept per context
     ~DevBufs() {
-        for (void* p : ptrs)
-            if (p) (void)hipFree(p);
+        for (auto& e : held) {
+            if (!e.second) continue;
+            if (ctx) {
+                std::lock_guard<std::mutex> lk(ctx->pool_mu);
+                if (ctx->pool_bytes + e.first <= kPoolCap) {
+                    ctx->pool.push_back(e);
+                    ctx->pool_bytes += e.first;
+                    continue;
+                }
+            }
+            (void)hipFree(e.second);
+        }
     }
     template <class T>
     hipError_t alloc(T** p, size_t n) {
-        hipError_t e = hipMalloc(p, sizeof(T) * (n ? n : 1));
-        if (e == hipSuccess) ptrs.push_back(*p);
+        const size_t bytes = sizeof(T) * (n ? n : 1);
+        if (ctx) {  // smallest cached buffer that fits and is not more than twice too large
+            std::lock_guard<std::mutex> lk(ctx->pool_mu);
+            int best = -1;
+            for (int i = 0; i < (int)ctx->pool.size(); ++i)
+                if (ctx->pool[i].first >= bytes && ctx->pool[i].first <= 2 * bytes + 4096 &&
+                    (best < 0 || ctx->pool[i].first < ctx->pool[best].first))
+                    best = i;
+            if (best >= 0) {
+                held.push_back(ctx->pool[best]);
+                *p = (T*)ctx->pool[best].second;
+                ctx->pool_bytes -= ctx->pool[best].first;
+                ctx->pool.erase(ctx->pool.begin() + best);
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(p, bytes);
+        if (e == hipSuccess) held.push_back({bytes, (void*)*p});
         return e;
     }
 };
@@ -225,6 +253,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     DevBufs bufs;
+    bufs.ctx = ctx;
     double *th[2], *X[2], *lp[2], *d_params = nullptr, *d_data = nullptr, *d_out = nullptr,
            *d_Xout = nullptr;
     uint8_t* alive;
@@ -630,6 +659,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     DevBufs bufs;
+    bufs.ctx = ctx;
     double *th, *Cc, *lpi, *d_params = nullptr, *d_data = nullptr, *d_out, *d_cout;
     uint8_t *ones, *ok, *pending;
     int32_t* cidx;

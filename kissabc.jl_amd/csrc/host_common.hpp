@@ -7,6 +7,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "kabc_device.hpp"
 
@@ -37,6 +40,13 @@ struct kabc_ctx {
     int device;
     hipStream_t stream;
     bool own_stream;
+    // scratch-buffer cache of the run-to-completion entry points (kabc_smc_run, kabc_pfilter_run):
+    // a C4 smc run allocates ~15 device buffers; hipMalloc / hipFree per call cost more than a
+    // tenth of the run.  Buffers return here instead of to the driver and are handed out again
+    // (best fit) by the next call on this context; released by kabc_ctx_destroy.
+    std::mutex pool_mu;
+    std::vector<std::pair<size_t, void*>> pool;
+    size_t pool_bytes = 0;
 };
 
 // ---- communicators (capi_comm.hip) ------------------------------------------------
