@@ -31,8 +31,8 @@ extern "C" {
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
 /* AIS accepts length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM a run-time-dimension
  * kernel keeps the walker rows in memory (several times slower per evaluation, same results).
- * smc / ABCDE / pfilter and user cost plugins stop at KABC_MAX_DIM.  The reference has no
- * bound (src/priors.jl:10-13). */
+ * User cost plugins follow.  smc / ABCDE / pfilter stop at KABC_MAX_DIM.  The reference has
+ * no bound (src/priors.jl:10-13). */
 #define KABC_MAX_DIM_DYN 256
 
 typedef enum kabc_status {

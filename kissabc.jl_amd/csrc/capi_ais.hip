@@ -213,10 +213,20 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         return KABC_ERR_UNSUPPORTED;
     }
     const bool dyn = m->D > KABC_MAX_DIM;
-    if (dyn && (nchains != 1 || m->cost.id >= KABC_COST_USER)) {
-        set_error("length(prior) = %d > %d runs on the run-time-dimension kernels: built-in "
-                  "DeviceCosts, one chain per handle", m->D, KABC_MAX_DIM);
-        return KABC_ERR_UNSUPPORTED;
+    AisDynLaunchFn dyn_fn = nullptr;
+    if (dyn) {
+        if (m->cost.id >= KABC_COST_USER) {
+            const CostPlugin* pl = find_plugin(m->cost.id);
+            dyn_fn = (pl && pl->ais_dyn) ? (AisDynLaunchFn)pl->ais_dyn() : nullptr;
+        } else {
+            dyn_fn = find_ais_dyn_kernel();
+        }
+        if (nchains != 1 || !dyn_fn) {
+            set_error("length(prior) = %d > %d runs on the run-time-dimension kernels: one chain per "
+                      "handle, built-in DeviceCosts or a plugin built from the current headers",
+                      m->D, KABC_MAX_DIM);
+            return KABC_ERR_UNSUPPORTED;
+        }
     }
     // src/KissABC.jl:43-48
     if (n_total < m->D + 5) {
@@ -263,7 +273,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->eps = m->eps;
     std::memset(h->raw, 0, sizeof h->raw);
     std::memset(&h->prior, 0, sizeof h->prior);
-    h->dyn = dyn ? find_ais_dyn_kernel() : nullptr;
+    h->dyn = dyn_fn;
     h->d_raw = nullptr;
     h->d_scratch = nullptr;
     bool prior_ok = true;

@@ -87,8 +87,8 @@ struct PriorUtilArgs {
     uint64_t attempt;
     uint32_t first_walker;
     uint32_t domain;
-    PriorSet prior;
-    kabc_prior_t raw[KABC_MAX_DIM];
+    const PriorDev* prior;     // [D] prepared components (device; any D up to KABC_MAX_DIM_DYN)
+    const kabc_prior_t* raw;   // [D] raw components (device)
 };
 
 __global__ void __launch_bounds__(256) prior_logpdf_kernel(const PriorUtilArgs A) {
@@ -97,12 +97,13 @@ __global__ void __launch_bounds__(256) prior_logpdf_kernel(const PriorUtilArgs A
     double s = 0.0;
     for (int k = 0; k < A.D; ++k) {
         const double xv = A.x[i * A.D + k];
-        const double v = A.prior.c[k].discrete ? kabc_rint(xv) : xv;
+        const PriorDev q = A.prior[k];
+        const double v = q.discrete ? kabc_rint(xv) : xv;
         if (A.mode == 1) {
             A.out[i * A.D + k] = v;
         } else {
             // logpdf(Factored, x) is evaluated on x as given (src/priors.jl:30-36)
-            const double l = comp_logpdf(A.prior.c[k].kind, A.prior.c[k], xv);
+            const double l = comp_logpdf(q.kind, q, xv);
             s = (k == 0) ? l : s + l;
         }
     }
@@ -115,7 +116,8 @@ __global__ void __launch_bounds__(256) prior_rand_kernel(const PriorUtilArgs A) 
     for (int k = 0; k < A.D; ++k) {
         kabc_slotwin_t win = {A.seed, A.attempt, A.first_walker + (uint32_t)i, A.domain,
                               (uint32_t)k * KABC_SLOTS_PER_DIM};
-        A.out[i * A.D + k] = kabc_sample_prior(&A.raw[k], &win);
+        const kabc_prior_t pr = A.raw[k];
+        A.out[i * A.D + k] = kabc_sample_prior(&pr, &win);
     }
 }
 
@@ -244,13 +246,26 @@ static kabc_status_t prior_util(kabc_ctx_t* ctx, const kabc_prior_t* prior, int3
     }
     PriorUtilArgs A;
     std::memset(&A, 0, sizeof A);
-    if (!prepare_priors(prior, D, A.prior)) {
-        set_error("invalid prior (kind/parameters) or D outside 1..%d", KABC_MAX_DIM);
+    if (D < 1 || D > KABC_MAX_DIM_DYN) {
+        set_error("invalid prior: D outside 1..%d", KABC_MAX_DIM_DYN);
         return KABC_ERR_INVALID_ARG;
     }
+    std::vector<PriorDev> prep((size_t)D);
+    for (int k = 0; k < D; ++k)
+        if (!prepare_prior(prior[k], prep[k])) {
+            set_error("invalid prior (kind/parameters) of component %d", k + 1);
+            return KABC_ERR_INVALID_ARG;
+        }
     if (n == 0) return KABC_OK;
-    std::memcpy(A.raw, prior, sizeof(kabc_prior_t) * D);
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    PriorDev* d_prep = nullptr;
+    kabc_prior_t* d_raw = nullptr;
+    KABC_HIP_CHECK(hipMalloc(&d_prep, sizeof(PriorDev) * D));
+    KABC_HIP_CHECK(hipMalloc(&d_raw, sizeof(kabc_prior_t) * D));
+    KABC_HIP_CHECK(hipMemcpyAsync(d_prep, prep.data(), sizeof(PriorDev) * D, hipMemcpyHostToDevice, ctx->stream));
+    KABC_HIP_CHECK(hipMemcpyAsync(d_raw, prior, sizeof(kabc_prior_t) * D, hipMemcpyHostToDevice, ctx->stream));
+    A.prior = d_prep;
+    A.raw = d_raw;
     const size_t in_bytes = sizeof(double) * n * D;
     const size_t out_bytes = sizeof(double) * n * ((mode == 0) ? 1 : D);
     double *dx = nullptr, *dout = nullptr;
@@ -278,6 +293,8 @@ static kabc_status_t prior_util(kabc_ctx_t* ctx, const kabc_prior_t* prior, int3
     KABC_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (dx) (void)hipFree(dx);
     (void)hipFree(dout);
+    (void)hipFree(d_prep);
+    (void)hipFree(d_raw);
     return KABC_OK;
 }
 

@@ -70,3 +70,31 @@ def test_dynamic_dimension_limits_and_sharding(k, orc, gpu_ctx):
     xo, lpo, llo, _ = o.state()
     assert np.array_equal(x, xo) and np.array_equal(lp, lpo) and np.array_equal(ll, llo)
     grp.close()
+
+
+def test_dynamic_dimension_user_cost_and_utilities(k, orc, gpu_ctx):
+    """A run-time compiled user cost at D = 20 (the plugin carries its own instantiation of
+    the run-time-dimension kernels), and the Factored utilities (logpdf / push_p / rand on
+    the device) beyond 16 components."""
+    src = """
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
+                              const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
+    double z0, z1, s = 0.0;
+    kabc_cost_rng_normal2(rng, &z0, &z1);
+    for (int k = 0; k < D; ++k) s += (x[k] - params[0]) * (x[k] - params[0]);
+    return kabc_sqrt(s) + 0.01 * kabc_fabs(z0);
+}"""
+    cost = k.costs.UserCost(src, dims=[20], params=[0.25], name="dyn_user", posteriors=["kernelized"])
+    orc.register_user_cost(cost)
+    pri = k.Factored(*[k.Normal(0, 1)] * 19, k.DiscreteUniform(-2, 2))
+    model = k.ApproxKernelizedPosterior(pri, cost, 0.7)
+    e = k.AisEnsemble(model, 200, seed=5).init()
+    tr = e.advance(3, 5, collect=True)
+    o = orc.OracleAIS(model, 200, seed=5).init()
+    assert np.array_equal(tr, o.generations_sync(3, 5))
+    assert e.stats() == o.stats()
+    e.close()
+    x = np.random.default_rng(1).normal(size=(64, 20))
+    assert np.array_equal(pri.logpdf(x), orc.factored_logpdf(pri, x))
+    assert np.array_equal(pri.push_p(x), orc.push_p(pri, x))
+    assert np.array_equal(pri.rand(32, seed=3), orc.push_p(pri, orc.factored_rand(pri, 32, seed=3)))
