@@ -220,7 +220,8 @@ template <int D>
 __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R, int si,
                                                 uint64_t t, uint32_t w_base, int n_active,
                                                 uint8_t* listB, int lane,
-                                                const double* logtab) {
+                                                const double* logtab,
+                                                const kabc_u128_t* pre01 = nullptr) {
     constexpr int NB = RecGeom<D>::NB;
     const uint64_t nc = (uint64_t)A.n_comp;
     const bool active = lane < n_active;
@@ -229,8 +230,9 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     // -- phase A: one (walker, t) per lane: move id, partner a, log u, stretch factor
     if (active) {
         const uint32_t w = w_base + (uint32_t)lane;
-        const kabc_u128_t B0 = kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_AIS_MOVE);
-        const kabc_u128_t B1 = kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_AIS_MOVE);
+        // (the prologue hands over the two blocks it expanded while the table was in flight)
+        const kabc_u128_t B0 = pre01 ? pre01[0] : kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_AIS_MOVE);
+        const kabc_u128_t B1 = pre01 ? pre01[1] : kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_AIS_MOVE);
         const uint32_t m7 = (uint32_t)(((uint64_t)B0.w[2] * 7u) >> 32);  // rand((1,1,1,1,2,2,3))
         move = (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
         a = kabc_index32(kabc_lo64(B0), (uint32_t)nc);
@@ -399,7 +401,9 @@ ais_half_kernel(const AisArgs A0) {
         if (!ld_valid(PK, lp, ll)) err = 2;  // accept(): "old log-density is invalid"
     }
 
-    for (int j = threadIdx.x; j < KABC_MATH_TAB_WORDS; j += kAisBlock) slogtab[j] = kabc_log_tab[j];
+    // the table's loads are issued here and land in LDS right before the barrier below
+    static_assert(KABC_MATH_TAB_WORDS == 2 * kAisBlock, "two table words per thread");
+    const double tab0 = kabc_log_tab[threadIdx.x], tab1 = kabc_log_tab[threadIdx.x + kAisBlock];
     if (threadIdx.x < D * (int)(sizeof(PriorDev) / 8))
         reinterpret_cast<double*>(sprior)[threadIdx.x] =
             reinterpret_cast<const double*>(A.prior)[threadIdx.x];
@@ -416,7 +420,18 @@ ais_half_kernel(const AisArgs A0) {
     double blo[kBoxRegs ? D : 1], bhi[kBoxRegs ? D : 1];
     const BoxPrior box = {kBoxRegs ? blo : sbox_lo, kBoxRegs ? bhi : sbox_hi, dmask, A.box_lp};
 
+    // while the table's loads are in flight the producers expand the two Philox blocks
+    // every lane of their first sub-step needs (they depend on nothing else)
+    kabc_u128_t pro01[2] = {};
+    if (wave > 0 && wave - 1 < A.nt && lane < n_active) {
+        const uint32_t w = w_base + (uint32_t)lane;
+        const uint64_t t = A.t0 + (uint64_t)(wave - 1);
+        pro01[0] = kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_AIS_MOVE);
+        pro01[1] = kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_AIS_MOVE);
+    }
     // the log table is staged by all four waves and read by the producers right away
+    slogtab[threadIdx.x] = tab0;
+    slogtab[threadIdx.x + kAisBlock] = tab1;
     KABC_TIMED_BARRIER();
     if constexpr (kBoxRegs) {  // per-lane copies from LDS (vector registers: scalar ones ran
                                // out and spilled when these were loaded as uniform values)
@@ -432,7 +447,7 @@ ais_half_kernel(const AisArgs A0) {
         const int si = wave - 1;
         if (si < A.nt && !(KABL & 4)) {
             produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
-                               lane, slogtab);
+                               lane, slogtab, pro01);
             if constexpr (kAuxW > 0)
                 prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)si, w_base, lane, saux[0][si],
                                               slogtab);
@@ -618,8 +633,8 @@ ais_half_kernel(const AisArgs A0) {
             }
         }
         // one atomic per batch and counter
-        const unsigned long long se = wave_sum(n_eval);
-        const unsigned long long sa = wave_sum(n_acc);
+        const unsigned long long se = wave_total_u32(n_eval);   // n <= ntransitions per lane
+        const unsigned long long sa = wave_total_u32(n_acc);
         if (lane == 0) {
             unsigned long long* sl =
                 A.slots + (size_t)((blockIdx.x + blockIdx.y * gridDim.x) & (kCounterSlots - 1)) * 8;

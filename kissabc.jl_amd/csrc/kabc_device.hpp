@@ -239,6 +239,25 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// inclusive prefix sum over the 64 lanes with DPP (row_shr 1/2/4/8, row_bcast 15/31): six
+// VALU instructions instead of six LDS-crossbar shuffles (each ~100 cycles of latency)
+__device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return v;
+}
+
+// sum of a 32-bit per-lane counter over the wavefront, as a wave-uniform value (the inclusive
+// scan's last lane): ~8 VALU instead of 12 dependent LDS-crossbar shuffles (~1 us at the very
+// end of every launch of the AIS kernel)
+__device__ __forceinline__ unsigned wave_total_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_readlane((int)wave_scan_incl(v), kWave - 1);
+}
+
 // compile-time mirror of kabc_cost_dim_ok (include/kabc_costs.h)
 constexpr bool cost_dim_ok_c(int id, int D) {
     switch (id) {

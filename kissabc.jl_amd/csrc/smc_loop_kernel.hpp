@@ -106,18 +106,6 @@ __device__ __forceinline__ unsigned long long wave_sum_all(unsigned long long v)
     return v;
 }
 
-// inclusive prefix sum over the 64 lanes with DPP (row_shr 1/2/4/8, row_bcast 15/31): six
-// VALU instructions instead of six LDS-crossbar shuffles (each ~100 cycles of latency)
-__device__ __forceinline__ unsigned wave_scan_incl(unsigned v) {
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31
-    return v;
-}
-
 // Device-wide barrier number `nb` (0-based) of the G resident workgroups.  A monotonically
 // increasing arrival counter (no reset) and a generation word on its own cache line: the
 // workgroup whose arrival completes the count publishes generation nb + 1, the others poll
