@@ -185,16 +185,33 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         lp = factored_logpdf_push<D, PC == kPriorSimple>(P, y, yp);
     }
     ev = kabc_isfinite(lp);
+    // A cheap deterministic cost is evaluated for every lane and selected afterwards: the
+    // divergent region around it (exec save / branch / restore) costs the consumer wave more
+    // issue slots than the arithmetic it would skip, and in practice some lane always needs it.
+    constexpr bool kCheap = COST == KABC_COST_GAUSS_DIST || COST == KABC_COST_ROSENBROCK ||
+                            COST == KABC_COST_DIRAC_SQ || COST == KABC_COST_ABS_DIFF ||
+                            COST == KABC_COST_NORM_SHELL;
     if (posterior == KABC_POSTERIOR_KERNELIZED) {
-        ll = lp;
-        if (ev) {
+        if constexpr (kCheap) {
             const double c = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
             const double q = kabc_div_rc(c, eps, reps);
-            ll = -0.5 * (q * q);
+            ll = ev ? -0.5 * (q * q) : lp;
+        } else {
+            ll = lp;
+            if (ev) {
+                const double c = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
+                const double q = kabc_div_rc(c, eps, reps);
+                ll = -0.5 * (q * q);
+            }
         }
     } else {
-        ll = -lp;
-        if (ev) ll = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
+        if constexpr (kCheap) {
+            const double c = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
+            ll = ev ? c : -lp;
+        } else {
+            ll = -lp;
+            if (ev) ll = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
+        }
     }
 }
 
@@ -555,22 +572,24 @@ ais_half_kernel(const AisArgs A0) {
                 // accept(...)  src/types.jl:62-75, :96-104
                 // (the old state's validity is checked once, before the first sub-step: it
                 // can only change through an accept, which requires a valid new state)
-                bool acc = false;
-                if (!kabc_isfinite(corr)) err = err ? err : 1;
-                else if (ld_valid(PK, nlp, nll)) {
-                    const double e = -logu;  // randexp(rng)
-                    if (PK == KABC_POSTERIOR_KERNELIZED) {
-                        const double lW = corr + (nlp + nll) - (lp + ll);
-                        acc = (-e <= lW);
-                    } else if (PK == KABC_POSTERIOR_COMMON) {
-                        const double lW = corr + nll - ll;  // src/types.jl:127
-                        acc = (-e <= lW);
-                    } else {
-                        const double lW = corr + nlp - lp;
-                        const double mx = (A.eps > ll) ? A.eps : ll;
-                        const double lW2 = mx - nll;
-                        acc = (-e <= lW) && (lW2 >= 0.0);
-                    }
+                // straight-line: every comparison is evaluated, the flags are combined (a NaN /
+                // Inf log-density makes `valid` false whatever the comparisons say)
+                const bool okc = kabc_isfinite(corr);
+                err = (!okc && err == 0) ? 1 : err;
+                const bool valid = okc && ld_valid(PK, nlp, nll);
+                const double e = -logu;  // randexp(rng)
+                bool acc;
+                if (PK == KABC_POSTERIOR_KERNELIZED) {
+                    const double lW = corr + (nlp + nll) - (lp + ll);
+                    acc = valid && (-e <= lW);
+                } else if (PK == KABC_POSTERIOR_COMMON) {
+                    const double lW = corr + nll - ll;  // src/types.jl:127
+                    acc = valid && (-e <= lW);
+                } else {
+                    const double lW = corr + nlp - lp;
+                    const double mx = (A.eps > ll) ? A.eps : ll;
+                    const double lW2 = mx - nll;
+                    acc = valid && (-e <= lW) && (lW2 >= 0.0);
                 }
                 if (acc) {
 #pragma unroll
