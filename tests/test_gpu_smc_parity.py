@@ -136,3 +136,16 @@ def _oracle_c4(orc, prior, cost, kw):
     if "r" not in _C4_ORACLE:      # 1.7 s of CPU, once for the three cases
         _C4_ORACLE["r"] = orc.smc(prior, cost, **kw)
     return _C4_ORACLE["r"]
+
+
+def test_kernel_path_beyond_the_loop_kernel(k, orc, gpu_ctx, monkeypatch):
+    """More than 65 536 particles: the alive mask no longer fits the loop kernel's LDS, the
+    kernel-per-phase path (cooperative 32-workgroup select) takes over on its own."""
+    monkeypatch.delenv("KABC_SMC_LOOP", raising=False)
+    pri = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    kw = dict(nparticles=100001, alpha=0.9, epstol=0.3, seed=6)
+    got = k.smc(pri, k.costs.GaussDist([1.0, -0.5]), return_array=True, **kw)
+    ref = orc.smc(pri, k.costs.GaussDist([1.0, -0.5]), **kw)
+    assert got.info["log"] == ref["log"] and got.eps == ref["eps"]
+    assert np.array_equal(got.info["theta_all"], ref["theta_all"])
+    assert np.array_equal(got.info["alive"], ref["alive"])
