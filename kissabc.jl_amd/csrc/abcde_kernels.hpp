@@ -36,7 +36,42 @@ struct AbcdeArgs {
     double gamma;  // proposal_width * 2.38 / sqrt(2 * length(prior))  (:370)
     PriorSet prior;
     kabc_prior_t raw[KABC_MAX_DIM];
+    // Rank structure of the current generation (capi_abcde.hip, large N): the costs in ascending
+    // order and a wavelet matrix over the particle indices in that order.  It answers the
+    // reference's donor draw  s = rand((1:N)[Δs .<= Δs[i]])  (:392) -- "the m-th smallest index
+    // among the particles whose cost does not exceed mine" -- in O(log N) instead of two O(N)
+    // scans per particle.  NULL = scan (small N).
+    const double* sorted_delta;          // [N]
+    const unsigned long long* wm_bits;   // [levels][wm_words]: bit p of level b = bit b of the
+                                         // p-th index of the sequence entering that level
+    const unsigned* wm_cnt;              // [levels][wm_words]: ones before each word
+    const unsigned* wm_nz;               // [levels]: zeros of the level
+    int32_t wm_levels;
+    int64_t wm_words;
 };
+
+// k-th smallest (0-based) of the first c indices of the cost-sorted order
+__device__ __forceinline__ unsigned wm_quantile(const AbcdeArgs& A, unsigned c, unsigned k) {
+    unsigned l = 0, r = c, val = 0;
+    for (int b = A.wm_levels - 1; b >= 0; --b) {
+        const unsigned long long* bits = A.wm_bits + (size_t)b * A.wm_words;
+        const unsigned* cnt = A.wm_cnt + (size_t)b * A.wm_words;
+        const unsigned ol = cnt[l >> 6] + (unsigned)__popcll(bits[l >> 6] & ((1ull << (l & 63u)) - 1ull));
+        const unsigned orr = cnt[r >> 6] + (unsigned)__popcll(bits[r >> 6] & ((1ull << (r & 63u)) - 1ull));
+        const unsigned zl = l - ol, zr = r - orr, zeros = zr - zl;
+        if (k < zeros) {
+            l = zl;
+            r = zr;
+        } else {
+            k -= zeros;
+            const unsigned nz = A.wm_nz[b];
+            l = nz + ol;
+            r = nz + orr;
+            val |= 1u << b;
+        }
+    }
+    return val;
+}
 
 constexpr int kAbcdeBlock = 64;
 constexpr unsigned kAbcdeMaxInitTries = 100000u;
@@ -136,9 +171,21 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_gen_kernel(const AbcdeArgs 
             const kabc_u128_t B1 = kabc_stream_block(A.seed, w, g, 1u, KABC_DOM_ABCDE_MOVE);
             int64_t s = i;
             const double eps = (di <= A.eps_target) ? A.eps_target : A.ctrl->eps_pop;  // :390
-            if (di > eps) {
-                // s = rand(trng, (1:N)[Δs .<= Δs[i]])  (:392): the m-th index, in ascending
-                // order, whose cost does not exceed ours
+            if (di > eps && A.sorted_delta) {
+                // s = rand(trng, (1:N)[Δs .<= Δs[i]])  (:392) through the rank structure:
+                // c = #{Δ <= Δ_i} by bisection of the sorted costs, then the m-th smallest
+                // index among the first c entries of the cost-sorted order
+                int64_t lo = 0, hi = N;  // first position whose cost exceeds di
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (A.sorted_delta[mid] <= di) lo = mid + 1;
+                    else hi = mid;
+                }
+                const int64_t m = (int64_t)kabc_index(kabc_lo64(B0), (uint64_t)lo);
+                s = (int64_t)wm_quantile(A, (unsigned)lo, (unsigned)m);
+            } else if (di > eps) {
+                // the same by two scans (small N): the m-th index, in ascending order, whose
+                // cost does not exceed ours
                 int64_t c = 0;
                 for (int64_t j = 0; j < N; ++j) c += (DL[j] <= di) ? 1 : 0;
                 int64_t m = (int64_t)kabc_index(kabc_lo64(B0), (uint64_t)c);

@@ -4,6 +4,8 @@
 #include <cmath>
 #include <vector>
 
+#include <hipcub/hipcub.hpp>
+
 #define KABC_ABCDE_SINGLE_UNIT 1
 #include "abcde_kernels.hpp"
 #include "host_common.hpp"
@@ -30,6 +32,78 @@ template <int... Ds>
 static AbcdeLaunchFn pick_gen(int D, std::integer_sequence<int, Ds...>) {
     static const AbcdeLaunchFn f[] = {&l_gen<Ds + 1>...};
     return f[D - 1];
+}
+
+// ---- rank structure (the donor draw was O(N) per particle) ------------------------
+constexpr int64_t kRankMinN = 4096;  // below this the two scans are cheaper than building it
+
+__global__ void __launch_bounds__(256) wm_iota_kernel(unsigned* v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = (unsigned)i;
+}
+// bit b of every element of the sequence entering level b, packed 64 per word
+__global__ void __launch_bounds__(256) wm_bits_kernel(const unsigned* seq, int64_t n, int b,
+                                                      unsigned long long* bits, int64_t words) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool one = p < n && ((seq[p] >> b) & 1u);
+    const unsigned long long m = __ballot(one);
+    if ((threadIdx.x & 63) == 0 && (p >> 6) < words) bits[p >> 6] = m;
+}
+// exclusive prefix of the words' popcounts (ones before each word) and the level's zero count
+__global__ void __launch_bounds__(1024) wm_count_kernel(const unsigned long long* bits, int64_t words,
+                                                        int64_t n, unsigned* cnt, unsigned* nz) {
+    __shared__ unsigned s_w[16];
+    __shared__ unsigned s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int64_t w0 = 0; w0 < words; w0 += 1024) {
+        const int64_t w = w0 + threadIdx.x;
+        const unsigned c = w < words ? (unsigned)__popcll(bits[w]) : 0u;
+        const unsigned incl = wave_scan_incl(c);
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned off = s_run, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < (int)(threadIdx.x >> 6)) off += s_w[q];
+            tot += s_w[q];
+        }
+        if (w < words) cnt[w] = off + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *nz = (unsigned)n - s_run;
+}
+
+struct RankStructure {
+    double* sorted = nullptr;
+    unsigned *iota = nullptr, *seq[2] = {nullptr, nullptr}, *cnt = nullptr, *nz = nullptr;
+    unsigned long long* bits = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    int levels = 0;
+    int64_t words = 0;
+};
+
+// sorted costs + wavelet matrix of the cost-sorted particle order, all on stream s
+static hipError_t build_rank(const RankStructure& R, const double* delta, int64_t N, hipStream_t s) {
+    size_t tb = R.tmp_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(R.tmp, tb, delta, R.sorted, R.iota, R.seq[0],
+                                                      (int)N, 0, 64, s);
+    int cur = 0;
+    const unsigned g256 = (unsigned)((R.words * 64 + 255) / 256);
+    for (int b = R.levels - 1; b >= 0 && e == hipSuccess; --b) {
+        unsigned long long* bits = R.bits + (size_t)b * R.words;
+        hipLaunchKernelGGL(wm_bits_kernel, dim3(g256), dim3(256), 0, s, R.seq[cur], N, b, bits, R.words);
+        hipLaunchKernelGGL(wm_count_kernel, dim3(1), dim3(1024), 0, s, bits, R.words, N,
+                           R.cnt + (size_t)b * R.words, R.nz + b);
+        if (b > 0) {  // stable partition by bit b: the sequence entering the next level
+            tb = R.tmp_bytes;
+            e = hipcub::DeviceRadixSort::SortKeys(R.tmp, tb, R.seq[cur], R.seq[1 - cur], (int)N, b, b + 1, s);
+            cur ^= 1;
+        }
+    }
+    return e == hipSuccess ? hipGetLastError() : e;
 }
 
 }  // namespace kabc
@@ -141,8 +215,40 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     A.dom_init_cost = KABC_DOM_ABCDE_INIT_COST;
     f_init(A, s);
     KABC_HIP_CHECK(hipGetLastError());
+    // large ensembles: a rank structure per generation replaces the O(N) donor scans
+    RankStructure R;
+    if (N >= kRankMinN) {
+        R.levels = 1;
+        while ((1ll << R.levels) < N) ++R.levels;
+        R.words = (N + 64) / 64;  // one word past position N (rank queries at p = N)
+        KABC_HIP_CHECK(alloc((void**)&R.sorted, sizeof(double) * N));
+        KABC_HIP_CHECK(alloc((void**)&R.iota, sizeof(unsigned) * N));
+        KABC_HIP_CHECK(alloc((void**)&R.seq[0], sizeof(unsigned) * N));
+        KABC_HIP_CHECK(alloc((void**)&R.seq[1], sizeof(unsigned) * N));
+        KABC_HIP_CHECK(alloc((void**)&R.bits, sizeof(unsigned long long) * R.levels * R.words));
+        KABC_HIP_CHECK(alloc((void**)&R.cnt, sizeof(unsigned) * R.levels * R.words));
+        KABC_HIP_CHECK(alloc((void**)&R.nz, sizeof(unsigned) * R.levels));
+        size_t t1 = 0, t2 = 0;
+        KABC_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const double*)nullptr, (double*)nullptr,
+                                                          (const unsigned*)nullptr, (unsigned*)nullptr, (int)N,
+                                                          0, 64, s));
+        KABC_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, t2, (const unsigned*)nullptr,
+                                                         (unsigned*)nullptr, (int)N, 0, 1, s));
+        R.tmp_bytes = t1 > t2 ? t1 : t2;
+        KABC_HIP_CHECK(alloc(&R.tmp, R.tmp_bytes));
+        hipLaunchKernelGGL(wm_iota_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, R.iota, N);
+        A.sorted_delta = R.sorted;
+        A.wm_bits = R.bits;
+        A.wm_cnt = R.cnt;
+        A.wm_nz = R.nz;
+        A.wm_levels = R.levels;
+        A.wm_words = R.words;
+    }
     for (int64_t g = 0; g < o->generations; ++g) {  // while iters < generations (:372)
         hipLaunchKernelGGL(abcde_extrema_kernel, dim3(1), dim3(1024), 0, s, A);
+        // the buffer set flips once per generation until the earlystop break, after which every
+        // kernel is a no-op: the host knows which one is current
+        if (R.sorted) KABC_HIP_CHECK(build_rank(R, A.delta[g & 1], N, s));
         f_gen(A, s);
         hipLaunchKernelGGL(abcde_flip_kernel, dim3(1), dim3(1), 0, s, A.ctrl);
     }

@@ -42,3 +42,26 @@ def test_abcde_bit_exact(k, orc, gpu_ctx, name):
     assert got.reached_ϵ == ref["reached_eps"]
     assert got.info["generations_run"] == ref["generations_run"]
     assert got.info["nsims"] == ref["nsims"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["gauss_5000", "ties_4096", "early_9000", "power2_8192"])
+def test_abcde_rank_structure_bit_exact(k, orc, gpu_ctx, name):
+    """From 4096 particles on, the donor draw s = rand((1:N)[Δs .<= Δs[i]]) (src/smc.jl:392)
+    goes through a per-generation rank structure (costs sorted by rocPRIM, a wavelet matrix over
+    the particle order) instead of two O(N) scans per particle; the oracle keeps the scans.
+    Heavy ties (integer-valued costs) make the <= prefix sets differ from the strict ranks."""
+    N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    du = k.Factored(k.DiscreteUniform(-30, 30), k.DiscreteUniform(-30, 30))
+    cases = {
+        "gauss_5000": (N2, k.costs.GaussDist([1.0, -0.5]), 0.05, dict(nparticles=5000, generations=12)),
+        "ties_4096": (du, k.costs.GaussDist([3.0, -2.0]), 0.5, dict(nparticles=4096, generations=10)),
+        "early_9000": (N2, k.costs.GaussDist([1.0, -0.5]), 2.0,
+                       dict(nparticles=9000, generations=10, alpha=0.3, earlystop=True)),
+        "power2_8192": (N2, k.costs.NoisyBanana(0.0), 0.5, dict(nparticles=8192, generations=6)),
+    }
+    pri, cost, eps, kw = cases[name]
+    got = k.ABCDE(pri, cost, eps, seed=9, return_array=True, **kw)
+    ref = orc.abcde(pri, cost, eps, seed=9, **kw)
+    assert np.array_equal(got.P, ref["P"]) and np.array_equal(got.C, ref["C"])
+    assert got.info["generations_run"] == ref["generations_run"] and got.info["nsims"] == ref["nsims"]

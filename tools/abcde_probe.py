@@ -14,8 +14,8 @@ from oracle import oracle as orc  # noqa: E402
 N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
 cost = k.costs.GaussDist([1.0, -0.5])
 out = {}
-for N in (1000, 16384):
-    kw = dict(nparticles=N, generations=50, seed=3)
+for N in (1000, 16384, 65536):
+    kw = dict(nparticles=N, generations=50 if N <= 16384 else 10, seed=3)
     k.ABCDE(N2, cost, 0.01, return_array=True, **kw)
     t0 = time.perf_counter()
     r = k.ABCDE(N2, cost, 0.01, return_array=True, **kw)
