@@ -29,9 +29,9 @@ extern "C" {
 
 #define KABC_VERSION 200 /* 0.2.0 */
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
-/* AIS accepts length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM a run-time-dimension
- * kernel keeps the walker rows in memory (several times slower per evaluation, same results).
- * User cost plugins follow.  smc / ABCDE / pfilter stop at KABC_MAX_DIM.  The reference has
+/* AIS and smc accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM run-time-dimension
+ * kernels keep the walker / particle rows in memory (several times slower per evaluation, same
+ * results).  User cost plugins follow.  ABCDE / pfilter stop at KABC_MAX_DIM.  The reference has
  * no bound (src/priors.jl:10-13). */
 #define KABC_MAX_DIM_DYN 256
 

@@ -61,6 +61,7 @@ extern "C" kabc_status_t kabc_register_cost_plugin(const char* path, int32_t* ou
     p.pf_attempt = (void* (*)(int32_t))dlsym(dl, "kabc_plugin_pf_attempt");
     p.smc_loop = (void* (*)(int32_t, int32_t))dlsym(dl, "kabc_plugin_smc_loop");
     p.ais_dyn = (void* (*)(void))dlsym(dl, "kabc_plugin_ais_dyn");
+    p.smc_dyn = (void* (*)(void))dlsym(dl, "kabc_plugin_smc_dyn");
     if (!abi || !p.dim_ok || !p.ais || !p.smc || !p.ais_init || !p.smc_init) {
         dlclose(dl);
         set_error("%s is not a kabc cost plugin (missing entry points)", path);

@@ -9,6 +9,7 @@
 #include "host_common.hpp"
 #include "plugin_registry.hpp"
 #include "smc_loop_kernel.hpp"
+#include "smc_dyn_kernels.hpp"
 #include "abcde_kernels.hpp"
 #include "pfilter_kernels.hpp"
 
@@ -218,12 +219,24 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     KABC_REQ(o->mcmc_tol >= 0, "mcmc_tol must be >= 0")
     KABC_REQ(o->max_stretch > 1, "max_stretch must be > 1")
 #undef KABC_REQ
-    if (D < 1 || D > KABC_MAX_DIM) {
-        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM);
+    if (D < 1 || D > KABC_MAX_DIM_DYN) {
+        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM_DYN);
         return KABC_ERR_UNSUPPORTED;
     }
+    // beyond KABC_MAX_DIM: run-time-dimension kernels (smc_dyn_kernels.hpp) on the
+    // kernel-per-phase path; the selection / control kernels do not depend on D
+    const bool dyn = D > KABC_MAX_DIM;
     PriorSet P;
-    if (!prepare_priors(prior, D, P)) {
+    std::memset(&P, 0, sizeof P);
+    std::vector<PriorDev> Pdyn;
+    bool prior_ok = true;
+    if (dyn) {
+        Pdyn.resize((size_t)D);
+        for (int k = 0; k < D && prior_ok; ++k) prior_ok = prepare_prior(prior[k], Pdyn[k]);
+    } else {
+        prior_ok = prepare_priors(prior, D, P);
+    }
+    if (!prior_ok) {
         set_error("invalid prior parameters");
         return KABC_ERR_INVALID_ARG;
     }
@@ -233,8 +246,17 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     }
     bool simple = true;
     for (int k = 0; k < D; ++k) simple = simple && prior_is_simple(prior[k].kind);
-    SmcLaunchFn mcmc = find_smc_kernel(cost->id, D, simple);
-    if (!mcmc) {
+    SmcLaunchFn mcmc = dyn ? nullptr : find_smc_kernel(cost->id, D, simple);
+    SmcDynLaunchFn dyn_fn = nullptr;
+    if (dyn) {
+        if (cost->id >= KABC_COST_USER) {
+            const CostPlugin* pl = find_plugin(cost->id);
+            dyn_fn = (pl && pl->smc_dyn) ? (SmcDynLaunchFn)pl->smc_dyn() : nullptr;
+        } else {
+            dyn_fn = &launch_smc_dyn<0>;
+        }
+    }
+    if (!mcmc && !dyn_fn) {
         set_error("no gfx950 kernel instantiated for cost id %d, D = %d", cost->id, D);
         return KABC_ERR_UNSUPPORTED;
     }
@@ -306,8 +328,41 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     double mcmc_ms = 0.0;
     int64_t mcmc_timed = 0;
 
+    SmcDynArgs da;
+    std::memset(&da, 0, sizeof da);
+    if (dyn) {
+        PriorDev* d_prior;
+        kabc_prior_t* d_raw;
+        KABC_HIP_CHECK(bufs.alloc(&d_prior, (size_t)D));
+        KABC_HIP_CHECK(bufs.alloc(&d_raw, (size_t)D));
+        KABC_HIP_CHECK(bufs.alloc(&da.scratch, (size_t)N * 2 * D));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_prior, Pdyn.data(), sizeof(PriorDev) * D, hipMemcpyHostToDevice, s));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_raw, prior, sizeof(kabc_prior_t) * D, hipMemcpyHostToDevice, s));
+        for (int b = 0; b < 2; ++b) {
+            da.theta[b] = th[b];
+            da.X[b] = X[b];
+            da.lpi[b] = lp[b];
+        }
+        da.alive = alive;
+        da.cidx = cidx;
+        da.ctrl = ctrl;
+        da.slots = slots;
+        da.cost_params = d_params;
+        da.cost_data = d_data;
+        da.cost_ndata = cost->ndata;
+        da.N = N;
+        da.seed = o->seed;
+        da.max_stretch = o->max_stretch;
+        da.D = D;
+        da.cost_id = cost->id;
+        da.prior = d_prior;
+        da.raw = d_raw;
+        da.part = part;
+        dyn_fn(da, s, 1);
+        KABC_HIP_CHECK(hipGetLastError());
+    }
     // :119-125
-    {
+    if (!dyn) {
         SmcInitArgs a;
         std::memset(&a, 0, sizeof a);
         a.theta = th[0];
@@ -391,7 +446,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         const bool allow = !(env && env[0] == '0');
         const unsigned G = (unsigned)((N + kLoopBlock - 1) / kLoopBlock);
         SmcLoopLaunchFn loop_fn =
-            (allow && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple) : nullptr;
+            (allow && !dyn && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple) : nullptr;
         if (loop_fn) {
             SmcLoopScratch* lsc;
             KABC_HIP_CHECK(bufs.alloc(&lsc, 1));
@@ -475,7 +530,8 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
                 for (int r = r0; r < r1; ++r) {
                     const bool timed = (it == 0 && r == 0);
                     if (timed) KABC_HIP_CHECK(hipEventRecord(ev0, s));
-                    mcmc(ma, s);
+                    if (dyn) dyn_fn(da, s, 0);
+                    else mcmc(ma, s);
                     if (timed) KABC_HIP_CHECK(hipEventRecord(ev1, s));
                     ended = (r == R - 1);
                     hipLaunchKernelGGL(smc_pass_end_kernel, dim3(1), dim3(kSmcSlots), 0, s, ctrl,
@@ -532,6 +588,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         fa.N = N;
         fa.D = D;
         fa.prior = P;
+        fa.dprior = dyn ? da.prior : nullptr;
         hipLaunchKernelGGL(smc_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
                            fa);
         KABC_HIP_CHECK(hipGetLastError());
@@ -811,6 +868,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     fa.N = N;
     fa.D = D;
     fa.prior = P;
+    fa.dprior = nullptr;
     hipLaunchKernelGGL(smc_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, fa);
     KABC_HIP_CHECK(hipGetLastError());
     if (res->theta)

@@ -17,6 +17,7 @@ struct CostPlugin {
     void* (*pf_attempt)(int32_t D);                 // -> PfLaunchFn (may be NULL)
     void* (*smc_loop)(int32_t D, int32_t simple_prior);  // -> SmcLoopLaunchFn (may be NULL)
     void* (*ais_dyn)(void);                          // -> AisDynLaunchFn (may be NULL)
+    void* (*smc_dyn)(void);                          // -> SmcDynLaunchFn (may be NULL)
 };
 
 const CostPlugin* find_plugin(int cost_id);

@@ -132,6 +132,7 @@ struct SmcFinalArgs {
     int64_t N;
     int32_t D;
     PriorSet prior;
+    const PriorDev* dprior;  // [D] on the device when D > KABC_MAX_DIM (else NULL: `prior`)
 };
 
 constexpr int kSmcBlock = 64;
@@ -858,7 +859,8 @@ __global__ void __launch_bounds__(256) smc_finalize_kernel(const SmcFinalArgs A)
     const int cur = A.ctrl->cur;
     for (int k = 0; k < A.D; ++k) {
         const double v = A.theta[cur][i * A.D + k];
-        A.out[i * A.D + k] = A.prior.c[k].discrete ? kabc_rint(v) : v;
+        const bool disc = A.dprior ? (A.dprior[k].discrete != 0) : (A.prior.c[k].discrete != 0);
+        A.out[i * A.D + k] = disc ? kabc_rint(v) : v;
     }
     A.Xout[i] = A.X[cur][i];
 }

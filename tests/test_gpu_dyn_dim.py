@@ -59,7 +59,7 @@ def test_dynamic_dimension_limits_and_sharding(k, orc, gpu_ctx):
         k.Factored(*[k.Normal(0, 1)] * 257)
     big = k.Factored(*[k.Normal(0, 1)] * 20)
     with pytest.raises(k.KabcError, match="outside the device path's range"):
-        k.smc(big, k.costs.GaussDist(np.zeros(20)), nparticles=500)
+        k.pfilter(big, k.costs.GaussDist(np.zeros(20)), 500)     # pfilter / ABCDE stop at 16
     # walker-sharded (3 emulated ranks, P2P exchange) at D = 20
     model = k.ApproxKernelizedPosterior(big, k.costs.GaussDist(np.ones(20)), 0.5)
     grp = k.EnsembleGroup(model, 301, seed=9, devices=[0, 0, 0], backend="p2p").init()
@@ -98,3 +98,26 @@ KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
     assert np.array_equal(pri.logpdf(x), orc.factored_logpdf(pri, x))
     assert np.array_equal(pri.push_p(x), orc.push_p(pri, x))
     assert np.array_equal(pri.rand(32, seed=3), orc.push_p(pri, orc.factored_rand(pri, 32, seed=3)))
+
+
+@pytest.mark.parametrize("name", ["gauss_d20", "hier_d40_mixed", "shell_d17_retrys"])
+def test_smc_dynamic_dimension_bit_exact(k, orc, gpu_ctx, name):
+    """smc() beyond 16 parameters: run-time-dimension init / propose+accept kernels on the
+    kernel-per-phase path (csrc/smc_dyn_kernels.hpp), bit-exact vs the oracle."""
+    rng = np.random.default_rng(8)
+    cases = {
+        "gauss_d20": (k.Factored(*[k.Normal(0, 2)] * 20), k.costs.GaussDist(rng.normal(size=20)),
+                      dict(nparticles=3000, alpha=0.9, epstol=3.0)),
+        "hier_d40_mixed": (k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 36,
+                                      k.Gamma(2.0, 1.0), k.DiscreteUniform(-3, 3)),
+                           k.costs.HierGaussSim(rng.normal(size=38)), dict(nparticles=2000, epstol=1.2)),
+        "shell_d17_retrys": (k.MvNormal(17, 1.0), k.costs.NormShell(2.0),
+                             dict(nparticles=1500, alpha=0.8, epstol=0.3, mcmc_retrys=3, mcmc_tol=0.2)),
+    }
+    pri, cost, kw = cases[name]
+    got = k.smc(pri, cost, seed=4, return_array=True, **kw)
+    ref = orc.smc(pri, cost, seed=4, **kw)
+    assert got.info["log"] == ref["log"] and got.eps == ref["eps"]
+    assert np.array_equal(got.info["theta_all"], ref["theta_all"])
+    assert np.array_equal(got.info["alive"], ref["alive"]) and np.array_equal(got.C, ref["C"])
+    assert got.info["cost_evals"] == ref["cost_evals"] and got.info["proposals"] == ref["proposals"]
