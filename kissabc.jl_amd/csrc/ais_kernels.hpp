@@ -150,6 +150,12 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
                                         int64_t ndata, kabc_cost_rng_t* rng, double& lp,
                                         double& ll, bool& ev) {
     double yp[D];
+    // A cheap deterministic cost is evaluated for every lane and selected afterwards: the
+    // divergent region around it (exec save / branch / restore) costs the consumer wave more
+    // issue slots than the arithmetic it would skip, and in practice some lane always needs it.
+    constexpr bool kCheap = COST == KABC_COST_GAUSS_DIST || COST == KABC_COST_ROSENBROCK ||
+                            COST == KABC_COST_DIRAC_SQ || COST == KABC_COST_ABS_DIFF ||
+                            COST == KABC_COST_NORM_SHELL;
     if (posterior == KABC_POSTERIOR_COMMON) {
         // loglike(density::CommonLogDensity, sample) = lπ(sample.x)  src/types.jl:117-119;
         // push_p is the identity for a plain AbstractDensity (:27)
@@ -168,10 +174,23 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         bool in = true;
         if (B.dmask == 0u) {  // wave-uniform: all components continuous, push_p = identity
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                yp[k] = y[k];
-                in = in && (y[k] >= lo[k]) && (y[k] <= hi[k]);
+            for (int k = 0; k < D; ++k) in = in && (y[k] >= lo[k]) && (y[k] <= hi[k]);
+            if constexpr (kCheap) {
+                // finish here, on y itself: merging this path with the rounding one through yp
+                // costs D register-pair copies per transition
+                lp = in ? B.lp : -KABC_INF;
+                ev = in;
+                const double c = eval_cost<COST, D>(y, cost_params, cost_data, ndata, rng);
+                if (posterior == KABC_POSTERIOR_KERNELIZED) {
+                    const double q = kabc_div_rc(c, eps, reps);
+                    ll = in ? -0.5 * (q * q) : lp;
+                } else {
+                    ll = in ? c : -lp;
+                }
+                return;
             }
+#pragma unroll
+            for (int k = 0; k < D; ++k) yp[k] = y[k];
         } else {
 #pragma unroll
             for (int k = 0; k < D; ++k) {
@@ -185,12 +204,6 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         lp = factored_logpdf_push<D, PC == kPriorSimple>(P, y, yp);
     }
     ev = kabc_isfinite(lp);
-    // A cheap deterministic cost is evaluated for every lane and selected afterwards: the
-    // divergent region around it (exec save / branch / restore) costs the consumer wave more
-    // issue slots than the arithmetic it would skip, and in practice some lane always needs it.
-    constexpr bool kCheap = COST == KABC_COST_GAUSS_DIST || COST == KABC_COST_ROSENBROCK ||
-                            COST == KABC_COST_DIRAC_SQ || COST == KABC_COST_ABS_DIFF ||
-                            COST == KABC_COST_NORM_SHELL;
     if (posterior == KABC_POSTERIOR_KERNELIZED) {
         if constexpr (kCheap) {
             const double c = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
