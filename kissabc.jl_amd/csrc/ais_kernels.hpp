@@ -142,6 +142,64 @@ struct BoxPrior {
     double lp;          // in-support log-density
 };
 
+// y inside the box [lo, hi]^D as ONE v_cmpx chain (D = 2..8, the sizes whose bounds live in
+// registers): every comparison narrows EXEC itself, so the 2D s_and_b64 that combine ordinary
+// v_cmp results disappear -- SALU instructions cost a wave an issue slot each, and these sat on
+// a dependent VALU -> SALU -> VALU chain (C3: 155.4 -> 149.6 us per launch at ntransitions =
+// 100).  Lanes still enabled at the end are inside the box; EXEC is restored before the
+// statement ends.  NaN compares false, as `y >= lo && y <= hi` does.
+#define KABC_BOXP(k) \
+    "v_cmpx_ge_f64_e32 vcc, %[y" #k "], %[l" #k "]\n\tv_cmpx_le_f64_e32 vcc, %[y" #k "], %[h" #k "]\n\t"
+#define KABC_BOXO(k) [y##k] "v"(y[k]), [l##k] "v"(lo[k]), [h##k] "v"(hi[k])
+#define KABC_BOX_ASM(BODY, ...)                                                                   \
+    unsigned flag = 0;                                                                            \
+    unsigned long long saved;                                                                     \
+    asm volatile("s_mov_b64 %[sv], exec\n\t" BODY "v_mov_b32 %[fl], 1\n\ts_mov_b64 exec, %[sv]"  \
+                 : [fl] "+v"(flag), [sv] "=&s"(saved)                                             \
+                 : __VA_ARGS__                                                                    \
+                 : "vcc");                                                                        \
+    return flag != 0u;
+template <int D>
+__device__ __forceinline__ bool box_contains(const double* y, const double* lo, const double* hi);
+template <>
+__device__ __forceinline__ bool box_contains<2>(const double* y, const double* lo, const double* hi) {
+    KABC_BOX_ASM(KABC_BOXP(0) KABC_BOXP(1), KABC_BOXO(0), KABC_BOXO(1))
+}
+template <>
+__device__ __forceinline__ bool box_contains<3>(const double* y, const double* lo, const double* hi) {
+    KABC_BOX_ASM(KABC_BOXP(0) KABC_BOXP(1) KABC_BOXP(2), KABC_BOXO(0), KABC_BOXO(1), KABC_BOXO(2))
+}
+template <>
+__device__ __forceinline__ bool box_contains<4>(const double* y, const double* lo, const double* hi) {
+    KABC_BOX_ASM(KABC_BOXP(0) KABC_BOXP(1) KABC_BOXP(2) KABC_BOXP(3), KABC_BOXO(0), KABC_BOXO(1), KABC_BOXO(2),
+                 KABC_BOXO(3))
+}
+template <>
+__device__ __forceinline__ bool box_contains<5>(const double* y, const double* lo, const double* hi) {
+    KABC_BOX_ASM(KABC_BOXP(0) KABC_BOXP(1) KABC_BOXP(2) KABC_BOXP(3) KABC_BOXP(4), KABC_BOXO(0), KABC_BOXO(1),
+                 KABC_BOXO(2), KABC_BOXO(3), KABC_BOXO(4))
+}
+template <>
+__device__ __forceinline__ bool box_contains<6>(const double* y, const double* lo, const double* hi) {
+    KABC_BOX_ASM(KABC_BOXP(0) KABC_BOXP(1) KABC_BOXP(2) KABC_BOXP(3) KABC_BOXP(4) KABC_BOXP(5), KABC_BOXO(0),
+                 KABC_BOXO(1), KABC_BOXO(2), KABC_BOXO(3), KABC_BOXO(4), KABC_BOXO(5))
+}
+template <>
+__device__ __forceinline__ bool box_contains<7>(const double* y, const double* lo, const double* hi) {
+    KABC_BOX_ASM(KABC_BOXP(0) KABC_BOXP(1) KABC_BOXP(2) KABC_BOXP(3) KABC_BOXP(4) KABC_BOXP(5) KABC_BOXP(6),
+                 KABC_BOXO(0), KABC_BOXO(1), KABC_BOXO(2), KABC_BOXO(3), KABC_BOXO(4), KABC_BOXO(5), KABC_BOXO(6))
+}
+template <>
+__device__ __forceinline__ bool box_contains<8>(const double* y, const double* lo, const double* hi) {
+    KABC_BOX_ASM(KABC_BOXP(0) KABC_BOXP(1) KABC_BOXP(2) KABC_BOXP(3) KABC_BOXP(4) KABC_BOXP(5) KABC_BOXP(6)
+                     KABC_BOXP(7),
+                 KABC_BOXO(0), KABC_BOXO(1), KABC_BOXO(2), KABC_BOXO(3), KABC_BOXO(4), KABC_BOXO(5), KABC_BOXO(6),
+                 KABC_BOXO(7))
+}
+#undef KABC_BOX_ASM
+#undef KABC_BOXO
+#undef KABC_BOXP
+
 // loglike(density, push_p(density, y)) -- src/types.jl:51-58, :84-91
 template <int D, int COST, int PC>
 __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const BoxPrior& B,
@@ -173,8 +231,11 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         }
         bool in = true;
         if (B.dmask == 0u) {  // wave-uniform: all components continuous, push_p = identity
+            if constexpr (D >= 2 && D <= 8) in = box_contains<D>(y, lo, hi);
+            else {
 #pragma unroll
-            for (int k = 0; k < D; ++k) in = in && (y[k] >= lo[k]) && (y[k] <= hi[k]);
+                for (int k = 0; k < D; ++k) in = in && (y[k] >= lo[k]) && (y[k] <= hi[k]);
+            }
             if constexpr (kCheap) {
                 // finish here, on y itself: merging this path with the rounding one through yp
                 // costs D register-pair copies per transition
@@ -538,6 +599,13 @@ ais_half_kernel(const AisArgs A0) {
                 const uint32_t move = mva >> 30;
                 double y[D];
                 double corr = 0.0;
+                // ais_walk_propose  src/transition.jl:24-43 -- W does not depend on x_i: the
+                // producer has already formed it.  Evaluated for every lane (8 adds; a lane
+                // with another move overwrites y below): two independent masked regions
+                // instead of a three-way nest, i.e. fewer EXEC manipulations on the wave's
+                // single issue stream.
+#pragma unroll
+                for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];
                 if (move == 1u) {
                     // stretch_propose  src/transition.jl:51-59
                     const double Z = zs[0];
@@ -547,7 +615,8 @@ ais_half_kernel(const AisArgs A0) {
                         const double W = (x[k] - pa[k]) * Z;
                         y[k] = pa[k] + W;
                     }
-                } else if (move == 2u) {
+                }
+                if (move == 2u) {
                     // de_propose  src/transition.jl:2-22
                     const double gamma = zs[0];
 #pragma unroll
@@ -558,11 +627,6 @@ ais_half_kernel(const AisArgs A0) {
                         const double Tk = kabc_div_rc(gamma * sk, 300.0, 1.0 / 300.0) * zs[1 + k];
                         y[k] = x[k] + Wk + Tk;
                     }
-                } else {
-                    // ais_walk_propose  src/transition.jl:24-43
-                    // W does not depend on x_i: the producer has already formed it
-#pragma unroll
-                    for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (kLate) {  // pa/pb are dead now: na/nb alias them
