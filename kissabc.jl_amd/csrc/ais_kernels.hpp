@@ -456,7 +456,8 @@ ais_half_kernel(const AisArgs A0) {
     constexpr int kAuxW = cost_aux_c(COST);
     __shared__ double saux[2][kChunk][kAuxW > 0 ? kAuxW : 1][kBatch];
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
+    // (wave index as a scalar: role branches and record addresses are wave-uniform)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
     const int64_t r0 = (int64_t)blockIdx.x * kBatch;
     const int64_t rem = A.rows_owned - r0;
     const int n_active = rem >= kBatch ? kBatch : (int)rem;
@@ -546,10 +547,15 @@ ais_half_kernel(const AisArgs A0) {
     }
     KABC_TIMED_BARRIER();
 
+    // The two roles run SEPARATE chunk loops (same trip count, one barrier per trip): values a
+    // role keeps across its loop -- Philox keys and polynomial constants for the producers, the
+    // walker's state and the box for the consumer -- then never occupy the other role's
+    // registers (one shared loop made both sets live through both bodies: scalar-register
+    // spills and re-materialised constants in every sub-step).
+    if (wave > 0) {
 #pragma unroll 1
-    for (int c = 0; c < nchunks; ++c) {
-        const int s0 = c * kChunk;
-        if (wave > 0) {
+        for (int c = 0; c < nchunks; ++c) {
+            const int s0 = c * kChunk;
             // PRODUCER: sub-step (s0 + kChunk + wave - 1) of the next chunk
             const int si = wave - 1;
             const int s = s0 + kChunk + si;
@@ -560,146 +566,153 @@ ais_half_kernel(const AisArgs A0) {
                     prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)s, w_base, lane,
                                                   saux[(c + 1) & 1][si], slogtab);
             }
-        } else if (active && !(KABL & 1)) {
-            // CONSUMER
-            const ChunkRec<D>& R = rec[(KABL & 2) ? 0 : (c & 1)];
-            const int ns = (A.nt - s0 < kChunk) ? (A.nt - s0) : kChunk;
-            // partner rows: (pa, pb) serve this sub-step, (na, nb) are the next one's, in
-            // flight while this one computes.  Both rows are fetched for every lane
-            // whatever its move (bb defaults to a): no divergence around the loads.
-            // The sub-step body is instantiated twice with the two register sets
-            // swapped, so no row is ever copied.
-            constexpr bool kLate = D > kLateFrom;
-            double r0a[D], r0b[D], r1a[kLate ? 1 : D], r1b[kLate ? 1 : D];
-            load_row<D>(A.x_comp + (int64_t)(R.mva[0][lane] & 0x3fffffffu) * D, r0a);
-            load_row<D>(A.x_comp + (int64_t)R.bb[0][lane] * D, r0b);
-            auto substep = [&](const int si, const double (&pa)[D], const double (&pb)[D],
-                               double (&na)[D], double (&nb)[D]) __attribute__((always_inline)) {
-                const uint64_t t = A.t0 + (uint64_t)(s0 + si);
-                // (1) every LDS word of this sub-step in one batch, plus the partner
-                //     ids of the next one
-                const int sn = (si + 1 < ns) ? si + 1 : si;
-                const uint32_t mva = R.mva[si][lane];
-                const uint32_t mvan = R.mva[sn][lane], bn = R.bb[sn][lane];
-                const double logu = R.logu[si][lane];
-                double zs[D + 1];
-#pragma unroll
-                for (int j = 0; j < D + 1; ++j) zs[j] = R.zs[si][j][lane];
-                // (2) prefetch.  D <= kLateFrom: into the second register set, right away.
-                //     Larger D (two more rows would not fit 256 VGPRs: D = 16 spilled 480 B
-                //     and ran 4.3x slower than D = 8): into the SAME registers, as soon as
-                //     the proposal below has consumed the current rows.
-                if constexpr (!kLate) {
-                    load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
-                    load_row<D>(A.x_comp + (int64_t)bn * D, nb);
-                }
-                // scheduling fences: without them hipcc interleaves the phases of a
-                // sub-step for ILP and needs > 300 VGPRs (spills, 1 wave per SIMD)
-                __builtin_amdgcn_sched_barrier(0);
-                const uint32_t move = mva >> 30;
-                double y[D];
-                double corr = 0.0;
-                // ais_walk_propose  src/transition.jl:24-43 -- W does not depend on x_i: the
-                // producer has already formed it.  Evaluated for every lane (8 adds; a lane
-                // with another move overwrites y below): two independent masked regions
-                // instead of a three-way nest, i.e. fewer EXEC manipulations on the wave's
-                // single issue stream.
-#pragma unroll
-                for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];
-                if (move == 1u) {
-                    // stretch_propose  src/transition.jl:51-59
-                    const double Z = zs[0];
-                    corr = zs[1];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double W = (x[k] - pa[k]) * Z;
-                        y[k] = pa[k] + W;
+            KABC_TIMED_BARRIER();
+        }
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < nchunks; ++c) {
+            const int s0 = c * kChunk;
+            if (active && !(KABL & 1)) {
+                // CONSUMER
+                const ChunkRec<D>& R = rec[(KABL & 2) ? 0 : (c & 1)];
+                const int ns = (A.nt - s0 < kChunk) ? (A.nt - s0) : kChunk;
+                // partner rows: (pa, pb) serve this sub-step, (na, nb) are the next one's, in
+                // flight while this one computes.  Both rows are fetched for every lane
+                // whatever its move (bb defaults to a): no divergence around the loads.
+                // The sub-step body is instantiated twice with the two register sets
+                // swapped, so no row is ever copied.
+                constexpr bool kLate = D > kLateFrom;
+                double r0a[D], r0b[D], r1a[kLate ? 1 : D], r1b[kLate ? 1 : D];
+                load_row<D>(A.x_comp + (int64_t)(R.mva[0][lane] & 0x3fffffffu) * D, r0a);
+                load_row<D>(A.x_comp + (int64_t)R.bb[0][lane] * D, r0b);
+                auto substep = [&](const int si, const double (&pa)[D], const double (&pb)[D],
+                                   double (&na)[D], double (&nb)[D]) __attribute__((always_inline)) {
+                    const uint64_t t = A.t0 + (uint64_t)(s0 + si);
+                    // (1) every LDS word of this sub-step in one batch, plus the partner
+                    //     ids of the next one
+                    const int sn = (si + 1 < ns) ? si + 1 : si;
+                    const uint32_t mva = R.mva[si][lane];
+                    const uint32_t mvan = R.mva[sn][lane], bn = R.bb[sn][lane];
+                    const double logu = R.logu[si][lane];
+                    double zs[D + 1];
+    #pragma unroll
+                    for (int j = 0; j < D + 1; ++j) zs[j] = R.zs[si][j][lane];
+                    // (2) prefetch.  D <= kLateFrom: into the second register set, right away.
+                    //     Larger D (two more rows would not fit 256 VGPRs: D = 16 spilled 480 B
+                    //     and ran 4.3x slower than D = 8): into the SAME registers, as soon as
+                    //     the proposal below has consumed the current rows.
+                    if constexpr (!kLate) {
+                        load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
+                        load_row<D>(A.x_comp + (int64_t)bn * D, nb);
                     }
-                }
-                if (move == 2u) {
-                    // de_propose  src/transition.jl:2-22
-                    const double gamma = zs[0];
-#pragma unroll
-                    for (int k = 0; k < D; ++k) {
-                        const double Wk = (pa[k] - pb[k]) * gamma;
-                        const double sk = kabc_fabs(pa[k] - pb[k]) + kabc_fabs(x[k] - pb[k]) +
-                                          kabc_fabs(pa[k] - x[k]);
-                        const double Tk = kabc_div_rc(gamma * sk, 300.0, 1.0 / 300.0) * zs[1 + k];
-                        y[k] = x[k] + Wk + Tk;
+                    // scheduling fences: without them hipcc interleaves the phases of a
+                    // sub-step for ILP and needs > 300 VGPRs (spills, 1 wave per SIMD)
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint32_t move = mva >> 30;
+                    double y[D];
+                    double corr = 0.0;
+                    // ais_walk_propose  src/transition.jl:24-43 -- W does not depend on x_i: the
+                    // producer has already formed it.  Evaluated for every lane (8 adds; a lane
+                    // with another move overwrites y below): two independent masked regions
+                    // instead of a three-way nest, i.e. fewer EXEC manipulations on the wave's
+                    // single issue stream.
+    #pragma unroll
+                    for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];
+                    if (move == 1u) {
+                        // stretch_propose  src/transition.jl:51-59
+                        const double Z = zs[0];
+                        corr = zs[1];
+    #pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const double W = (x[k] - pa[k]) * Z;
+                            y[k] = pa[k] + W;
+                        }
                     }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (kLate) {  // pa/pb are dead now: na/nb alias them
-                    load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
-                    load_row<D>(A.x_comp + (int64_t)bn * D, nb);
-                }
-                // ld = loglike(density, push_p(density, p))   src/transition.jl:75
-                kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u,
-                                       0u, nullptr, slogtab};
-                if constexpr (kAuxW > 0) {
-                    rng.aux = &saux[(KABL & 2) ? 0 : (c & 1)][si][0][lane];
-                    rng.aux_stride = kBatch;
-                }
-                double nlp, nll;
-                bool ev;
-                loglike<D, COST, PC>(sprior, box, PK, A.eps, A.reps, y, A.cost_params,
-                                     A.cost_data, A.cost_ndata, &rng, nlp, nll, ev);
-                __builtin_amdgcn_sched_barrier(0);
-                n_eval += ev ? 1u : 0u;
-                // accept(...)  src/types.jl:62-75, :96-104
-                // (the old state's validity is checked once, before the first sub-step: it
-                // can only change through an accept, which requires a valid new state)
-                // straight-line: every comparison is evaluated, the flags are combined (a NaN /
-                // Inf log-density makes `valid` false whatever the comparisons say)
-                const bool okc = kabc_isfinite(corr);
-                err = (!okc && err == 0) ? 1 : err;
-                const bool valid = okc && ld_valid(PK, nlp, nll);
-                const double e = -logu;  // randexp(rng)
-                bool acc;
-                if (PK == KABC_POSTERIOR_KERNELIZED) {
-                    const double lW = corr + (nlp + nll) - (lp + ll);
-                    acc = valid && (-e <= lW);
-                } else if (PK == KABC_POSTERIOR_COMMON) {
-                    const double lW = corr + nll - ll;  // src/types.jl:127
-                    acc = valid && (-e <= lW);
+                    if (move == 2u) {
+                        // de_propose  src/transition.jl:2-22
+                        const double gamma = zs[0];
+    #pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const double Wk = (pa[k] - pb[k]) * gamma;
+                            const double sk = kabc_fabs(pa[k] - pb[k]) + kabc_fabs(x[k] - pb[k]) +
+                                              kabc_fabs(pa[k] - x[k]);
+                            const double Tk = kabc_div_rc(gamma * sk, 300.0, 1.0 / 300.0) * zs[1 + k];
+                            y[k] = x[k] + Wk + Tk;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (kLate) {  // pa/pb are dead now: na/nb alias them
+                        load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
+                        load_row<D>(A.x_comp + (int64_t)bn * D, nb);
+                    }
+                    // ld = loglike(density, push_p(density, p))   src/transition.jl:75
+                    kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u,
+                                           0u, nullptr, slogtab};
+                    if constexpr (kAuxW > 0) {
+                        rng.aux = &saux[(KABL & 2) ? 0 : (c & 1)][si][0][lane];
+                        rng.aux_stride = kBatch;
+                    }
+                    double nlp, nll;
+                    bool ev;
+                    loglike<D, COST, PC>(sprior, box, PK, A.eps, A.reps, y, A.cost_params,
+                                         A.cost_data, A.cost_ndata, &rng, nlp, nll, ev);
+                    __builtin_amdgcn_sched_barrier(0);
+                    n_eval += ev ? 1u : 0u;
+                    // accept(...)  src/types.jl:62-75, :96-104
+                    // (the old state's validity is checked once, before the first sub-step: it
+                    // can only change through an accept, which requires a valid new state)
+                    // straight-line: every comparison is evaluated, the flags are combined (a NaN /
+                    // Inf log-density makes `valid` false whatever the comparisons say)
+                    const bool okc = kabc_isfinite(corr);
+                    err = (!okc && err == 0) ? 1 : err;
+                    const bool valid = okc && ld_valid(PK, nlp, nll);
+                    const double e = -logu;  // randexp(rng)
+                    bool acc;
+                    if (PK == KABC_POSTERIOR_KERNELIZED) {
+                        const double lW = corr + (nlp + nll) - (lp + ll);
+                        acc = valid && (-e <= lW);
+                    } else if (PK == KABC_POSTERIOR_COMMON) {
+                        const double lW = corr + nll - ll;  // src/types.jl:127
+                        acc = valid && (-e <= lW);
+                    } else {
+                        const double lW = corr + nlp - lp;
+                        const double mx = (A.eps > ll) ? A.eps : ll;
+                        const double lW2 = mx - nll;
+                        acc = valid && (-e <= lW) && (lW2 >= 0.0);
+                    }
+                    if (acc) {
+    #pragma unroll
+                        for (int k = 0; k < D; ++k) x[k] = y[k];
+                        lp = nlp;
+                        ll = nll;
+                        n_acc += 1u;
+                    }
+                    if (A.dbg) {
+                        int32_t* d = A.dbg + (r * A.nt + (s0 + si)) * 6;
+                        d[0] = (int32_t)move;
+                        d[1] = acc ? 1 : 0;
+                        d[2] = (int32_t)(mva & 0x3fffffffu);
+                        d[3] = move >= 2u ? (int32_t)R.bb[si][lane] : -1;
+                        d[4] = move == 3u ? (int32_t)R.cc[si][lane] : -1;
+                        d[5] = ev ? 1 : 0;
+                    }
+                };
+                // an error (src/types.jl:69-70) is sticky and reported after the launch; the
+                // remaining sub-steps still run (their result is discarded by the host), which
+                // keeps the loop bounds wave-uniform
+                if constexpr (kLate) {
+    #pragma unroll 1
+                    for (int si = 0; si < ns; ++si) substep(si, r0a, r0b, r0a, r0b);
                 } else {
-                    const double lW = corr + nlp - lp;
-                    const double mx = (A.eps > ll) ? A.eps : ll;
-                    const double lW2 = mx - nll;
-                    acc = valid && (-e <= lW) && (lW2 >= 0.0);
-                }
-                if (acc) {
-#pragma unroll
-                    for (int k = 0; k < D; ++k) x[k] = y[k];
-                    lp = nlp;
-                    ll = nll;
-                    n_acc += 1u;
-                }
-                if (A.dbg) {
-                    int32_t* d = A.dbg + (r * A.nt + (s0 + si)) * 6;
-                    d[0] = (int32_t)move;
-                    d[1] = acc ? 1 : 0;
-                    d[2] = (int32_t)(mva & 0x3fffffffu);
-                    d[3] = move >= 2u ? (int32_t)R.bb[si][lane] : -1;
-                    d[4] = move == 3u ? (int32_t)R.cc[si][lane] : -1;
-                    d[5] = ev ? 1 : 0;
-                }
-            };
-            // an error (src/types.jl:69-70) is sticky and reported after the launch; the
-            // remaining sub-steps still run (their result is discarded by the host), which
-            // keeps the loop bounds wave-uniform
-            if constexpr (kLate) {
-#pragma unroll 1
-                for (int si = 0; si < ns; ++si) substep(si, r0a, r0b, r0a, r0b);
-            } else {
-#pragma unroll 1
-                for (int si = 0; si < ns; si += 2) {
-                    substep(si, r0a, r0b, r1a, r1b);
-                    if (si + 1 < ns) substep(si + 1, r1a, r1b, r0a, r0b);
+    #pragma unroll 1
+                    for (int si = 0; si < ns; si += 2) {
+                        substep(si, r0a, r0b, r1a, r1b);
+                        if (si + 1 < ns) substep(si + 1, r1a, r1b, r0a, r0b);
+                    }
                 }
             }
+            KABC_TIMED_BARRIER();
         }
-        KABC_TIMED_BARRIER();
     }
 
     if (tprobe && lane == 0) {
