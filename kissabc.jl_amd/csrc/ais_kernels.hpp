@@ -370,14 +370,28 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         R.cc[si][l] = (uint32_t)c;
     }
     wave_lds_fence();
-    // walk lanes start fetching their three partner rows now; the loads fly
-    // under the Box-Muller phase
-    double wa[D], wb[D], wc[D];
-    if (move == 3) {
-        load_row<D>(A.x_comp + (int64_t)a * D, wa);
-        load_row<D>(A.x_comp + (int64_t)R.bb[si][lane] * D, wb);
-        load_row<D>(A.x_comp + (int64_t)R.cc[si][lane] * D, wc);
-    }
+    // -- walk work, dense: the state-independent displacement W of a walk lane is D independent
+    // coordinates, so it is spread over the wave as (walk lane, coordinate) items -- 64 / D walk
+    // lanes per pass -- instead of D coordinates in each of the ~9 walk lanes of 64 (one lane in
+    // seven busy).  The three partner values of the first two passes (all there is in 99 % of
+    // the sub-steps at D = 8) are fetched now and fly under the Box-Muller phase.
+    constexpr int kWPP = kWave / D;  // walk lanes per pass
+    const int nWK = nB - nDE;
+    const int wq = lane / D, wk = lane - wq * D;
+    auto walk_fetch = [&](int pass, int& l, double& va, double& vb, double& vc) {
+        const int q = pass * kWPP + wq;
+        l = -1;
+        if (wq < kWPP && q < nWK) {
+            l = listB[nDE + q];
+            va = A.x_comp[(int64_t)(R.mva[si][l] & 0x3fffffffu) * D + wk];
+            vb = A.x_comp[(int64_t)R.bb[si][l] * D + wk];
+            vc = A.x_comp[(int64_t)R.cc[si][l] * D + wk];
+        }
+    };
+    int wl0, wl1;
+    double wa0 = 0.0, wb0 = 0.0, wc0 = 0.0, wa1 = 0.0, wb1 = 0.0, wc1 = 0.0;
+    walk_fetch(0, wl0, wa0, wb0, wc0);
+    walk_fetch(1, wl1, wa1, wb1, wc1);
     // -- phase N: Box-Muller blocks, dense
 #pragma unroll 1
     for (int e = lane; e < ((KABL & 8) ? 0 : nN); e += kWave) {
@@ -400,15 +414,31 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     if (move == 2) {
         const double z0 = R.zs[si][0][lane];
         R.zs[si][0][lane] = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp(z0 * 0.1);
-    } else if (move == 3) {
-        // ais_walk_propose (src/transition.jl:24-43): Xs = (a + (b + c)) / 3,
-        // W = z1 (a - Xs) + z2 (b - Xs) + z3 (c - Xs); the consumer adds x_i.
-        const double z0 = R.zs[si][0][lane], z1 = R.zs[si][1][lane], z2 = R.zs[si][2][lane];
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const double Xs = kabc_div_rc(wa[k] + (wb[k] + wc[k]), 3.0, 1.0 / 3.0);
-            R.zs[si][k][lane] = z0 * (wa[k] - Xs) + z1 * (wb[k] - Xs) + z2 * (wc[k] - Xs);
+    }
+    // ais_walk_propose (src/transition.jl:24-43): Xs = (a + (b + c)) / 3,
+    // W = z1 (a - Xs) + z2 (b - Xs) + z3 (c - Xs); the consumer adds x_i.  W_k overwrites the
+    // walk lane's normals (zs[0..2]): every item of a pass reads them before any item writes.
+    auto walk_finish = [&](int l, double va, double vb, double vc) {
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+        if (l >= 0) {
+            z0 = R.zs[si][0][l];
+            z1 = R.zs[si][1][l];
+            z2 = R.zs[si][2][l];
         }
+        wave_lds_fence();
+        if (l >= 0) {
+            const double Xs = kabc_div_rc(va + (vb + vc), 3.0, 1.0 / 3.0);
+            R.zs[si][wk][l] = z0 * (va - Xs) + z1 * (vb - Xs) + z2 * (vc - Xs);
+        }
+    };
+    if (nWK > 0) walk_finish(wl0, wa0, wb0, wc0);
+    if (nWK > kWPP) walk_finish(wl1, wa1, wb1, wc1);
+#pragma unroll 1
+    for (int pass = 2; pass * kWPP < nWK; ++pass) {
+        int l;
+        double va = 0.0, vb = 0.0, vc = 0.0;
+        walk_fetch(pass, l, va, vb, vc);
+        walk_finish(l, va, vb, vc);
     }
 }
 
