@@ -151,7 +151,8 @@ def pinned_empty(shape, dtype="float64"):
 
 
 MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6,
-           "log_pn": 7, "sqrt_pn": 8, "u01": 9, "normal_pair": 10, "index32": 11}
+           "log_pn": 7, "sqrt_pn": 8, "u01": 9, "normal_pair": 10, "index32": 11,
+           "exp_bounded": 12}
 
 
 def math_probe(name, x, ctx=None):

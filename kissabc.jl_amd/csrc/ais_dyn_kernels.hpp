@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(kWave) ais_dyn_half_kernel(const AisDynArgs A)
                 const double* xb = A.x_comp + b * D;
                 DynNormals zn = {A.seed, t, w, -1, 0.0, 0.0};
                 if (move == 2) {  // de_propose  src/transition.jl:2-22
-                    const double gamma = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp(zn.get(0) * 0.1);
+                    const double gamma = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp_bounded(zn.get(0) * 0.1);
                     for (int k = 0; k < D; ++k) {
                         const double Wk = (xa[k] - xb[k]) * gamma;
                         const double sk = kabc_fabs(xa[k] - xb[k]) + kabc_fabs(x[k] - xb[k]) +

@@ -413,7 +413,8 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     if (KABL & 16) return;
     if (move == 2) {
         const double z0 = R.zs[si][0][lane];
-        R.zs[si][0][lane] = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp(z0 * 0.1);
+        // |z0| <= sqrt(-2 log 2^-53) = 8.6 (kabc_u01 is never 0): the exponent is within +-0.86
+        R.zs[si][0][lane] = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp_bounded(z0 * 0.1);
     }
     // ais_walk_propose (src/transition.jl:24-43): Xs = (a + (b + c)) / 3,
     // W = z1 (a - Xs) + z2 (b - Xs) + z3 (c - Xs); the consumer adds x_i.  W_k overwrites the

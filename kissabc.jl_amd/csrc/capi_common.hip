@@ -151,6 +151,7 @@ __global__ void math_probe_kernel(int fn, int64_t n, const double* __restrict__ 
                 kabc_normal_pair(kabc_bits(x[2 * i]), kabc_bits(x[2 * i + 1]), &out[2 * i],
                                  &out[2 * i + 1]);
                 break;
+            case 12: out[i] = kabc_exp_bounded(x[i]); break;
             default:
                 out[i] = (double)kabc_index32(kabc_bits(x[2 * i]), (uint32_t)x[2 * i + 1]);
         }
@@ -315,7 +316,7 @@ kabc_status_t kabc_factored_rand(kabc_ctx_t* ctx, const kabc_prior_t* prior, int
 
 kabc_status_t kabc_math_probe(kabc_ctx_t* ctx, int32_t fn, int64_t n, const double* x,
                               double* out) {
-    if (!ctx || !x || !out || n < 0 || fn < 0 || fn > 11) {
+    if (!ctx || !x || !out || n < 0 || fn < 0 || fn > 12) {
         set_error("kabc_math_probe: bad argument");
         return KABC_ERR_INVALID_ARG;
     }

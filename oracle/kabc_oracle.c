@@ -97,6 +97,7 @@ void orc_math_vec(int32_t fn, int64_t n, const double* x, double* out) {
             case 11:
                 out[i] = (double)kabc_index32(kabc_bits(x[2 * i]), (uint32_t)x[2 * i + 1]);
                 break;
+            case 12: out[i] = kabc_exp_bounded(x[i]); break;
             default: out[i] = KABC_NAN;
         }
     }
@@ -532,7 +533,7 @@ static int transition(orc_ais_t* h, int64_t i, uint64_t t, const partner_set_t* 
             blk_t Bn = stream(h->seed, w, t, 3 + j, KABC_DOM_AIS_MOVE);
             kabc_normal_pair(Bn.lo, Bn.hi, &z[2 * j], &z[2 * j + 1]);
         }
-        double gamma = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp(z[0] * 0.1);
+        double gamma = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp_bounded(z[0] * 0.1);
         for (int k = 0; k < D; ++k) {
             double Wk = (xa[k] - xb[k]) * gamma;
             double s = kabc_fabs(xa[k] - xb[k]) + kabc_fabs(xi[k] - xb[k]) +

@@ -98,7 +98,8 @@ def _dp(a):
 
 
 MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6,
-           "log_pn": 7, "sqrt_pn": 8, "u01": 9, "normal_pair": 10, "index32": 11}
+           "log_pn": 7, "sqrt_pn": 8, "u01": 9, "normal_pair": 10, "index32": 11,
+           "exp_bounded": 12}
 MATH_IN_W = {"normal_pair": 2, "index32": 2}
 MATH_OUT_W = {"sincos2pi": 2, "normal_pair": 2}
 

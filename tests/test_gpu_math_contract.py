@@ -27,6 +27,9 @@ def test_log_exp_log1p_lgamma(orc):
     _same(orc, "log", np.concatenate([_pos(rng, -1070, 1023), rng.uniform(0.5, 2.0, N), edge]))
     _same(orc, "log_pn", np.concatenate([_pos(rng, -1020, 1023), rng.uniform(0.0, 1.0, N) + 2.0 ** -53]))
     _same(orc, "exp", np.concatenate([rng.uniform(-750, 710, N), rng.normal(0, 1, N), edge, -edge]))
+    xb = np.concatenate([rng.uniform(-700, 700, N), rng.normal(0, 1, N), [0.0, -0.0, 700.0, -700.0]])
+    _same(orc, "exp_bounded", xb)
+    assert np.array_equal(orc.math_vec("exp_bounded", xb), orc.math_vec("exp", xb))
     _same(orc, "log1p", np.concatenate([rng.uniform(-1, 1, N), _pos(rng, -60, 60), -_pos(rng, -60, 0), edge]))
     _same(orc, "lgamma", np.concatenate([_pos(rng, -20, 20), rng.uniform(0, 40, N), edge]))
 

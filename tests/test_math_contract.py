@@ -53,6 +53,13 @@ def test_log_exp_log1p_within_1ulp_of_libm(orc):
     assert ulp_diff(orc.math_vec("log1p", z), np.log1p(z)).max() <= 1.0
 
 
+def test_exp_bounded_is_exp_on_its_domain(orc):
+    # kabc_exp without the special cases (DE's gamma = c exp(0.1 randn), |arg| < 0.86)
+    x = np.concatenate([rng.uniform(-700, 700, 300000), rng.normal(0, 1, 300000),
+                        [0.0, -0.0, 700.0, -700.0]])
+    assert np.array_equal(orc.math_vec("exp_bounded", x), orc.math_vec("exp", x))
+
+
 def test_log_pn_is_log_on_positive_normals(orc):
     x = np.ldexp(rng.random(300000) + 0.5, rng.integers(-1020, 1020, 300000))
     assert np.array_equal(orc.math_vec("log_pn", x), orc.math_vec("log", x))
