@@ -103,7 +103,9 @@ constexpr int kChunk = 3;    // sub-steps per record buffer = number of producer
 template <int D>
 struct RecGeom {
     static constexpr int NB = (D + 2) / 2;                 // normal blocks of a DE move
-    static constexpr int NZ = (D + 1 > 4) ? (D + 1) : 4;   // doubles per record
+    // doubles per record: D + 1 used; one more so that the second normal of a DE lane's last
+    // block (unused when D is even) has a slot and the Box-Muller phase stores both unconditionally
+    static constexpr int NZ = (D + 2 > 4) ? (D + 2) : 4;
 };
 
 // SoA record buffer of one chunk, lane-contiguous (conflict-free ds_read_b64)
@@ -404,9 +406,10 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
                                                  KABC_DOM_AIS_MOVE);
         double z0, z1;
         kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &z0, &z1, logtab);
-        const int lim = is_de ? D : 2;  // last variate index used
-        if (2 * j <= lim) R.zs[si][2 * j][l] = z0;
-        if (2 * j + 1 <= lim) R.zs[si][2 * j + 1][l] = z1;
+        // both variates are stored: the one past the last used index (DE with even D: D + 1;
+        // walk: 3) lands in a slot nobody reads, or that the walk displacement overwrites
+        R.zs[si][2 * j][l] = z0;
+        R.zs[si][2 * j + 1][l] = z1;
     }
     wave_lds_fence();
     // -- phase C: gamma = 2.38/sqrt(2D) * exp(0.1 randn)   (src/transition.jl:3)
