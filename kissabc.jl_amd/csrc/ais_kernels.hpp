@@ -321,24 +321,26 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     int move = 0;
     uint32_t a = 0;
     // -- phase A: one (walker, t) per lane: move id, partner a, log u, stretch factor
-    if (active) {
+    // Straight-line for all 64 lanes: the lanes past a ragged batch's end draw too (their move
+    // is forced to 0, so they join no list and nobody reads their record), and the stretch
+    // factor is formed and stored whatever the move -- a DE / walk lane's zs[0..1] are
+    // overwritten by its normals in the Box-Muller phase below.
+    {
         const uint32_t w = w_base + (uint32_t)lane;
         // (the prologue hands over the two blocks it expanded while the table was in flight)
         const kabc_u128_t B0 = pre01 ? pre01[0] : kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_AIS_MOVE);
         const kabc_u128_t B1 = pre01 ? pre01[1] : kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_AIS_MOVE);
         const uint32_t m7 = (uint32_t)(((uint64_t)B0.w[2] * 7u) >> 32);  // rand((1,1,1,1,2,2,3))
-        move = (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
-        a = kabc_index32(kabc_lo64(B0), (uint32_t)nc);
+        move = !active ? 0 : (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
+        a = active ? kabc_index32(kabc_lo64(B0), (uint32_t)nc) : 0u;
         R.logu[si][lane] = kabc_log_pn_tab(kabc_u01(kabc_lo64(B1)), logtab);
-        if (move == 1) {
-            // Z = cdf_g_inv(rand(rng), 3.0); correction (D-1) log Z
-            const double sq3 = kabc_sqrt(3.0), isq3 = kabc_sqrt(1.0 / 3.0);
-            const double u = kabc_u01(kabc_hi64(B1));
-            const double tz = u * (sq3 - isq3) + isq3;
-            const double Z = tz * tz;
-            R.zs[si][0][lane] = Z;
-            R.zs[si][1][lane] = (double)(D - 1) * kabc_log_pn_tab(Z, logtab);
-        }
+        // Z = cdf_g_inv(rand(rng), 3.0); correction (D-1) log Z
+        const double sq3 = kabc_sqrt(3.0), isq3 = kabc_sqrt(1.0 / 3.0);
+        const double u = kabc_u01(kabc_hi64(B1));
+        const double tz = u * (sq3 - isq3) + isq3;
+        const double Z = tz * tz;
+        R.zs[si][0][lane] = Z;
+        R.zs[si][1][lane] = (double)(D - 1) * kabc_log_pn_tab(Z, logtab);
     }
     R.mva[si][lane] = ((uint32_t)move << 30) | a;
     R.bb[si][lane] = a;  // valid row for the consumer's unconditional prefetch
@@ -397,10 +399,12 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     // -- phase N: Box-Muller blocks, dense
 #pragma unroll 1
     for (int e = lane; e < ((KABL & 8) ? 0 : nN); e += kWave) {
-        const int e2 = e - nDE * NB;
-        const bool is_de = e2 < 0;
-        const int q = is_de ? e / NB : nDE + (e2 >> 1);
-        const int j = is_de ? e - q * NB : (e2 & 1);
+        // (unsigned arithmetic, both decodings evaluated and selected: no masked regions)
+        const unsigned ue = (unsigned)e, ude = (unsigned)(nDE * NB);
+        const bool is_de = ue < ude;
+        const unsigned qd = ue / (unsigned)NB, e2 = ue - ude;
+        const int q = (int)(is_de ? qd : (unsigned)nDE + (e2 >> 1));
+        const int j = (int)(is_de ? ue - qd * (unsigned)NB : (e2 & 1u));
         const int l = listB[q];
         const kabc_u128_t Bn = kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 3u + (uint32_t)j,
                                                  KABC_DOM_AIS_MOVE);
