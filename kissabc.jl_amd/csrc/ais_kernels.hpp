@@ -633,7 +633,7 @@ ais_half_kernel(const AisArgs A0) {
                     const uint32_t mvan = R.mva[sn][lane], bn = R.bb[sn][lane];
                     const double logu = R.logu[si][lane];
                     double zs[D + 1];
-    #pragma unroll
+#pragma unroll
                     for (int j = 0; j < D + 1; ++j) zs[j] = R.zs[si][j][lane];
                     // (2) prefetch.  D <= kLateFrom: into the second register set, right away.
                     //     Larger D (two more rows would not fit 256 VGPRs: D = 16 spilled 480 B
@@ -654,13 +654,13 @@ ais_half_kernel(const AisArgs A0) {
                     // with another move overwrites y below): two independent masked regions
                     // instead of a three-way nest, i.e. fewer EXEC manipulations on the wave's
                     // single issue stream.
-    #pragma unroll
+#pragma unroll
                     for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];
                     if (move == 1u) {
                         // stretch_propose  src/transition.jl:51-59
                         const double Z = zs[0];
                         corr = zs[1];
-    #pragma unroll
+#pragma unroll
                         for (int k = 0; k < D; ++k) {
                             const double W = (x[k] - pa[k]) * Z;
                             y[k] = pa[k] + W;
@@ -669,7 +669,7 @@ ais_half_kernel(const AisArgs A0) {
                     if (move == 2u) {
                         // de_propose  src/transition.jl:2-22
                         const double gamma = zs[0];
-    #pragma unroll
+#pragma unroll
                         for (int k = 0; k < D; ++k) {
                             const double Wk = (pa[k] - pb[k]) * gamma;
                             const double sk = kabc_fabs(pa[k] - pb[k]) + kabc_fabs(x[k] - pb[k]) +
@@ -719,7 +719,7 @@ ais_half_kernel(const AisArgs A0) {
                         acc = valid && (-e <= lW) && (lW2 >= 0.0);
                     }
                     if (acc) {
-    #pragma unroll
+#pragma unroll
                         for (int k = 0; k < D; ++k) x[k] = y[k];
                         lp = nlp;
                         ll = nll;
@@ -739,10 +739,10 @@ ais_half_kernel(const AisArgs A0) {
                 // remaining sub-steps still run (their result is discarded by the host), which
                 // keeps the loop bounds wave-uniform
                 if constexpr (kLate) {
-    #pragma unroll 1
+#pragma unroll 1
                     for (int si = 0; si < ns; ++si) substep(si, r0a, r0b, r0a, r0b);
                 } else {
-    #pragma unroll 1
+#pragma unroll 1
                     for (int si = 0; si < ns; si += 2) {
                         substep(si, r0a, r0b, r1a, r1b);
                         if (si + 1 < ns) substep(si + 1, r1a, r1b, r0a, r0b);
