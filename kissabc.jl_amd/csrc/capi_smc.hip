@@ -496,9 +496,10 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
                 looped = true;
                 unsigned long long st[24];
                 if (la.stamps && hipMemcpy(st, la.stamps, 192, hipMemcpyDeviceToHost) == hipSuccess && st[8])
-                    fprintf(stderr, "[kabc smc loop, 10 ns ticks per iteration] publish %.0f B1 %.0f fold %.0f "
+                    fprintf(stderr, "[kabc smc loop, 10 ns ticks per iteration] publish (records %.0f + next draws %.0f + sync,arrive %.0f) B1 %.0f fold %.0f "
                             "rounds %.0f gather %.0f B2 %.0f eps+mask %.0f mcmc %.0f | iterations %llu "
                             "cand/iter %.1f predicted %llu barriers %.2f/iter | eps+mask split: loads+fold %.0f rank %.0f patch+scan %.0f | mcmc split: philox+select %.0f issue+pre %.0f wait %.0f logpdf %.0f cost+accept %.0f tail %.0f\n",
+                            (double)st[21] / st[8], (double)st[22] / st[8],
                             (double)st[0] / st[8], (double)st[1] / st[8], (double)st[2] / st[8],
                             (double)st[3] / st[8], (double)st[4] / st[8], (double)st[5] / st[8],
                             (double)st[6] / st[8], (double)st[7] / st[8], st[8], (double)st[9] / st[8],
