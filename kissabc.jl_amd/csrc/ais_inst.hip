@@ -1,6 +1,12 @@
 // ais_inst.hip -- instantiates ais_half_kernel<D, COST, prior class, posterior kind> for one DeviceCost id
 // (-DKABC_INST_COST=<id>) and every dimension 1..KABC_MAX_DIM the cost accepts.
 // One translation unit per cost id so the instantiations compile in parallel.
+// Horner constants (kabc_fma_c, include/kabc_math.h) as vector-register operands in these
+// kernels: the producers run their own chunk loop with ~80 vector registers to spare, so hipcc
+// hoists most of the constants out of it, where the scalar-register form re-materialises each one
+// with two s_mov_b32 at every use (scalar registers are what this kernel is short of).  Same
+// v_fma_f64, same results; -0.8 % per launch at ntransitions = 100, -3 % at 1.
+#define KABC_FMA_C_VGPR
 #include "ais_kernels.hpp"
 
 #ifndef KABC_INST_COST
