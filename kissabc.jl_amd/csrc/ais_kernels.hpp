@@ -261,6 +261,19 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
                 yp[k] = v;
                 in = in && (v >= lo[k]) && (v <= hi[k]);
             }
+            if constexpr (kCheap) {
+                // finished here too: the two paths then meet on (lp, ll, ev) only, not on yp
+                lp = in ? B.lp : -KABC_INF;
+                ev = in;
+                const double c = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
+                if (posterior == KABC_POSTERIOR_KERNELIZED) {
+                    const double q = kabc_div_rc(c, eps, reps);
+                    ll = in ? -0.5 * (q * q) : lp;
+                } else {
+                    ll = in ? c : -lp;
+                }
+                return;
+            }
         }
         lp = in ? B.lp : -KABC_INF;
     } else {
