@@ -241,14 +241,17 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
             if constexpr (kCheap) {
                 // finish here, on y itself: merging this path with the rounding one through yp
                 // costs D register-pair copies per transition
-                lp = in ? B.lp : -KABC_INF;
+                // (outside the box the reference's values are lp = -Inf, ll = -/+Inf: an invalid
+                // log-density that accept() rejects.  Here the caller gates on `ev` instead and
+                // lp / ll are left as computed -- no selects on the consumer's issue stream)
+                lp = B.lp;
                 ev = in;
                 const double c = eval_cost<COST, D>(y, cost_params, cost_data, ndata, rng);
                 if (posterior == KABC_POSTERIOR_KERNELIZED) {
                     const double q = kabc_div_rc(c, eps, reps);
-                    ll = in ? -0.5 * (q * q) : lp;
+                    ll = -0.5 * (q * q);
                 } else {
-                    ll = in ? c : -lp;
+                    ll = c;
                 }
                 return;
             }
@@ -263,14 +266,14 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
             }
             if constexpr (kCheap) {
                 // finished here too: the two paths then meet on (lp, ll, ev) only, not on yp
-                lp = in ? B.lp : -KABC_INF;
+                lp = B.lp;
                 ev = in;
                 const double c = eval_cost<COST, D>(yp, cost_params, cost_data, ndata, rng);
                 if (posterior == KABC_POSTERIOR_KERNELIZED) {
                     const double q = kabc_div_rc(c, eps, reps);
-                    ll = in ? -0.5 * (q * q) : lp;
+                    ll = -0.5 * (q * q);
                 } else {
-                    ll = in ? c : -lp;
+                    ll = c;
                 }
                 return;
             }
@@ -716,7 +719,9 @@ ais_half_kernel(const AisArgs A0) {
                     // Inf log-density makes `valid` false whatever the comparisons say)
                     const bool okc = kabc_isfinite(corr);
                     err = (!okc && err == 0) ? 1 : err;
-                    const bool valid = okc && ld_valid(PK, nlp, nll);
+                    // (`ev` false = the proposal has no prior support: its log-density is
+                    // invalid whatever loglike left in nlp / nll)
+                    const bool valid = okc && ev && ld_valid(PK, nlp, nll);
                     const double e = -logu;  // randexp(rng)
                     bool acc;
                     if (PK == KABC_POSTERIOR_KERNELIZED) {
