@@ -743,6 +743,11 @@ ais_half_kernel(const AisArgs A0) {
                         ll = nll;
                         n_acc += 1u;
                     }
+                    // (no code: pins the state to ONE set of registers here.  Without it hipcc
+                    // keeps a second copy of x -- the value "after the loop" -- and every accept
+                    // updates both: 8 v_mov_b64 per sub-step)
+#pragma unroll
+                    for (int k = 0; k < D; ++k) asm volatile("" : "+v"(x[k]));
                     if (A.dbg) {
                         int32_t* d = A.dbg + (r * A.nt + (s0 + si)) * 6;
                         d[0] = (int32_t)move;
