@@ -409,7 +409,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         }
     };
     int wl0, wl1;
-    double wa0 = 0.0, wb0 = 0.0, wc0 = 0.0, wa1 = 0.0, wb1 = 0.0, wc1 = 0.0;
+    double wa0, wb0, wc0, wa1, wb1, wc1;  // (defined exactly where wl0 / wl1 >= 0)
     walk_fetch(0, wl0, wa0, wb0, wc0);
     walk_fetch(1, wl1, wa1, wb1, wc1);
     // -- phase N: Box-Muller blocks, dense
@@ -441,16 +441,12 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     }
     // ais_walk_propose (src/transition.jl:24-43): Xs = (a + (b + c)) / 3,
     // W = z1 (a - Xs) + z2 (b - Xs) + z3 (c - Xs); the consumer adds x_i.  W_k overwrites the
-    // walk lane's normals (zs[0..2]): every item of a pass reads them before any item writes.
+    // walk lane's normals (zs[0..2]): every item of a pass reads them before any item writes --
+    // the items of a pass are the lanes of ONE wavefront executing the same instructions, each
+    // store depends on its lane's loads, and the LDS executes a wavefront's instructions in order.
     auto walk_finish = [&](int l, double va, double vb, double vc) {
-        double z0 = 0.0, z1 = 0.0, z2 = 0.0;
         if (l >= 0) {
-            z0 = R.zs[si][0][l];
-            z1 = R.zs[si][1][l];
-            z2 = R.zs[si][2][l];
-        }
-        wave_lds_fence();
-        if (l >= 0) {
+            const double z0 = R.zs[si][0][l], z1 = R.zs[si][1][l], z2 = R.zs[si][2][l];
             const double Xs = kabc_div_rc(va + (vb + vc), 3.0, 1.0 / 3.0);
             R.zs[si][wk][l] = z0 * (va - Xs) + z1 * (vb - Xs) + z2 * (vc - Xs);
         }
@@ -460,7 +456,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
 #pragma unroll 1
     for (int pass = 2; pass * kWPP < nWK; ++pass) {
         int l;
-        double va = 0.0, vb = 0.0, vc = 0.0;
+        double va, vb, vc;
         walk_fetch(pass, l, va, vb, vc);
         walk_finish(l, va, vb, vc);
     }
