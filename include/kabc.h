@@ -34,6 +34,9 @@ extern "C" {
  * results).  User cost plugins follow.  ABCDE / pfilter stop at KABC_MAX_DIM.  The reference has
  * no bound (src/priors.jl:10-13). */
 #define KABC_MAX_DIM_DYN 256
+/* AIS ensemble size: nparticles < 2^31 and (nparticles / 2) * length(prior) * 8 bytes < 4 GiB
+ * (partner rows are addressed by a 32-bit byte offset into their half: 134 M walkers at
+ * D = 8); beyond that kabc_ais_create* return KABC_ERR_UNSUPPORTED. */
 
 typedef enum kabc_status {
     KABC_OK = 0,

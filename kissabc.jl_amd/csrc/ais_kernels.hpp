@@ -528,6 +528,12 @@ ais_half_kernel(const AisArgs A0) {
         }                                                                 \
     } while (0)
 
+    // a row of the complementary half by a 32-bit byte offset from the (scalar) base: one shift
+    // per row instead of a 64-bit shift and add (the host guarantees n_comp * D * 8 < 2^32)
+    auto comp_row = [&](uint32_t idx) -> const double* {
+        return reinterpret_cast<const double*>(reinterpret_cast<const char*>(A.x_comp) +
+                                               (size_t)(idx * (uint32_t)(D * sizeof(double))));
+    };
     // consumer state (wave 0)
     const bool active = (wave == 0) && (lane < n_active);
     const int64_t r = r0 + lane;
@@ -633,8 +639,8 @@ ais_half_kernel(const AisArgs A0) {
                 // swapped, so no row is ever copied.
                 constexpr bool kLate = D > kLateFrom;
                 double r0a[D], r0b[D], r1a[kLate ? 1 : D], r1b[kLate ? 1 : D];
-                load_row<D>(A.x_comp + (int64_t)(R.mva[0][lane] & 0x3fffffffu) * D, r0a);
-                load_row<D>(A.x_comp + (int64_t)R.bb[0][lane] * D, r0b);
+                load_row<D>(comp_row(R.mva[0][lane] & 0x3fffffffu), r0a);
+                load_row<D>(comp_row(R.bb[0][lane]), r0b);
                 auto substep = [&](const int si, const double (&pa)[D], const double (&pb)[D],
                                    double (&na)[D], double (&nb)[D]) __attribute__((always_inline)) {
                     const uint64_t t = A.t0 + (uint64_t)(s0 + si);
@@ -652,8 +658,8 @@ ais_half_kernel(const AisArgs A0) {
                     //     and ran 4.3x slower than D = 8): into the SAME registers, as soon as
                     //     the proposal below has consumed the current rows.
                     if constexpr (!kLate) {
-                        load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
-                        load_row<D>(A.x_comp + (int64_t)bn * D, nb);
+                        load_row<D>(comp_row(mvan & 0x3fffffffu), na);
+                        load_row<D>(comp_row(bn), nb);
                     }
                     // scheduling fences: without them hipcc interleaves the phases of a
                     // sub-step for ILP and needs > 300 VGPRs (spills, 1 wave per SIMD)
@@ -692,8 +698,8 @@ ais_half_kernel(const AisArgs A0) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (kLate) {  // pa/pb are dead now: na/nb alias them
-                        load_row<D>(A.x_comp + (int64_t)(mvan & 0x3fffffffu) * D, na);
-                        load_row<D>(A.x_comp + (int64_t)bn * D, nb);
+                        load_row<D>(comp_row(mvan & 0x3fffffffu), na);
+                        load_row<D>(comp_row(bn), nb);
                     }
                     // ld = loglike(density, push_p(density, p))   src/transition.jl:75
                     kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u,

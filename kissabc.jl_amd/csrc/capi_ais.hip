@@ -238,6 +238,12 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         set_error("nparticles must be < 2^31");
         return KABC_ERR_INVALID_ARG;
     }
+    // the kernels address a partner row by a 32-bit byte offset into its half (include/kabc.h)
+    if ((n_total / 2 + 1 + 64ll * world) * m->D * 8 >= (1ll << 32)) {
+        set_error("nparticles = %lld with length(prior) = %d: a half-ensemble must stay below 4 GiB",
+                  (long long)n_total, m->D);
+        return KABC_ERR_UNSUPPORTED;
+    }
     if (m->posterior != KABC_POSTERIOR_KERNELIZED && m->posterior != KABC_POSTERIOR_THRESHOLD &&
         m->posterior != KABC_POSTERIOR_COMMON) {
         set_error("unknown posterior kind %d", m->posterior);

@@ -82,3 +82,8 @@ def test_argument_errors(k, gpu_ctx):
         k.AisEnsemble(k.ApproxKernelizedPosterior(k.Normal(0, 1), k.costs.Rosenbrock(), 1.0), 16)
     with pytest.raises(k.KabcError):      # invalid prior parameters
         k.AisEnsemble(k.ApproxKernelizedPosterior(k.Normal(0, -1), k.costs.AbsDiff(0.3), 0.5), 16)
+    # a half-ensemble must stay below 4 GiB (32-bit row offsets, include/kabc.h): refused before
+    # anything is allocated
+    big = k.ApproxKernelizedPosterior(k.Factored(*[k.Uniform(-5, 5)] * 8), k.costs.Rosenbrock(), 1.0)
+    with pytest.raises(k.KabcError, match="4 GiB"):
+        k.AisEnsemble(big, 2 ** 28, seed=1)
