@@ -403,9 +403,12 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         l = -1;
         if (wq < kWPP && q < nWK) {
             l = listB[nDE + q];
-            va = A.x_comp[(int64_t)(R.mva[si][l] & 0x3fffffffu) * D + wk];
-            vb = A.x_comp[(int64_t)R.bb[si][l] * D + wk];
-            vc = A.x_comp[(int64_t)R.cc[si][l] * D + wk];
+            // (32-bit byte offsets from the scalar base, like the consumer's row loads)
+            const char* cb = reinterpret_cast<const char*>(A.x_comp);
+            const uint32_t ko = (uint32_t)wk * 8u;
+            va = *reinterpret_cast<const double*>(cb + (size_t)((R.mva[si][l] & 0x3fffffffu) * (uint32_t)(D * 8) + ko));
+            vb = *reinterpret_cast<const double*>(cb + (size_t)(R.bb[si][l] * (uint32_t)(D * 8) + ko));
+            vc = *reinterpret_cast<const double*>(cb + (size_t)(R.cc[si][l] * (uint32_t)(D * 8) + ko));
         }
     };
     int wl0, wl1;
