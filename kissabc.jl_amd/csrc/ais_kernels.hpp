@@ -722,11 +722,12 @@ ais_half_kernel(const AisArgs A0) {
                     // can only change through an accept, which requires a valid new state)
                     // straight-line: every comparison is evaluated, the flags are combined (a NaN /
                     // Inf log-density makes `valid` false whatever the comparisons say)
-                    const bool okc = kabc_isfinite(corr);
-                    err = (!okc && err == 0) ? 1 : err;
+                    // `isfinite(ld_correction) || error(...)` (src/types.jl:69) cannot fire here:
+                    // the correction is 0 (DE, walk) or (D-1) log Z with Z in [1/3, 3] (stretch), so
+                    // the test is not on the consumer's issue stream (the oracle keeps it).
                     // (`ev` false = the proposal has no prior support: its log-density is
                     // invalid whatever loglike left in nlp / nll)
-                    const bool valid = okc && ev && ld_valid(PK, nlp, nll);
+                    const bool valid = ev && ld_valid(PK, nlp, nll);
                     const double e = -logu;  // randexp(rng)
                     bool acc;
                     if (PK == KABC_POSTERIOR_KERNELIZED) {
