@@ -677,13 +677,18 @@ ais_half_kernel(const AisArgs A0) {
                     // single issue stream.
 #pragma unroll
                     for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];
+                    // x - a serves the stretch move as it is and the DE move as |a - x| (a
+                    // negation is exact): formed once, for every lane, outside both regions
+                    double xa[D];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) xa[k] = x[k] - pa[k];
                     if (move == 1u) {
                         // stretch_propose  src/transition.jl:51-59
                         const double Z = zs[0];
                         corr = zs[1];
 #pragma unroll
                         for (int k = 0; k < D; ++k) {
-                            const double W = (x[k] - pa[k]) * Z;
+                            const double W = xa[k] * Z;
                             y[k] = pa[k] + W;
                         }
                     }
@@ -694,7 +699,7 @@ ais_half_kernel(const AisArgs A0) {
                         for (int k = 0; k < D; ++k) {
                             const double Wk = (pa[k] - pb[k]) * gamma;
                             const double sk = kabc_fabs(pa[k] - pb[k]) + kabc_fabs(x[k] - pb[k]) +
-                                              kabc_fabs(pa[k] - x[k]);
+                                              kabc_fabs(xa[k]);
                             const double Tk = kabc_div_rc(gamma * sk, 300.0, 1.0 / 300.0) * zs[1 + k];
                             y[k] = x[k] + Wk + Tk;
                         }
