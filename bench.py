@@ -253,10 +253,10 @@ def main():
     smc = None
     if world == 1 and not args.no_smc:
         prior, cost, kw = c4_problem(k)
-        # warm-up: module load, allocations, and the runtime's one-off ~20 ms hiccup that lands on
-        # about the fifth cooperative launch of a process (steady state afterwards)
+        # warm-up: module load, allocations, and a one-off ~25 ms hiccup on the fourth call that
+        # returns the 4 MiB particle array (host-side; steady state afterwards)
         for _ in range(6):
-            k.smc(prior, cost, ctx=ctx, **kw)
+            k.smc(prior, cost, ctx=ctx, return_array=True, **kw)
         walls, r = [], None
         for _ in range(7):
             t0 = time.perf_counter()
