@@ -51,6 +51,14 @@ def exchange_unique_id(rank, world, key=None, directory=None, timeout=300.0):
         with open(tmp, "wb") as f:
             f.write(uid)
         os.replace(tmp, path)   # atomic: readers see all 128 bytes or no file
+        import atexit
+
+        def _cleanup(p=path):    # a later job with the same rendezvous must not find this id
+            try:
+                os.remove(p)
+            except OSError:
+                pass
+        atexit.register(_cleanup)
         return uid
     t0 = time.time()
     while True:
