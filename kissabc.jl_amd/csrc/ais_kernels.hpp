@@ -326,7 +326,8 @@ __device__ __forceinline__ void wave_lds_fence() {
 #define KABL 0
 #endif
 template <int D>
-__device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R, int si,
+__device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t seed,
+                                                ChunkRec<D>& R, int si,
                                                 uint64_t t, uint32_t w_base, int n_active,
                                                 uint8_t* listB, int lane,
                                                 const double* logtab,
@@ -344,8 +345,8 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
     {
         const uint32_t w = w_base + (uint32_t)lane;
         // (the prologue hands over the two blocks it expanded while the table was in flight)
-        const kabc_u128_t B0 = pre01 ? pre01[0] : kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_AIS_MOVE);
-        const kabc_u128_t B1 = pre01 ? pre01[1] : kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_AIS_MOVE);
+        const kabc_u128_t B0 = pre01 ? pre01[0] : kabc_stream_block(seed, w, t, 0u, KABC_DOM_AIS_MOVE);
+        const kabc_u128_t B1 = pre01 ? pre01[1] : kabc_stream_block(seed, w, t, 1u, KABC_DOM_AIS_MOVE);
         const uint32_t m7 = (uint32_t)(((uint64_t)B0.w[2] * 7u) >> 32);  // rand((1,1,1,1,2,2,3))
         move = !active ? 0 : (m7 < 4u) ? 1 : (m7 < 6u) ? 2 : 3;
         a = active ? kabc_index32(kabc_lo64(B0), (uint32_t)nc) : 0u;
@@ -379,7 +380,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         const int l = listB[e];
         const uint32_t al = R.mva[si][l] & 0x3fffffffu;
         const kabc_u128_t B2 =
-            kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 2u, KABC_DOM_AIS_MOVE);
+            kabc_stream_block(seed, w_base + (uint32_t)l, t, 2u, KABC_DOM_AIS_MOVE);
         int64_t b = (int64_t)kabc_index32(kabc_lo64(B2), (uint32_t)nc - 1u);
         b += (b >= (int64_t)al);
         const int64_t lo = (int64_t)al < b ? (int64_t)al : b, hi = (int64_t)al < b ? b : (int64_t)al;
@@ -425,7 +426,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, ChunkRec<D>& R
         const int q = (int)(is_de ? qd : (unsigned)nDE + (e2 >> 1));
         const int j = (int)(is_de ? ue - qd * (unsigned)NB : (e2 & 1u));
         const int l = listB[q];
-        const kabc_u128_t Bn = kabc_stream_block(A.seed, w_base + (uint32_t)l, t, 3u + (uint32_t)j,
+        const kabc_u128_t Bn = kabc_stream_block(seed, w_base + (uint32_t)l, t, 3u + (uint32_t)j,
                                                  KABC_DOM_AIS_MOVE);
         double z0, z1;
         kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &z0, &z1, logtab);
@@ -593,11 +594,16 @@ ais_half_kernel(const AisArgs A0) {
         }
     }
 
+    // The stream seed as a VECTOR-register value for the producers: the ten Philox round keys
+    // derived from it are loop-invariant either way, but as scalars they took twenty of the scalar
+    // registers this kernel is short of (reloaded from spill lanes in every sub-step).
+    uint64_t seed_v = A.seed;
+    asm volatile("" : "+v"(seed_v));
     // prologue: producers fill chunk 0
     if (wave > 0) {
         const int si = wave - 1;
         if (si < A.nt && !(KABL & 4)) {
-            produce_substep<D>(A, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
+            produce_substep<D>(A, seed_v, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
                                lane, slogtab, pro01);
             if constexpr (kAuxW > 0)
                 prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)si, w_base, lane, saux[0][si],
@@ -619,7 +625,7 @@ ais_half_kernel(const AisArgs A0) {
             const int si = wave - 1;
             const int s = s0 + kChunk + si;
             if (s < A.nt && !(KABL & 2)) {
-                produce_substep<D>(A, rec[(c + 1) & 1], si, A.t0 + (uint64_t)s, w_base, n_active,
+                produce_substep<D>(A, seed_v, rec[(c + 1) & 1], si, A.t0 + (uint64_t)s, w_base, n_active,
                                    listB[si], lane, slogtab);
                 if constexpr (kAuxW > 0)
                     prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)s, w_base, lane,
