@@ -337,6 +337,10 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
     const bool in = i < N;
     const int nwords = (int)G * kLoopWaves;
 
+    // (the stream seed as a vector-register value: the Philox round keys derived from it then do
+    // not occupy twenty scalar registers; csrc/ais_kernels.hpp does the same)
+    uint64_t seed_v = A.seed;
+    asm volatile("" : "+v"(seed_v));
     unsigned long long t_prev = (A.stamps && bid == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // phase times are accumulated in registers and written once at the end (a global
     // read-modify-write per stamp cost more than the phases it measured)
@@ -391,7 +395,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
 #pragma unroll
                 for (int j = kPreA; j < kPre; ++j) {
                     const kabc_u128_t Bn =
-                        kabc_stream_block(A.seed, (uint32_t)i, nps, (uint32_t)j, KABC_DOM_SMC_COST);
+                        kabc_stream_block(seed_v, (uint32_t)i, nps, (uint32_t)j, KABC_DOM_SMC_COST);
                     kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
                                          kabc_log_tab);
                 }
@@ -457,9 +461,9 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
         if (in) {
             nps = pass + (iteration > 0 ? 2u : 1u);
             const uint32_t w = (uint32_t)i;
-            const kabc_u128_t B0 = kabc_stream_block(A.seed, w, nps, 0u, KABC_DOM_SMC_MOVE);
-            const kabc_u128_t B1 = kabc_stream_block(A.seed, w, nps, 1u, KABC_DOM_SMC_MOVE);
-            const kabc_u128_t B2 = kabc_stream_block(A.seed, w, nps, 2u, KABC_DOM_SMC_MOVE);
+            const kabc_u128_t B0 = kabc_stream_block(seed_v, w, nps, 0u, KABC_DOM_SMC_MOVE);
+            const kabc_u128_t B1 = kabc_stream_block(seed_v, w, nps, 1u, KABC_DOM_SMC_MOVE);
+            const kabc_u128_t B2 = kabc_stream_block(seed_v, w, nps, 2u, KABC_DOM_SMC_MOVE);
             int64_t a = (int64_t)kabc_index32(kabc_lo64(B0), (uint32_t)N - 1u);
             a += (a >= i);
             const int64_t lo = a < i ? a : i, hi = a < i ? i : a;
@@ -476,7 +480,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             if constexpr (kPre > 0) {
 #pragma unroll
                 for (int j = 0; j < kPre0; ++j) {
-                    const kabc_u128_t Bn = kabc_stream_block(A.seed, w, nps, (uint32_t)j, KABC_DOM_SMC_COST);
+                    const kabc_u128_t Bn = kabc_stream_block(seed_v, w, nps, (uint32_t)j, KABC_DOM_SMC_COST);
                     kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
                                          kabc_log_tab);
                 }
@@ -505,7 +509,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
 #pragma unroll
                 for (int j = kPre0; j < kPreA; ++j) {
                     const kabc_u128_t Bn =
-                        kabc_stream_block(A.seed, (uint32_t)i, nps, (uint32_t)j, KABC_DOM_SMC_COST);
+                        kabc_stream_block(seed_v, (uint32_t)i, nps, (uint32_t)j, KABC_DOM_SMC_COST);
                     kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
                                          kabc_log_tab);
                 }
@@ -943,7 +947,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                 load_row<D>(theta_src + sb * D, tb);
                 if (alive_i) {
                     const double s = nx_s, lprob = nx_lprob;
-                    kabc_cost_rng_t rng = {A.seed, ps, w, KABC_DOM_SMC_COST, 0u};
+                    kabc_cost_rng_t rng = {seed_v, ps, w, KABC_DOM_SMC_COST, 0u};
                     if constexpr (kPre > 0) {
                         rng.pre = nx_pre;
                         rng.pre_n = (uint32_t)kPre;
