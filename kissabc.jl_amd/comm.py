@@ -31,29 +31,69 @@ def unique_id():
     return bytes(buf)
 
 
-def exchange_unique_id(rank, world, key=None, directory=None, timeout=300.0):
+_UID_MAGIC = b"KABCUID1"
+
+
+def _launch_stamp():
+    """Identity of the LAUNCH this process belongs to: (pid, kernel start time) of its parent.
+    Every local rank of one launch is a child of the same launcher process (torchrun's elastic
+    agent, mpirun's proxy, a Julia / shell driver), two launches never share the pair -- the start
+    time disambiguates a recycled pid -- so a file named after it cannot be a leftover of an
+    earlier job, however long ago or recently that job ran."""
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open(f"/proc/{ppid}/stat", "rb") as f:
+            st = f.read()
+        start = st[st.rindex(b")") + 2:].split()[19].decode()   # field 22: starttime
+    except (OSError, ValueError, IndexError):
+        pass
+    return f"p{ppid}-{start}"
+
+
+def rendezvous_key(world):
+    """Default name of the rendezvous file.  KABC_RDZV_KEY (any string the host guarantees
+    unique per launch, e.g. a scheduler job id) wins; otherwise the launcher's rendezvous
+    variables + the launch stamp.  Without either there is nothing that tells two concurrent
+    jobs of one user apart, and the id is refused rather than guessed."""
+    clean = lambda v: "".join(ch if ch.isalnum() else "-" for ch in str(v))   # noqa: E731
+    explicit = os.environ.get("KABC_RDZV_KEY")
+    if explicit:
+        return f"{clean(explicit)}_w{world}"
+    env = [os.environ.get(v, "") for v in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
+                                           "TORCHELASTIC_RESTART_COUNT")]
+    if not (env[1] or env[2]):
+        raise RuntimeError(
+            "cannot name the unique-id rendezvous: neither MASTER_PORT nor TORCHELASTIC_RUN_ID is "
+            "set.  Launch the ranks with torchrun / `python -m torch.distributed.run`, or set "
+            "KABC_RDZV_KEY to a string unique to this launch (and identical on all its ranks), or "
+            "pass the id yourself: Comm.init_rank(uid, rank, world)")
+    return f"{clean('_'.join(env))}_{_launch_stamp()}_w{world}"
+
+
+def exchange_unique_id(rank, world, key=None, directory=None, timeout=300.0, make_id=None):
     """Ship rank 0's RCCL unique id to the other ranks of ONE node through a file
     (the id is 128 opaque bytes; any channel the host owns would do -- a Julia host
-    would use Distributed or MPI.bcast).  `key` defaults to the launcher's rendezvous
-    (MASTER_ADDR, MASTER_PORT, TORCHELASTIC_RUN_ID), so concurrent jobs do not collide."""
+    would use Distributed or MPI.bcast).  The file is named after `key`
+    (default: rendezvous_key -- unique per launch, so no freshness heuristic is needed: a rank
+    may start minutes after rank 0 published and still finds the right id).  Rank 0 replaces
+    whatever is at the path atomically and removes the file when it exits."""
+    make_id = make_id or unique_id
     if world == 1:
-        return unique_id()
+        return make_id()
     directory = directory or os.environ.get("KABC_RDZV_DIR") or "/tmp"
     if key is None:
-        key = "_".join(str(os.environ.get(v, "")) for v in
-                       ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID",
-                        "TORCHELASTIC_RESTART_COUNT"))
-        key = "".join(ch if ch.isalnum() else "-" for ch in key) + f"_w{world}"
+        key = rendezvous_key(world)
     path = os.path.join(directory, f"kabc_uid_{os.getuid()}_{key}.bin")
     if rank == 0:
-        uid = unique_id()
+        uid = make_id()
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)   # atomic: readers see all 128 bytes or no file
+            f.write(_UID_MAGIC + uid)
+        os.replace(tmp, path)   # atomic: readers see the whole record or the previous file
         import atexit
 
-        def _cleanup(p=path):    # a later job with the same rendezvous must not find this id
+        def _cleanup(p=path):    # nothing of this launch outlives it
             try:
                 os.remove(p)
             except OSError:
@@ -63,21 +103,15 @@ def exchange_unique_id(rank, world, key=None, directory=None, timeout=300.0):
     t0 = time.time()
     while True:
         try:
-            # only a file written after this job started counts (a stale one from an earlier
-            # job with the same rendezvous would hang ncclCommInitRank)
-            if os.path.getmtime(path) >= _JOB_START - 5.0:
-                with open(path, "rb") as f:
-                    uid = f.read()
-                if len(uid) == cd.KABC_COMM_ID_BYTES:
-                    return uid
+            with open(path, "rb") as f:
+                rec = f.read()
+            if len(rec) == len(_UID_MAGIC) + cd.KABC_COMM_ID_BYTES and rec.startswith(_UID_MAGIC):
+                return rec[len(_UID_MAGIC):]
         except OSError:
             pass
         if time.time() - t0 > timeout:
             raise TimeoutError(f"rank {rank}: no unique id at {path} after {timeout:.0f}s")
         time.sleep(0.02)
-
-
-_JOB_START = time.time()
 
 
 class Comm:
