@@ -269,6 +269,17 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h);
  * half-generation can draw partners from them.  Draws are keyed by GLOBAL walker id:
  * the trajectory is bit-identical for every world size.  Log-densities never travel.
  *
+ * Pipelined exchange.  With K > 1 EXCHANGE CHUNKS the ownership is block-cyclic: chunk k of
+ * a half is the row range [k*world*c, (k+1)*world*c), c = ceil(rows_h / (K*world)), and rank
+ * r owns its r-th segment of c rows -- so the all-gather of chunk k is in place and
+ * contiguous and runs on a second stream while the kernels of chunk k+1 compute; only the
+ * last chunk's gather is exposed.  K is chosen at kabc_ais_create_dist: the environment
+ * variable KABC_EXCHANGE_CHUNKS (1..KABC_MAX_EXCHANGE_CHUNKS), else one chunk per full
+ * residency wave of the kernel (K = 1 up to 65 536 walkers per rank and half: a smaller
+ * launch takes as long as a full one, so finer chunks would serialise the compute they are
+ * meant to hide).  Results do not depend on K.  kabc_ais_owned_segments
+ * reports the owned row ranges.
+ *
  * Two ways to form the communicator:
  *   one process per GPU   kabc_comm_unique_id on rank 0 -> the host ships the 128 bytes
  *                         to the other ranks (Julia: Distributed/MPI.bcast, a file, a
@@ -283,6 +294,7 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h);
 typedef struct kabc_comm kabc_comm_t;
 #define KABC_COMM_ID_BYTES 128
 #define KABC_COMM_MAX_WORLD 16
+#define KABC_MAX_EXCHANGE_CHUNKS 16
 typedef enum kabc_comm_backend {
     KABC_COMM_RCCL = 1,
     KABC_COMM_P2P = 2
@@ -317,6 +329,12 @@ kabc_status_t kabc_ais_create_dist(kabc_comm_t* comm, const kabc_model_t* model,
 /* the whole ensemble as this rank sees it after the last all-gather: x[N][D], walker-id
  * order, push_p NOT applied (identical on every rank) */
 kabc_status_t kabc_ais_get_ensemble(kabc_ais_t* h, double* x);
+/* The row ranges of `half` this handle owns, in the order kabc_ais_get_state / set_state /
+ * get_debug lay the owned rows out: first[i] = global row inside the half, count[i] rows
+ * (may be 0).  Returns the number of segments (= exchange chunks K; 1 for unsharded
+ * handles), at most `cap` of them are written; -1 on a bad argument. */
+int32_t kabc_ais_owned_segments(const kabc_ais_t* h, int32_t half, int64_t* first, int64_t* count,
+                                int32_t cap);
 /* single-process drivers for the n handles created on the n communicators of one
  * kabc_comm_init_all call (hs[i] on comms[i], every rank present exactly once) */
 kabc_status_t kabc_ais_init_multi(kabc_ais_t** hs, int32_t n, int32_t retry_sampling);

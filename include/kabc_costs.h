@@ -107,23 +107,61 @@ KABC_HD int kabc_cost_aux_words(int id) { return id == KABC_COST_NORMAL_MEANSTD_
 
 /* params = (n, mean(tdata), std(tdata)); x = (mu, sigma).  The n draws are
  * mu + sigma z_j, so mean = mu + sigma mean(z), std = |sigma| std(z).
- * prepare: aux = (sum z_j, sum z_j^2) over the n standard normals of the stream */
-KABC_HD void kabc_cost_normal_meanstd_prepare(const double* params, kabc_cost_rng_t* rng,
-                                              double* aux) {
-    int n = (int)params[0];
+ * prepare: aux = (sum z_j, sum z_j^2) over the n standard normals of the stream.
+ *
+ * SUMMATION ORDER (part of the contract: it fixes the bits).  The n draws are independent, so
+ * the sums are defined the way 64 lanes of a wavefront form them together:
+ *   - the ceil(n/2) normal pairs (one Philox block each, slot = pair index) are cut into
+ *     KABC_SIM_LANES = 64 contiguous slices of c = ceil(pairs / 64) pairs; slice l adds its
+ *     draws to its own partial sums in stream order (z0 then z1 of every pair);
+ *   - the 64 partials are combined by the pairwise tree
+ *         a[l] += a[l + off]   for l = 0, 2 off, 4 off, ...;   off = 1, 2, 4, 8, 16, 32
+ *     which is what lane 0 of an xor-butterfly over the wavefront computes (IEEE addition is
+ *     commutative, so both partners of a butterfly step hold the same bits).
+ * One thread evaluating the whole cost (init kernels, smc, the CPU oracle) runs the slices one
+ * after the other through kabc_cost_normal_meanstd_prepare below; the AIS path runs them on 64
+ * lanes (csrc/ais_aux_kernels.hpp) -- same operations, same order, same bits.  The README's
+ * AIS(10) ensemble (README.md:31-57) is what this is for: five walkers per half-generation used
+ * to mean five busy lanes running 500 pairs each, one after the other. */
+#define KABC_SIM_LANES 64
+KABC_HD int kabc_sim_pairs(int n) { return (n + 1) / 2; }
+KABC_HD int kabc_sim_slice(int n) { return (kabc_sim_pairs(n) + KABC_SIM_LANES - 1) / KABC_SIM_LANES; }
+/* slice l of the draws: partial (sum z, sum z^2); rng->slot must be the stream's base slot */
+KABC_HD void kabc_cost_normal_meanstd_slice(int n, int l, kabc_cost_rng_t* rng, double* psz,
+                                            double* pszz) {
+    const int pairs = kabc_sim_pairs(n), c = kabc_sim_slice(n);
+    const uint32_t base = rng->slot;
+    int hi = (l + 1) * c;
+    if (hi > pairs) hi = pairs;
     double sz = 0.0, szz = 0.0;
-    for (int j = 0; j < n; j += 2) {
+    for (int p = l * c; p < hi; ++p) {
         double z0, z1;
+        rng->slot = base + (uint32_t)p;
         kabc_cost_rng_normal2(rng, &z0, &z1);
         sz += z0;
         szz += z0 * z0;
-        if (j + 1 < n) {
+        if (2 * p + 1 < n) {
             sz += z1;
             szz += z1 * z1;
         }
     }
-    aux[0] = sz;
-    aux[1] = szz;
+    rng->slot = base;
+    *psz = sz;
+    *pszz = szz;
+}
+KABC_HD void kabc_cost_normal_meanstd_prepare(const double* params, kabc_cost_rng_t* rng,
+                                              double* aux) {
+    int n = (int)params[0];
+    double a[KABC_SIM_LANES], b[KABC_SIM_LANES];
+    for (int l = 0; l < KABC_SIM_LANES; ++l) kabc_cost_normal_meanstd_slice(n, l, rng, &a[l], &b[l]);
+    for (int off = 1; off < KABC_SIM_LANES; off <<= 1)
+        for (int l = 0; l < KABC_SIM_LANES; l += 2 * off) {
+            a[l] = a[l] + a[l + off];
+            b[l] = b[l] + b[l + off];
+        }
+    rng->slot += (uint32_t)kabc_sim_pairs(n);
+    aux[0] = a[0];
+    aux[1] = b[0];
 }
 KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* params,
                                             kabc_cost_rng_t* rng) {

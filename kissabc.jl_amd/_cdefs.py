@@ -9,6 +9,7 @@ KABC_MAX_DIM = 16
 KABC_MAX_DIM_DYN = 256   # AIS only: run-time-dimension kernels beyond KABC_MAX_DIM
 KABC_VERSION = 200   # include/kabc.h
 KABC_COMM_ID_BYTES = 128
+KABC_MAX_EXCHANGE_CHUNKS = 16
 KABC_COMM_MAX_WORLD = 16
 COMM_RCCL, COMM_P2P = 1, 2
 
@@ -129,6 +130,8 @@ PROTOTYPES = {
     "kabc_ais_set_state": (C.c_int, [VP, c_double_p, c_double_p, c_double_p, C.c_uint64]),
     "kabc_ais_get_stats": (C.c_int, [VP, C.POINTER(Stats)]),
     "kabc_ais_owned": (C.c_int64, [VP, C.c_int32]),
+    "kabc_ais_owned_segments": (C.c_int32, [VP, C.c_int32, C.POINTER(C.c_int64),
+                                            C.POINTER(C.c_int64), C.c_int32]),
     "kabc_ais_set_timing": (C.c_int, [VP, C.c_int32]),
     "kabc_ais_set_timing_stride": (C.c_int, [VP, C.c_int32]),
     "kabc_ais_kernel_ms": (C.c_double, [VP, C.POINTER(C.c_int64)]),

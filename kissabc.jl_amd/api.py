@@ -216,6 +216,15 @@ class AisEnsemble:
             self._h, x.ctypes.data_as(cd.c_double_p), lp.ctypes.data_as(cd.c_double_p),
             ll.ctypes.data_as(cd.c_double_p), int(t)))
 
+    def segments(self, half):
+        """[(first global row of the half, rows), ...]: the owned row ranges of `half` in the
+        order state() / get_debug() lay the owned rows out (kabc_ais_owned_segments; one range
+        unless the handle is sharded with more than one exchange chunk)."""
+        cap = cd.KABC_MAX_EXCHANGE_CHUNKS
+        first, count = (C.c_int64 * cap)(), (C.c_int64 * cap)()
+        n = _lib.load().kabc_ais_owned_segments(self._h, int(half), first, count, cap)
+        return [(first[i], count[i]) for i in range(n)]
+
     def stats(self):
         st = cd.Stats()
         _lib.check(_lib.load().kabc_ais_get_stats(self._h, C.byref(st)))

@@ -222,13 +222,14 @@ class EnsembleGroup:
         lib = _lib.load()
         for s in self.shards:
             xs, lps, lls, _ = s.state()
-            o0, o1 = s.owned
-            per0 = -(-n0 // len(self.shards))
-            per1 = -(-(self.N - n0) // len(self.shards))
-            r = s.comm.rank
-            a0, a1 = min(r * per0, n0), n0 + min(r * per1, self.N - n0)
-            x[a0:a0 + o0], lp[a0:a0 + o0], ll[a0:a0 + o0] = xs[:o0], lps[:o0], lls[:o0]
-            x[a1:a1 + o1], lp[a1:a1 + o1], ll[a1:a1 + o1] = xs[o0:], lps[o0:], lls[o0:]
+            src = 0
+            for half, base in ((0, 0), (1, n0)):
+                for first, count in s.segments(half):
+                    dst = base + first
+                    x[dst:dst + count] = xs[src:src + count]
+                    lp[dst:dst + count] = lps[src:src + count]
+                    ll[dst:dst + count] = lls[src:src + count]
+                    src += count
         return x, lp, ll
 
     def stats(self):

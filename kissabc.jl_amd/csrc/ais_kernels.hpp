@@ -45,6 +45,12 @@ struct AisArgs {
     // is bit-identical to a single-chain run with its seed.  seeds == NULL: one chain.
     const uint64_t* seeds;
     int64_t stride_act, stride_comp, stride_own, stride_trace;
+    // prepared cost words of every (sub-step, owned row) of this launch, computed by the grid-wide
+    // pre-pass (ais_aux_kernels.hpp): [chain][nt][W][rows_owned]; NULL = the producers compute them
+    const double* aux;
+    int64_t stride_aux;
+    // debug records of a launch that covers sub-steps [dbg_s0, dbg_s0 + nt) of dbg_nt
+    int32_t dbg_nt, dbg_s0;
 };
 
 constexpr int kLateFrom = 10;  // D above this: the consumer keeps ONE set of partner-row registers
@@ -471,7 +477,15 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t
 template <int COST, int W>
 __device__ __forceinline__ void prepare_cost_aux(const AisArgs& A, uint64_t t, uint32_t w_base,
                                                  int lane, double (*aux)[kBatch],
-                                                 const double* logtab) {
+                                                 const double* logtab, int64_t r0, int n_active) {
+    if (A.aux) {  // wave-uniform: the pre-pass has them, lane = walker copies W words
+        if (lane < n_active) {
+            const int64_t s = (int64_t)(t - A.t0);
+#pragma unroll
+            for (int j = 0; j < W; ++j) aux[j][lane] = A.aux[(s * W + j) * A.rows_owned + r0 + lane];
+        }
+        return;
+    }
     kabc_cost_rng_t rng = {A.seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u, 0u, nullptr,
                            logtab};
     double a[W];
@@ -495,6 +509,7 @@ ais_half_kernel(const AisArgs A0) {
         A.lp += c * A0.stride_own;
         A.ll += c * A0.stride_own;
         if (A0.trace) A.trace += c * A0.stride_trace;
+        if (A0.aux) A.aux += c * A0.stride_aux;
     }
     __shared__ ChunkRec<D> rec[2];
     __shared__ uint8_t listB[kChunk][kBatch];
@@ -607,7 +622,7 @@ ais_half_kernel(const AisArgs A0) {
                                lane, slogtab, pro01);
             if constexpr (kAuxW > 0)
                 prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)si, w_base, lane, saux[0][si],
-                                              slogtab);
+                                              slogtab, r0, n_active);
         }
     }
     KABC_TIMED_BARRIER();
@@ -629,7 +644,7 @@ ais_half_kernel(const AisArgs A0) {
                                    listB[si], lane, slogtab);
                 if constexpr (kAuxW > 0)
                     prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)s, w_base, lane,
-                                                  saux[(c + 1) & 1][si], slogtab);
+                                                  saux[(c + 1) & 1][si], slogtab, r0, n_active);
             }
             KABC_TIMED_BARRIER();
         }
@@ -766,7 +781,7 @@ ais_half_kernel(const AisArgs A0) {
 #pragma unroll
                     for (int k = 0; k < D; ++k) asm volatile("" : "+v"(x[k]));
                     if (A.dbg) {
-                        int32_t* d = A.dbg + (r * A.nt + (s0 + si)) * 6;
+                        int32_t* d = A.dbg + (r * A.dbg_nt + (A.dbg_s0 + s0 + si)) * 6;
                         d[0] = (int32_t)move;
                         d[1] = acc ? 1 : 0;
                         d[2] = (int32_t)(mva & 0x3fffffffu);

@@ -8,6 +8,7 @@
 #include <thread>
 #include <vector>
 
+#include "ais_aux_kernels.hpp"
 #include "ais_dyn_kernels.hpp"
 #include "host_common.hpp"
 #include "plugin_registry.hpp"
@@ -90,9 +91,17 @@ struct kabc_ais {
     int64_t cost_ndata;
     int64_t N;             // total walkers (all ranks)
     int64_t rows[2];       // global rows per half
-    int64_t row_first[2];  // first owned row per half
-    int64_t rows_owned[2];
-    int64_t per[2];        // rows per rank segment of each half (all-gather count / D)
+    int64_t rows_owned[2]; // owned rows per half (all segments)
+    // Ownership is block-cyclic over `xk` EXCHANGE CHUNKS: chunk k of a half is the row range
+    // [k * world * cper, (k + 1) * world * cper), split into `world` rank segments of cper rows
+    // -- so that the all-gather of chunk k is in place and contiguous (count = cper * D) and
+    // can run while the kernels of chunk k + 1 compute.  xk = 1 is the plain contiguous
+    // split.  Draws are keyed by the global walker id, never by the owner: results do not
+    // depend on xk or world.
+    struct Seg { int64_t first, count, off; };  // global first row, rows, offset in lp / ll
+    std::vector<Seg> seg[2];
+    int32_t xk;
+    int64_t cper[2];       // rows per rank and chunk (all-gather count / D)
     kabc_comm_t* comm;     // library-owned exchange (kabc_ais_create_dist), else NULL
     // length(prior) > KABC_MAX_DIM: run-time-dimension kernels (ais_dyn_kernels.hpp)
     AisDynLaunchFn dyn;
@@ -122,6 +131,9 @@ struct kabc_ais {
     int64_t trace_cap_gens;
     hipStream_t copy_stream;
     hipEvent_t ev_filled[kTraceBufs];
+    // prepared-cost words of the launch in flight (ais_aux_kernels.hpp)
+    double* d_aux;
+    size_t aux_cap;  // bytes
     // debug records (tests)
     int32_t* d_dbg;
     int64_t dbg_cap;  // in int32 units
@@ -162,7 +174,7 @@ static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0,
     for (int hf = 0; hf < 2; ++hf) {
         if (h->own_halves) {
             // padded to world equal segments so that the in-place all-gather has one count
-            const size_t nb = sizeof(double) * (size_t)(h->per[hf] * world) * h->D * nch;
+            const size_t nb = sizeof(double) * (size_t)(h->cper[hf] * h->xk * world) * h->D * nch;
             KABC_HIP_CHECK(hipMalloc(&h->d_half[hf], nb));
             KABC_HIP_CHECK(hipMemsetAsync(h->d_half[hf], 0, nb, s));
         } else {
@@ -313,16 +325,31 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->nchains = nchains;
     h->d_seeds = nullptr;
     h->d_chain_retries = nullptr;
+    // exchange chunks: KABC_EXCHANGE_CHUNKS, else one chunk per residency wave of the half-
+    // generation kernel (512 workgroups of 64 walkers fill the 256 CUs; a launch below that
+    // takes as long as a full one -- tools/occupancy_probe.py -- so finer chunks would only
+    // serialise the compute they are meant to overlap)
+    h->xk = 1;
+    if (comm) {
+        const int64_t per_rank = (h->rows[0] + world - 1) / world;
+        int64_t k = world > 1 ? per_rank / (512 * (int64_t)kBatch) : 1;
+        if (const char* e = std::getenv("KABC_EXCHANGE_CHUNKS")) k = std::atol(e);
+        h->xk = (int32_t)(k < 1 ? 1 : (k > KABC_MAX_EXCHANGE_CHUNKS ? KABC_MAX_EXCHANGE_CHUNKS : k));
+    }
     for (int hf = 0; hf < 2; ++hf) {
         // caller-lent buffers: equal shards (n_total % (2 world) == 0 was checked); library-
-        // owned exchange: ceil shards, the last ranks may own fewer rows or none
-        const int64_t per = comm ? (h->rows[hf] + world - 1) / world : h->rows[hf] / world;
-        int64_t lo = per * rank, hi = per * (rank + 1);
-        lo = lo < h->rows[hf] ? lo : h->rows[hf];
-        hi = hi < h->rows[hf] ? hi : h->rows[hf];
-        h->per[hf] = per;
-        h->row_first[hf] = lo;
-        h->rows_owned[hf] = hi - lo;
+        // owned exchange: ceil shards, the last segments may hold fewer rows or none
+        const int64_t parts = (int64_t)world * h->xk;
+        const int64_t cper = comm ? (h->rows[hf] + parts - 1) / parts : h->rows[hf] / world;
+        h->cper[hf] = cper;
+        h->rows_owned[hf] = 0;
+        for (int k = 0; k < h->xk; ++k) {
+            int64_t lo = cper * ((int64_t)k * world + rank), hi = lo + cper;
+            lo = lo < h->rows[hf] ? lo : h->rows[hf];
+            hi = hi < h->rows[hf] ? hi : h->rows[hf];
+            h->seg[hf].push_back({lo, hi - lo, h->rows_owned[hf]});
+            h->rows_owned[hf] += hi - lo;
+        }
     }
     h->seed = seed;
     h->t = 0;
@@ -335,6 +362,8 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     }
     h->d_dbg = nullptr;
     h->dbg_cap = 0;
+    h->d_aux = nullptr;
+    h->aux_cap = 0;
     h->timing = false;
     h->timing_stride = 1;
     h->launch_index = 0;
@@ -420,21 +449,26 @@ kabc_status_t kabc_ais_create_dist(kabc_comm_t* comm, const kabc_model_t* model,
                              nullptr, comm, out);
 }
 
-static AisDynArgs dyn_args(kabc_ais_t* h, int half) {
+// exchange chunk k of a half: [world][cper][D] doubles, this rank's segment at rank * cper
+static double* chunk_base(kabc_ais_t* h, int half, int k) {
+    return h->d_half[half] + (size_t)k * h->world * h->cper[half] * h->D;
+}
+
+static AisDynArgs dyn_args(kabc_ais_t* h, int half, const kabc_ais::Seg& sg) {
     AisDynArgs a;
     std::memset(&a, 0, sizeof a);
     a.x_act = h->d_half[half];
     a.x_comp = h->d_half[1 - half];
-    a.lp = h->d_lp[half];
-    a.ll = h->d_ll[half];
-    a.scratch = h->d_scratch;
+    a.lp = h->d_lp[half] + sg.off;
+    a.ll = h->d_ll[half] + sg.off;
+    a.scratch = h->d_scratch + sg.off * 2 * h->D;
     a.counters = h->d_counters;
     a.slots = h->d_slots;
     a.cost_params = h->d_cost_params;
     a.cost_data = h->d_cost_data;
     a.cost_ndata = h->cost_ndata;
-    a.row_first = h->row_first[half];
-    a.rows_owned = h->rows_owned[half];
+    a.row_first = sg.first;
+    a.rows_owned = sg.count;
     a.n_comp = h->rows[1 - half];
     a.seed = h->seed;
     a.id_base = h->id_base[half];
@@ -461,41 +495,45 @@ static kabc_status_t ais_init_enqueue(kabc_ais_t* h, int32_t retry_sampling) {
     KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
     if (h->d_chain_retries)
         KABC_HIP_CHECK(hipMemsetAsync(h->d_chain_retries, 0, sizeof(unsigned long long) * h->nchains, s));
-    for (int hf = 0; hf < 2 && h->dyn; ++hf) {
-        AisDynArgs a = dyn_args(h, hf);
-        a.retry_budget = (unsigned long long)retry_sampling *
-                         (unsigned long long)(h->rows_owned[0] + h->rows_owned[1]);
-        h->dyn(a, s, 1);
-        KABC_HIP_CHECK(hipGetLastError());
-    }
-    for (int hf = 0; hf < 2 && !h->dyn; ++hf) {
-        InitArgs a;
-        std::memset(&a, 0, sizeof a);
-        a.x_act = h->d_half[hf];
-        a.lp = h->d_lp[hf];
-        a.ll = h->d_ll[hf];
-        a.counters = h->d_counters;
-        a.cost_params = h->d_cost_params;
-        a.cost_data = h->d_cost_data;
-        a.cost_ndata = h->cost_ndata;
-        a.row_first = h->row_first[hf];
-        a.rows_owned = h->rows_owned[hf];
-        a.seed = h->seed;
-        a.id_base = h->id_base[hf];
-        a.posterior = h->posterior;
-        a.cost_id = h->cost_id;
-        a.eps = h->eps;
-        // the budget is per ensemble (src/KissABC.jl:52); a shard gets its share
-        a.retry_budget = (unsigned long long)retry_sampling *
-                         (unsigned long long)(h->rows_owned[0] + h->rows_owned[1]);
-        a.prior = h->prior;
-        std::memcpy(a.raw, h->raw, sizeof a.raw);
-        a.seeds = h->d_seeds;
-        a.chain_retries = h->d_chain_retries;
-        a.stride_act = h->rows[hf] * h->D;
-        a.stride_own = h->rows_owned[hf];
-        launch_ais_init(h->D, a, s, (unsigned)h->nchains);
-        KABC_HIP_CHECK(hipGetLastError());
+    // the budget is per ensemble (src/KissABC.jl:52); a shard gets its share
+    const unsigned long long budget = (unsigned long long)retry_sampling *
+                                      (unsigned long long)(h->rows_owned[0] + h->rows_owned[1]);
+    for (int hf = 0; hf < 2; ++hf) {
+        for (const kabc_ais::Seg& sg : h->seg[hf]) {
+            if (sg.count == 0) continue;
+            if (h->dyn) {
+                AisDynArgs a = dyn_args(h, hf, sg);
+                a.retry_budget = budget;
+                h->dyn(a, s, 1);
+                KABC_HIP_CHECK(hipGetLastError());
+                continue;
+            }
+            InitArgs a;
+            std::memset(&a, 0, sizeof a);
+            a.x_act = h->d_half[hf];
+            a.lp = h->d_lp[hf] + sg.off;
+            a.ll = h->d_ll[hf] + sg.off;
+            a.counters = h->d_counters;
+            a.cost_params = h->d_cost_params;
+            a.cost_data = h->d_cost_data;
+            a.cost_ndata = h->cost_ndata;
+            a.row_first = sg.first;
+            a.rows_owned = sg.count;
+            a.seed = h->seed;
+            a.id_base = h->id_base[hf];
+            a.posterior = h->posterior;
+            a.cost_id = h->cost_id;
+            a.eps = h->eps;
+            a.retry_budget = budget;
+            a.prior = h->prior;
+            std::memcpy(a.raw, h->raw, sizeof a.raw);
+            a.seeds = h->d_seeds;
+            a.chain_retries = h->d_chain_retries;
+            a.stride_act = h->rows[hf] * h->D;
+            a.stride_own = h->rows_owned[hf];
+            launch_ais_init(h->D, a, s, (unsigned)h->nchains);
+            KABC_HIP_CHECK(hipGetLastError());
+        }
     }
     return KABC_OK;
 }
@@ -526,9 +564,10 @@ kabc_status_t kabc_ais_init(kabc_ais_t* h, int32_t retry_sampling) {
         // every rank takes part in the exchange whatever its own outcome, and every rank
         // reports the failure of any (the reference's retry budget is per ensemble)
         for (int hf = 0; hf < 2; ++hf)
-            if (kabc_status_t st = comm_allgather_inplace(h->comm, h->d_half[hf],
-                                                          (size_t)h->per[hf] * h->D))
-                return st;
+            for (int k = 0; k < h->xk; ++k)
+                if (kabc_status_t st = comm_allgather_inplace(h->comm, chunk_base(h, hf, k),
+                                                              (size_t)h->cper[hf] * h->D))
+                    return st;
         if (kabc_status_t st = kabc_comm_allreduce_sum_u64(h->comm, &failed, 1)) return st;
     }
     if (failed) return ais_init_failed();
@@ -546,7 +585,7 @@ static kabc_status_t check_group(kabc_ais_t** hs, int32_t n, const char* who) {
         kabc_ais_t* h = hs[i];
         if (!h || !h->comm || !h->comm->single_process || h->comm->world != n ||
             h->comm->backend != hs[0]->comm->backend || h->comm->grp != hs[0]->comm->grp ||
-            h->N != hs[0]->N || h->D != hs[0]->D || h->seed != hs[0]->seed) {
+            h->N != hs[0]->N || h->D != hs[0]->D || h->seed != hs[0]->seed || h->xk != hs[0]->xk) {
             set_error("%s: the handles must be the %d shards of one ensemble, created with "
                       "kabc_ais_create_dist on the communicators of one kabc_comm_init_all call",
                       who, n);
@@ -561,14 +600,15 @@ static kabc_status_t check_group(kabc_ais_t** hs, int32_t n, const char* who) {
     return KABC_OK;
 }
 
-static kabc_status_t gather_multi(kabc_ais_t** hs, int32_t n, int half) {
+// all-gather of exchange chunk k of a half on the context streams (no pipelining)
+static kabc_status_t gather_multi(kabc_ais_t** hs, int32_t n, int half, int k) {
     kabc_comm_t* comms[KABC_COMM_MAX_WORLD];
     double* bases[KABC_COMM_MAX_WORLD];
     for (int i = 0; i < n; ++i) {
         comms[i] = hs[i]->comm;
-        bases[i] = hs[i]->d_half[half];
+        bases[i] = chunk_base(hs[i], half, k);
     }
-    return comm_allgather_inplace_multi(comms, bases, n, (size_t)hs[0]->per[half] * hs[0]->D);
+    return comm_allgather_inplace_multi(comms, bases, n, (size_t)hs[0]->cper[half] * hs[0]->D);
 }
 
 kabc_status_t kabc_ais_init_multi(kabc_ais_t** hs, int32_t n, int32_t retry_sampling) {
@@ -576,7 +616,8 @@ kabc_status_t kabc_ais_init_multi(kabc_ais_t** hs, int32_t n, int32_t retry_samp
     for (int i = 0; i < n; ++i)
         if (kabc_status_t st = ais_init_enqueue(hs[i], retry_sampling)) return st;
     for (int hf = 0; hf < 2; ++hf)
-        if (kabc_status_t st = gather_multi(hs, n, hf)) return st;
+        for (int k = 0; k < hs[0]->xk; ++k)
+            if (kabc_status_t st = gather_multi(hs, n, hf, k)) return st;
     bool failed = false;
     for (int i = 0; i < n; ++i) {
         KABC_HIP_CHECK(hipSetDevice(hs[i]->ctx->device));
@@ -586,6 +627,134 @@ kabc_status_t kabc_ais_init_multi(kabc_ais_t** hs, int32_t n, int32_t retry_samp
     }
     if (failed) return ais_init_failed();
     for (int i = 0; i < n; ++i) ais_mark_initialised(hs[i]);
+    return KABC_OK;
+}
+
+// one launch: `ntransitions` transitions for the owned rows of segment `sg` of `half`
+static kabc_status_t launch_half_seg(kabc_ais_t* h, int32_t half, const kabc_ais::Seg& sg,
+                                     int32_t ntransitions, double* dev_trace_rows) {
+    if (sg.count == 0) return KABC_OK;
+    hipStream_t s = h->ctx->stream;
+    // debug records: layout [N_owned][nt][6] in the order of the owned rows (half 0 first)
+    int32_t* dbg = nullptr;
+    if (h->d_dbg) {
+        const int64_t off = ((half == 0 ? 0 : h->rows_owned[0]) + sg.off) * (int64_t)ntransitions * 6;
+        if (off + sg.count * (int64_t)ntransitions * 6 <= h->dbg_cap) dbg = h->d_dbg + off;
+    }
+    // timing: one hipEvent pair brackets `timing_stride` consecutive launches (the
+    // marker packets cost ~3 us per pair; amortised over the group they stop
+    // inflating the per-kernel figure)
+    const int64_t li = h->launch_index++;
+    const bool t_on = h->timing && (h->ev_used + 2 <= h->ev.size());
+    if (t_on && li % h->timing_stride == 0) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
+    if (h->dyn) {
+        AisDynArgs a = dyn_args(h, half, sg);
+        a.trace = dev_trace_rows ? dev_trace_rows + sg.off * h->D : nullptr;
+        a.dbg = dbg;
+        a.t0 = h->t;
+        a.nt = ntransitions;
+        h->dyn(a, s, 0);
+    } else {
+        AisArgs a;
+        std::memset(&a, 0, sizeof a);
+        a.x_act = h->d_half[half];
+        a.x_comp = h->d_half[1 - half];
+        a.lp = h->d_lp[half] + sg.off;
+        a.ll = h->d_ll[half] + sg.off;
+        a.dbg = dbg;
+        a.dbg_nt = ntransitions;
+        a.counters = h->d_counters;
+        a.slots = h->d_slots;
+        a.cost_params = h->d_cost_params;
+        a.cost_data = h->d_cost_data;
+        a.cost_ndata = h->cost_ndata;
+        a.row_first = sg.first;
+        a.rows_owned = sg.count;
+        a.n_comp = h->rows[1 - half];
+        a.seed = h->seed;
+        a.id_base = h->id_base[half];
+        a.posterior = h->posterior;
+        a.eps = h->eps;
+        a.reps = (h->posterior == KABC_POSTERIOR_COMMON) ? 1.0 : 1.0 / h->eps;
+        a.box_lp = h->box_lp;
+        a.prior = h->d_prior;
+        a.seeds = h->d_seeds;
+        a.stride_act = h->rows[half] * h->D;
+        a.stride_comp = h->rows[1 - half] * h->D;
+        a.stride_own = h->rows_owned[half];
+        a.stride_trace = h->N * h->D;
+        {
+            static const int ab = [] {
+                const char* e = getenv("KABC_ABLATE");
+                const int v = e ? atoi(e) : 0;
+#ifndef KABC_PROBES
+                if (v) fprintf(stderr, "[kabc] KABC_ABLATE=%d ignored: the timing probes are compiled "
+                                       "only into libkabc_hip_probes.so (make PROBES=1, KABC_PROBES=1)\n", v);
+#endif
+                return v;
+            }();
+            a.ablate = ab;
+        }
+        // A prepared built-in cost: its parameter-independent words for every (sub-step, row) of
+        // the launch come from a grid-wide pre-pass, one wavefront per cost evaluation
+        // (ais_aux_kernels.hpp).  The buffer is bounded: beyond it the launch is cut into blocks
+        // of sub-steps -- the state lives in memory between launches, so the result is the same.
+        const int W = aux_prepass_words(h->cost_id);
+        int32_t blk = ntransitions;
+        if (W) {
+            const size_t per_step = sizeof(double) * (size_t)W * (size_t)sg.count * (size_t)h->nchains;
+            size_t cap = (size_t)256 << 20;
+            if (const char* e = std::getenv("KABC_AUX_KIB")) {  // tests: force the block path
+                const long kib = std::atol(e);
+                if (kib > 0) cap = (size_t)kib << 10;
+            }
+            const size_t fit = cap / per_step;
+            blk = (int32_t)(fit < 1 ? 1 : (fit > (size_t)ntransitions ? (size_t)ntransitions : fit));
+            if (per_step * (size_t)blk > h->aux_cap) {
+                if (h->d_aux) {
+                    KABC_HIP_CHECK(hipStreamSynchronize(s));
+                    KABC_HIP_CHECK(hipFree(h->d_aux));
+                    h->d_aux = nullptr;
+                    h->aux_cap = 0;
+                }
+                KABC_HIP_CHECK(hipMalloc(&h->d_aux, per_step * (size_t)blk));
+                h->aux_cap = per_step * (size_t)blk;
+            }
+        }
+        for (int32_t s0 = 0; s0 < ntransitions; s0 += blk) {
+            const int32_t nb = ntransitions - s0 < blk ? ntransitions - s0 : blk;
+            a.t0 = h->t + (uint64_t)s0;
+            a.nt = nb;
+            a.dbg_s0 = s0;
+            // push_p(x) after the LAST transition is the sample step() returns (src/KissABC.jl:78)
+            a.trace = (dev_trace_rows && s0 + nb == ntransitions) ? dev_trace_rows + sg.off * h->D : nullptr;
+            if (W) {
+                AuxArgs x;
+                std::memset(&x, 0, sizeof x);
+                x.aux = h->d_aux;
+                x.cost_params = h->d_cost_params;
+                x.cost_data = h->d_cost_data;
+                x.cost_ndata = h->cost_ndata;
+                x.row_first = sg.first;
+                x.rows = sg.count;
+                x.seed = h->seed;
+                x.t0 = a.t0;
+                x.id_base = h->id_base[half];
+                x.nt = nb;
+                x.seeds = h->d_seeds;
+                x.stride_aux = (int64_t)nb * W * sg.count;
+                launch_aux_prepass(h->cost_id, x, s, (unsigned)h->nchains);
+                a.aux = h->d_aux;
+                a.stride_aux = x.stride_aux;
+            }
+            h->launch(a, s, (unsigned)h->nchains);
+        }
+    }
+    if (t_on && li % h->timing_stride == h->timing_stride - 1) {
+        KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], s));
+        h->ev_used += 2;
+    }
+    KABC_HIP_CHECK(hipGetLastError());
     return KABC_OK;
 }
 
@@ -600,88 +769,9 @@ kabc_status_t kabc_ais_half_generation(kabc_ais_t* h, int32_t half, int32_t ntra
         set_error("half must be 0/1 and ntransitions >= 1");
         return KABC_ERR_INVALID_ARG;
     }
-    if (h->dyn) {
-        AisDynArgs a = dyn_args(h, half);
-        a.trace = (double*)dev_trace_rows;
-        if (h->d_dbg) {
-            const int64_t off = (half == 0 ? 0 : h->rows_owned[0]) * (int64_t)ntransitions * 6;
-            if (off + h->rows_owned[half] * (int64_t)ntransitions * 6 <= h->dbg_cap) a.dbg = h->d_dbg + off;
-        }
-        a.t0 = h->t;
-        a.nt = ntransitions;
-        const int64_t li = h->launch_index++;
-        const bool t_on = h->timing && (h->ev_used + 2 <= h->ev.size());
-        if (t_on && li % h->timing_stride == 0)
-            KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], h->ctx->stream));
-        h->dyn(a, h->ctx->stream, 0);
-        if (t_on && li % h->timing_stride == h->timing_stride - 1) {
-            KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], h->ctx->stream));
-            h->ev_used += 2;
-        }
-        KABC_HIP_CHECK(hipGetLastError());
-        return KABC_OK;
-    }
-    AisArgs a;
-    std::memset(&a, 0, sizeof a);
-    a.x_act = h->d_half[half];
-    a.x_comp = h->d_half[1 - half];
-    a.lp = h->d_lp[half];
-    a.ll = h->d_ll[half];
-    a.trace = (double*)dev_trace_rows;
-    a.dbg = nullptr;
-    if (h->d_dbg) {
-        // layout [N][nt][6] in walker-id order of the owned rows (half 0 first)
-        const int64_t off = (half == 0 ? 0 : h->rows_owned[0]) * (int64_t)ntransitions * 6;
-        if (off + h->rows_owned[half] * (int64_t)ntransitions * 6 <= h->dbg_cap)
-            a.dbg = h->d_dbg + off;
-    }
-    a.counters = h->d_counters;
-    a.slots = h->d_slots;
-    a.cost_params = h->d_cost_params;
-    a.cost_data = h->d_cost_data;
-    a.cost_ndata = h->cost_ndata;
-    a.row_first = h->row_first[half];
-    a.rows_owned = h->rows_owned[half];
-    a.n_comp = h->rows[1 - half];
-    a.seed = h->seed;
-    a.t0 = h->t;
-    a.id_base = h->id_base[half];
-    a.nt = ntransitions;
-    a.posterior = h->posterior;
-    a.eps = h->eps;
-    a.reps = (h->posterior == KABC_POSTERIOR_COMMON) ? 1.0 : 1.0 / h->eps;
-    a.box_lp = h->box_lp;
-    a.prior = h->d_prior;
-    a.seeds = h->d_seeds;
-    a.stride_act = h->rows[half] * h->D;
-    a.stride_comp = h->rows[1 - half] * h->D;
-    a.stride_own = h->rows_owned[half];
-    a.stride_trace = h->N * h->D;
-    {
-        static const int ab = [] {
-            const char* e = getenv("KABC_ABLATE");
-            const int v = e ? atoi(e) : 0;
-#ifndef KABC_PROBES
-            if (v) fprintf(stderr, "[kabc] KABC_ABLATE=%d ignored: the timing probes are compiled "
-                                   "only into libkabc_hip_probes.so (make PROBES=1, KABC_PROBES=1)\n", v);
-#endif
-            return v;
-        }();
-        a.ablate = ab;
-    }
-    hipStream_t s = h->ctx->stream;
-    // timing: one hipEvent pair brackets `timing_stride` consecutive launches (the
-    // marker packets cost ~3 us per pair; amortised over the group they stop
-    // inflating the per-kernel figure)
-    const int64_t li = h->launch_index++;
-    const bool t_on = h->timing && (h->ev_used + 2 <= h->ev.size());
-    if (t_on && li % h->timing_stride == 0) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
-    h->launch(a, s, (unsigned)h->nchains);
-    if (t_on && li % h->timing_stride == h->timing_stride - 1) {
-        KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], s));
-        h->ev_used += 2;
-    }
-    KABC_HIP_CHECK(hipGetLastError());
+    for (const kabc_ais::Seg& sg : h->seg[half])
+        if (kabc_status_t st = launch_half_seg(h, half, sg, ntransitions, (double*)dev_trace_rows))
+            return st;
     return KABC_OK;
 }
 
@@ -720,16 +810,54 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
     hipStream_t s = h->ctx->stream;
     const int64_t gen_elems = h->N * h->D * h->nchains;  // [chain][N][D] per generation
     const size_t gen_bytes = sizeof(double) * (size_t)gen_elems;
+    // A rank-local failure (a launch that did not go out) must not leave the other ranks
+    // blocked in a collective this rank never joins: the kernels stop, the exchanges of the
+    // remaining half-generations are still issued, and the ranks agree on the outcome below.
+    kabc_status_t local_err = KABC_OK;
+    char local_msg[512] = "";
+    auto keep = [&](kabc_status_t st) {
+        if (st != KABC_OK && local_err == KABC_OK) {
+            local_err = st;
+            std::snprintf(local_msg, sizeof local_msg, "%s", get_error());
+        }
+    };
     if (!out_samples || ngenerations == 0) {
         for (int64_t g = 0; g < ngenerations; ++g) {
             for (int hf = 0; hf < 2; ++hf) {
-                kabc_status_t st = kabc_ais_half_generation(h, hf, ntransitions, nullptr);
-                // the one collective of the design: rebuild half hf on every rank
-                if (st == KABC_OK && h->comm)
-                    st = comm_allgather_inplace(h->comm, h->d_half[hf], (size_t)h->per[hf] * h->D);
-                if (st) return st;
+                if (!h->comm || h->xk == 1) {
+                    if (local_err == KABC_OK) keep(kabc_ais_half_generation(h, hf, ntransitions, nullptr));
+                    // the one collective of the design: rebuild half hf on every rank
+                    if (h->comm)
+                        keep(comm_allgather_inplace(h->comm, h->d_half[hf], (size_t)h->cper[hf] * h->D));
+                } else {
+                    // pipelined: the kernels read the half gathered last (fence), then chunk k
+                    // is gathered on the exchange stream while the kernels of chunk k + 1 run
+                    keep(comm_exchange_fence(h->comm));
+                    for (int k = 0; k < h->xk; ++k) {
+                        if (local_err == KABC_OK)
+                            keep(launch_half_seg(h, hf, h->seg[hf][k], ntransitions, nullptr));
+                        keep(comm_exchange_chunk(h->comm, chunk_base(h, hf, k),
+                                                 (size_t)h->cper[hf] * h->D, k));
+                    }
+                }
+                if (local_err && !h->comm) return local_err;
             }
-            h->t += (uint64_t)ntransitions;
+            if (local_err == KABC_OK) h->t += (uint64_t)ntransitions;
+        }
+        if (h->comm && h->xk > 1) keep(comm_exchange_fence(h->comm));
+        if (h->comm) {
+            uint64_t bad = local_err != KABC_OK;
+            const kabc_status_t st = kabc_comm_allreduce_sum_u64(h->comm, &bad, 1);
+            if (local_err) {
+                set_error("%s", local_msg);
+                return local_err;
+            }
+            if (st) return st;
+            if (bad) {
+                set_error("kabc_ais_advance failed on %llu other rank(s) of the communicator",
+                          (unsigned long long)bad);
+                return KABC_ERR_DEVICE;
+            }
         }
     } else {
         // ---- sample-trace streaming ------------------------------------------------
@@ -850,17 +978,44 @@ kabc_status_t kabc_ais_advance_multi(kabc_ais_t** hs, int32_t n, int64_t ngenera
         set_error("ngenerations must be >= 0 and ntransitions >= 1");
         return KABC_ERR_INVALID_ARG;
     }
+    for (int i = 0; i < n; ++i) {
+        if (!hs[i]->initialised) {
+            set_error("kabc_ais_init_multi has not been called");
+            return KABC_ERR_INVALID_STATE;
+        }
+    }
+    const int xk = hs[0]->xk;
+    kabc_comm_t* comms[KABC_COMM_MAX_WORLD];
+    for (int i = 0; i < n; ++i) comms[i] = hs[i]->comm;
     for (int64_t g = 0; g < ngenerations; ++g) {
         for (int hf = 0; hf < 2; ++hf) {
-            for (int i = 0; i < n; ++i) {
-                KABC_HIP_CHECK(hipSetDevice(hs[i]->ctx->device));
-                if (kabc_status_t st = kabc_ais_half_generation(hs[i], hf, ntransitions, nullptr))
+            if (xk == 1) {
+                for (int i = 0; i < n; ++i) {
+                    KABC_HIP_CHECK(hipSetDevice(hs[i]->ctx->device));
+                    if (kabc_status_t st = kabc_ais_half_generation(hs[i], hf, ntransitions, nullptr))
+                        return st;
+                }
+                if (kabc_status_t st = gather_multi(hs, n, hf, 0)) return st;
+                continue;
+            }
+            if (kabc_status_t st = comm_exchange_fence_multi(comms, n, false)) return st;
+            for (int k = 0; k < xk; ++k) {
+                double* bases[KABC_COMM_MAX_WORLD];
+                for (int i = 0; i < n; ++i) {
+                    KABC_HIP_CHECK(hipSetDevice(hs[i]->ctx->device));
+                    if (kabc_status_t st = launch_half_seg(hs[i], hf, hs[i]->seg[hf][k], ntransitions, nullptr))
+                        return st;
+                    bases[i] = chunk_base(hs[i], hf, k);
+                }
+                if (kabc_status_t st = comm_exchange_chunk_multi(comms, bases, n,
+                                                                 (size_t)hs[0]->cper[hf] * hs[0]->D, k))
                     return st;
             }
-            if (kabc_status_t st = gather_multi(hs, n, hf)) return st;
         }
         for (int i = 0; i < n; ++i) hs[i]->t += (uint64_t)ntransitions;
     }
+    if (xk > 1)
+        if (kabc_status_t st = comm_exchange_fence_multi(comms, n, true)) return st;
     for (int i = 0; i < n; ++i) {
         kabc_ais_t* h = hs[i];
         KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
@@ -885,8 +1040,8 @@ kabc_status_t kabc_ais_get_ensemble(kabc_ais_t* h, double* x) {
     hipStream_t s = h->ctx->stream;
     const size_t W = sizeof(double), nch = (size_t)h->nchains;
     // device pitch per chain: the (padded, for sharded handles) half buffer
-    const size_t p0 = W * (h->comm ? h->per[0] * h->world : h->rows[0]) * h->D;
-    const size_t p1 = W * (h->comm ? h->per[1] * h->world : h->rows[1]) * h->D;
+    const size_t p0 = W * (h->comm ? h->cper[0] * h->xk * h->world : h->rows[0]) * h->D;
+    const size_t p1 = W * (h->comm ? h->cper[1] * h->xk * h->world : h->rows[1]) * h->D;
     KABC_HIP_CHECK(hipMemcpy2DAsync(x, W * h->N * h->D, h->d_half[0], p0, W * h->rows[0] * h->D, nch,
                                     hipMemcpyDeviceToHost, s));
     if (h->rows[1] > 0)
@@ -908,12 +1063,14 @@ kabc_status_t kabc_ais_get_state(kabc_ais_t* h, double* x, double* logprior, dou
     int64_t off = 0;
     for (int hf = 0; hf < 2; ++hf) {
         const int64_t n = h->rows_owned[hf];
-        if (n > 0) {
-            if (x)
-                KABC_HIP_CHECK(hipMemcpy2DAsync(x + off * h->D, W * n_own * h->D,
-                                                h->d_half[hf] + h->row_first[hf] * h->D,
-                                                W * h->rows[hf] * h->D, W * n * h->D, nch,
+        // (the pitch between chains of a batch handle; sharded handles hold one chain)
+        for (const kabc_ais::Seg& sg : h->seg[hf])
+            if (x && sg.count > 0)
+                KABC_HIP_CHECK(hipMemcpy2DAsync(x + (off + sg.off) * h->D, W * n_own * h->D,
+                                                h->d_half[hf] + sg.first * h->D,
+                                                W * h->rows[hf] * h->D, W * sg.count * h->D, nch,
                                                 hipMemcpyDeviceToHost, s));
+        if (n > 0) {
             if (logprior)
                 KABC_HIP_CHECK(hipMemcpy2DAsync(logprior + off, W * n_own, h->d_lp[hf], W * n, W * n,
                                                 nch, hipMemcpyDeviceToHost, s));
@@ -944,10 +1101,12 @@ kabc_status_t kabc_ais_set_state(kabc_ais_t* h, const double* x, const double* l
     int64_t off = 0;
     for (int hf = 0; hf < 2; ++hf) {
         const int64_t n = h->rows_owned[hf];
+        for (const kabc_ais::Seg& sg : h->seg[hf])
+            if (sg.count > 0)
+                KABC_HIP_CHECK(hipMemcpy2DAsync(h->d_half[hf] + sg.first * h->D, W * h->rows[hf] * h->D,
+                                                x + (off + sg.off) * h->D, W * n_own * h->D,
+                                                W * sg.count * h->D, nch, hipMemcpyHostToDevice, s));
         if (n > 0) {
-            KABC_HIP_CHECK(hipMemcpy2DAsync(h->d_half[hf] + h->row_first[hf] * h->D,
-                                            W * h->rows[hf] * h->D, x + off * h->D, W * n_own * h->D,
-                                            W * n * h->D, nch, hipMemcpyHostToDevice, s));
             KABC_HIP_CHECK(hipMemcpy2DAsync(h->d_lp[hf], W * n, logprior + off, W * n_own, W * n, nch,
                                             hipMemcpyHostToDevice, s));
             KABC_HIP_CHECK(hipMemcpy2DAsync(h->d_ll[hf], W * n, loglik + off, W * n_own, W * n, nch,
@@ -975,6 +1134,17 @@ kabc_status_t kabc_ais_get_stats(kabc_ais_t* h, kabc_stats_t* stats) {
 int64_t kabc_ais_owned(const kabc_ais_t* h, int32_t half) {
     if (!h || (half != 0 && half != 1)) return -1;
     return h->rows_owned[half];
+}
+
+int32_t kabc_ais_owned_segments(const kabc_ais_t* h, int32_t half, int64_t* first, int64_t* count,
+                                int32_t cap) {
+    if (!h || (half != 0 && half != 1) || cap < 0) return -1;
+    const int32_t n = (int32_t)h->seg[half].size();
+    for (int32_t i = 0; i < n && i < cap; ++i) {
+        if (first) first[i] = h->seg[half][i].first;
+        if (count) count[i] = h->seg[half][i].count;
+    }
+    return n;
 }
 
 kabc_status_t kabc_ais_set_timing_stride(kabc_ais_t* h, int32_t stride) {
@@ -1073,6 +1243,7 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h) {
     }
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->d_dbg) (void)hipFree(h->d_dbg);
+    if (h->d_aux) (void)hipFree(h->d_aux);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     delete h;
     return KABC_OK;

@@ -106,6 +106,17 @@ struct P2PGroup {
     hipEvent_t ev[KABC_COMM_MAX_WORLD] = {};  // ev[r]: rank r's rows of the gathered half are final
 };
 
+// exchange stream + events of a communicator, created at first use (on the context's device)
+static kabc_status_t exchange_setup(kabc_comm* c) {
+    if (c->xstream) return KABC_OK;
+    KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
+    KABC_HIP_CHECK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    for (int k = 0; k < KABC_MAX_EXCHANGE_CHUNKS; ++k)
+        KABC_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
+    KABC_HIP_CHECK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    return KABC_OK;
+}
+
 struct PullArgs {
     const double* src[KABC_COMM_MAX_WORLD];  // rank r's buffer base (peer-mapped)
     double* dst;                             // this rank's buffer base
@@ -132,6 +143,22 @@ __global__ void __launch_bounds__(256) p2p_pull_kernel(const PullArgs A) {
     }
 }
 
+static kabc_status_t p2p_launch_pull(kabc_comm** comms, const int* at, double** bases, int n, int d,
+                                     size_t count, hipStream_t s) {
+    unsigned gx = (unsigned)((count / 2 + 255) / 256);
+    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+    PullArgs a;
+    std::memset(&a, 0, sizeof a);
+    for (int r = 0; r < n; ++r) a.src[r] = bases[at[r]];
+    a.dst = bases[at[d]];
+    a.count = count;
+    a.self = d;
+    a.world = n;
+    hipLaunchKernelGGL(p2p_pull_kernel, dim3(gx, (unsigned)(n - 1)), dim3(256), 0, s, a);
+    KABC_HIP_CHECK(hipGetLastError());
+    return KABC_OK;
+}
+
 static kabc_status_t p2p_allgather_multi(kabc_comm** comms, double** bases, int n, size_t count) {
     P2PGroup* g = comms[0]->grp;
     // order[r] = index into comms[] of rank r
@@ -143,24 +170,12 @@ static kabc_status_t p2p_allgather_multi(kabc_comm** comms, double** bases, int 
         KABC_HIP_CHECK(hipEventRecord(g->ev[r], c->ctx->stream));
     }
     if (n == 1 || count == 0) return KABC_OK;
-    unsigned gx = (unsigned)((count / 2 + 255) / 256);
-    gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
     for (int d = 0; d < n; ++d) {
         kabc_comm* c = comms[at[d]];
         KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
-        PullArgs a;
-        std::memset(&a, 0, sizeof a);
-        for (int r = 0; r < n; ++r) {
-            a.src[r] = bases[at[r]];
+        for (int r = 0; r < n; ++r)
             if (r != d) KABC_HIP_CHECK(hipStreamWaitEvent(c->ctx->stream, g->ev[r], 0));
-        }
-        a.dst = bases[at[d]];
-        a.count = count;
-        a.self = d;
-        a.world = n;
-        hipLaunchKernelGGL(p2p_pull_kernel, dim3(gx, (unsigned)(n - 1)), dim3(256), 0,
-                           c->ctx->stream, a);
-        KABC_HIP_CHECK(hipGetLastError());
+        if (kabc_status_t st = p2p_launch_pull(comms, at, bases, n, d, count, c->ctx->stream)) return st;
     }
     return KABC_OK;
 }
@@ -195,6 +210,91 @@ kabc_status_t comm_allgather_inplace_multi(kabc_comm** comms, double** bases, in
         }
     }
     KABC_NCCL_CHECK(R, R->GroupEnd());
+    return KABC_OK;
+}
+
+// ---- pipelined exchange ---------------------------------------------------------------
+kabc_status_t comm_exchange_chunk(kabc_comm* c, double* base, size_t count, int k) {
+    if (c->single_process) {
+        set_error("this communicator belongs to a single-process group: use the *_multi entry points");
+        return KABC_ERR_INVALID_ARG;
+    }
+    Rccl* R;
+    if (kabc_status_t st = need_rccl(&R)) return st;
+    if (kabc_status_t st = exchange_setup(c)) return st;
+    KABC_HIP_CHECK(hipEventRecord(c->ev_chunk[k], c->ctx->stream));
+    KABC_HIP_CHECK(hipStreamWaitEvent(c->xstream, c->ev_chunk[k], 0));
+    if (count == 0) return KABC_OK;
+    KABC_NCCL_CHECK(R, R->AllGather(base + (size_t)c->rank * count, base, count, ncclDouble,
+                                    (ncclComm_t)c->nccl, c->xstream));
+    return KABC_OK;
+}
+
+kabc_status_t comm_exchange_fence(kabc_comm* c) {
+    if (!c->xstream) return KABC_OK;  // nothing was ever issued on the exchange stream
+    KABC_HIP_CHECK(hipEventRecord(c->ev_done, c->xstream));
+    KABC_HIP_CHECK(hipStreamWaitEvent(c->ctx->stream, c->ev_done, 0));
+    return KABC_OK;
+}
+
+kabc_status_t comm_exchange_chunk_multi(kabc_comm** comms, double** bases, int n, size_t count, int k) {
+    int at[KABC_COMM_MAX_WORLD];
+    for (int i = 0; i < n; ++i) at[comms[i]->rank] = i;
+    // "the kernels of chunk k are done" on every rank's context stream
+    for (int r = 0; r < n; ++r) {
+        kabc_comm* c = comms[at[r]];
+        if (kabc_status_t st = exchange_setup(c)) return st;
+        KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
+        KABC_HIP_CHECK(hipEventRecord(c->ev_chunk[k], c->ctx->stream));
+    }
+    if (comms[0]->backend == KABC_COMM_P2P) {
+        // rank d pulls the peers' segments of the chunk once THEIR kernels of it are done
+        for (int d = 0; d < n; ++d) {
+            kabc_comm* c = comms[at[d]];
+            KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
+            for (int r = 0; r < n; ++r)
+                KABC_HIP_CHECK(hipStreamWaitEvent(c->xstream, comms[at[r]]->ev_chunk[k], 0));
+            if (n > 1 && count > 0)
+                if (kabc_status_t st = p2p_launch_pull(comms, at, bases, n, d, count, c->xstream)) return st;
+        }
+        return KABC_OK;
+    }
+    Rccl* R;
+    if (kabc_status_t st = need_rccl(&R)) return st;
+    for (int i = 0; i < n; ++i) {
+        KABC_HIP_CHECK(hipSetDevice(comms[i]->ctx->device));
+        KABC_HIP_CHECK(hipStreamWaitEvent(comms[i]->xstream, comms[i]->ev_chunk[k], 0));
+    }
+    if (count == 0) return KABC_OK;
+    KABC_NCCL_CHECK(R, R->GroupStart());
+    for (int i = 0; i < n; ++i) {
+        kabc_comm* c = comms[i];
+        ncclResult_t r = R->AllGather(bases[i] + (size_t)c->rank * count, bases[i], count,
+                                      ncclDouble, (ncclComm_t)c->nccl, c->xstream);
+        if (r != ncclSuccess) {
+            (void)R->GroupEnd();
+            set_error("RCCL error %d (%s) in grouped ncclAllGather", (int)r, R->GetErrorString(r));
+            return KABC_ERR_DEVICE;
+        }
+    }
+    KABC_NCCL_CHECK(R, R->GroupEnd());
+    return KABC_OK;
+}
+
+kabc_status_t comm_exchange_fence_multi(kabc_comm** comms, int n, bool all_ranks) {
+    for (int i = 0; i < n; ++i) {
+        kabc_comm* c = comms[i];
+        if (!c->xstream) return KABC_OK;  // set up together: none has one
+        KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
+        KABC_HIP_CHECK(hipEventRecord(c->ev_done, c->xstream));
+    }
+    for (int i = 0; i < n; ++i) {
+        kabc_comm* c = comms[i];
+        KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
+        for (int j = 0; j < n; ++j)
+            if (j == i || all_ranks)
+                KABC_HIP_CHECK(hipStreamWaitEvent(c->ctx->stream, comms[j]->ev_done, 0));
+    }
     return KABC_OK;
 }
 
@@ -243,6 +343,7 @@ kabc_status_t kabc_comm_init_rank(kabc_ctx_t* ctx, const uint8_t id[KABC_COMM_ID
     c->nccl = nc;
     c->grp = nullptr;
     c->d_scratch = nullptr;
+    c->xstream = nullptr;
     if (hipMalloc(&c->d_scratch, 64 * sizeof(double)) != hipSuccess) {
         (void)R->CommDestroy(nc);
         delete c;
@@ -335,6 +436,7 @@ kabc_status_t kabc_comm_init_all(int32_t ndev, const int32_t* dev_ids, int32_t b
         c->nccl = nc[i];
         c->grp = grp;
         c->d_scratch = nullptr;
+        c->xstream = nullptr;
         if (grp) grp->member[i] = c;
         comms[i] = c;
     }
@@ -394,6 +496,12 @@ kabc_status_t kabc_comm_destroy(kabc_comm_t* c) {
         if (--g->refs == 0) delete g;
     }
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->xstream) {
+        (void)hipStreamSynchronize(c->xstream);
+        for (int k = 0; k < KABC_MAX_EXCHANGE_CHUNKS; ++k) (void)hipEventDestroy(c->ev_chunk[k]);
+        (void)hipEventDestroy(c->ev_done);
+        (void)hipStreamDestroy(c->xstream);
+    }
     if (c->own_ctx) (void)kabc_ctx_destroy(c->ctx);
     delete c;
     return KABC_OK;

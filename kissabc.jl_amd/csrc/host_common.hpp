@@ -61,6 +61,11 @@ struct kabc_comm {
     void* nccl;            // ncclComm_t (RCCL backend)
     kabc::P2PGroup* grp;   // P2P backend
     void* d_scratch;       // small device buffer for the host-value reductions
+    // pipelined exchange (more than one exchange chunk per half): the all-gathers run on their
+    // own stream behind one event per chunk; created at first use
+    hipStream_t xstream;
+    hipEvent_t ev_chunk[KABC_MAX_EXCHANGE_CHUNKS];  // kernels of chunk k of the current half are done
+    hipEvent_t ev_done;    // every all-gather issued so far has completed on this rank
 };
 
 namespace kabc {
@@ -70,4 +75,15 @@ kabc_status_t comm_allgather_inplace(kabc_comm* c, double* base, size_t count);
 // the same for the n communicators of one kabc_comm_init_all call: bases[i] is the buffer of
 // comms[i]; RCCL: one ncclGroup; P2P: every rank pulls the peers' segments after their kernels
 kabc_status_t comm_allgather_inplace_multi(kabc_comm** comms, double** bases, int n, size_t count);
+// ---- pipelined exchange: chunk k of a half is gathered on the exchange stream while the
+// kernels of chunk k + 1 run on the context stream ------------------------------------
+// records "the kernels of chunk k are done" on the context stream(s) and gathers the chunk
+// ([world][count] doubles at base / bases[i]) on the exchange stream(s) behind it
+kabc_status_t comm_exchange_chunk(kabc_comm* c, double* base, size_t count, int k);
+kabc_status_t comm_exchange_chunk_multi(kabc_comm** comms, double** bases, int n, size_t count, int k);
+// the context stream(s) wait until every gather issued so far has landed (before the next
+// half-generation reads the gathered half; `all_ranks`: also until no peer still reads this
+// rank's rows -- before the host may touch them)
+kabc_status_t comm_exchange_fence(kabc_comm* c);
+kabc_status_t comm_exchange_fence_multi(kabc_comm** comms, int n, bool all_ranks);
 }  // namespace kabc

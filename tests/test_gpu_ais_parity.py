@@ -84,3 +84,44 @@ def test_ais_generation_bit_exact(k, orc, gpu_ctx, name):
     assert t == to == nt * (gens + 1)
     assert np.array_equal(xs, xo) and np.array_equal(lps, lpo) and np.array_equal(lls, llo)
     assert ens.stats() == o.stats()
+
+
+@pytest.mark.parametrize("N,n_draws,nt,kib", [(10, 1000, 7, 0), (600, 201, 7, 8), (130, 37, 5, 1)])
+def test_prepared_cost_prepass_bit_exact(k, orc, gpu_ctx, monkeypatch, N, n_draws, nt, kib):
+    """README.md:31-57's simulator: the parameter-independent sums of every (walker, sub-step) of
+    a launch come from the grid-wide pre-pass, one wavefront per cost evaluation, 64 lanes
+    sharing its draws in the contract's summation order (include/kabc_costs.h) -- the oracle runs
+    the same slices one after the other.  README size (AIS(10), 1000 draws), an odd number of
+    draws, fewer pairs than lanes; `kib` bounds the pre-pass buffer so that a launch is cut into
+    blocks of sub-steps (debug records and trace still line up)."""
+    if kib:
+        monkeypatch.setenv("KABC_AUX_KIB", str(kib))
+    prior = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
+    model = k.ApproxKernelizedPosterior(prior, k.costs.NormalMeanStdSim(n_draws, 2.0, 0.04), 0.005)
+    ens = k.AisEnsemble(model, N, seed=3).init()
+    o = orc.OracleAIS(model, N, seed=3).init()
+    assert np.array_equal(ens.state()[2], o.state()[2])       # init evaluates the cost in one thread
+    ens.set_debug(nt)
+    got = ens.advance(1, nt, collect=True)
+    dbg = ens.get_debug(nt)
+    ref, tr = o.generations_sync(1, nt, trace=True)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(dbg[:, :, 1], tr[0, :, :, 1]) and np.array_equal(dbg[:, :, 5], tr[0, :, :, 5])
+    ens.set_debug(0)
+    assert np.array_equal(ens.advance(3, nt, collect=True), o.generations_sync(3, nt))
+    xs, lps, lls, _ = ens.state()
+    xo, lpo, llo, _ = o.state()
+    assert np.array_equal(xs, xo) and np.array_equal(lps, lpo) and np.array_equal(lls, llo)
+    assert ens.stats() == o.stats()
+
+
+def test_prepared_cost_prepass_batched_chains(k, orc, gpu_ctx):
+    """chains as a grid dimension: the pre-pass keys every chain's draws by its own seed"""
+    prior = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
+    model = k.ApproxKernelizedPosterior(prior, k.costs.NormalMeanStdSim(100, 2.0, 0.04), 0.005)
+    seeds = [5, 6, 7]
+    ens = k.AisEnsemble(model, 12, seeds=seeds).init()
+    got = ens.advance(3, 4, collect=True)                    # [gen][chain][N][D]
+    for c, sd in enumerate(seeds):
+        ref = orc.OracleAIS(model, 12, seed=sd).init().generations_sync(3, 4)
+        assert np.array_equal(got[:, c], ref), f"chain {c}"

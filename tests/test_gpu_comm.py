@@ -44,22 +44,78 @@ def test_p2p_emulated_ranks_match_oracle(k, orc, gpu_ctx, world, N, D, nt, gens)
     grp.close()
 
 
-def test_c5_eight_emulated_ranks_full_size(k, orc, gpu_ctx):
+@pytest.mark.parametrize("world,N,D,nt,gens,K", [(2, 2048, 8, 5, 3, 4), (3, 1001, 4, 3, 4, 3),
+                                                  (8, 523, 8, 2, 3, 2), (5, 13, 8, 4, 2, 4),
+                                                  (4, 4100, 2, 1, 6, 16)])
+def test_pipelined_exchange_chunks_match_oracle(k, orc, gpu_ctx, monkeypatch, world, N, D, nt, gens, K):
+    """KABC_EXCHANGE_CHUNKS = K: block-cyclic ownership, chunk k gathered on the exchange stream
+    while the kernels of chunk k + 1 run.  Same trajectory as the oracle (and as K = 1): the
+    draws are keyed by walker id, not by owner.  Includes shards with empty segments."""
+    monkeypatch.setenv("KABC_EXCHANGE_CHUNKS", str(K))
+    model = _model(k, D)
+    grp = k.EnsembleGroup(model, N, seed=17, devices=[0] * world, backend="p2p").init()
+    segs = [grp.shards[r].segments(0) for r in range(world)]
+    assert all(len(sg) == K for sg in segs)
+    covered = sorted((f, c) for sg in segs for f, c in sg if c > 0)
+    assert covered[0][0] == 0 and sum(c for _, c in covered) == (N + 1) // 2
+    assert all(a[0] + a[1] == b[0] for a, b in zip(covered, covered[1:]))   # a partition of the half
+    o = orc.OracleAIS(model, N, seed=17).init()
+    assert np.array_equal(grp.ensemble(world - 1), o.state()[0])
+    for _ in range(2):                                             # two calls: the fences between them
+        grp.advance(gens, nt)
+        o.generations_sync(gens, nt, collect=False)
+        xo, lpo, llo, _ = o.state()
+        for r in range(world):
+            assert np.array_equal(grp.ensemble(r), xo), f"rank {r}"
+    x, lp, ll = grp.state()
+    assert np.array_equal(x, xo) and np.array_equal(lp, lpo) and np.array_equal(ll, llo)
+    assert grp.stats() == o.stats()
+    grp.close()
+
+
+def test_default_chunking_follows_the_residency_wave(k, orc, gpu_ctx):
+    """No knob: one exchange chunk per 512 workgroups (one residency wave of the half-generation
+    kernel) of a rank's share of a half -- 2^19 walkers on two ranks = 2048 workgroups per rank
+    and half = 4 chunks; 65 536 walkers per rank (C5) stay at one."""
+    model = _model(k, 8)
+    N, nt = 1 << 19, 2
+    grp = k.EnsembleGroup(model, N, seed=5, devices=[0, 0], backend="p2p").init()
+    assert [len(s.segments(0)) for s in grp.shards] == [4, 4]
+    assert grp.shards[1].segments(1)[0] == (32768, 32768)
+    grp.advance(1, nt)
+    o = orc.OracleAIS(model, N, seed=5).init()
+    o.generations_sync(1, nt, collect=False)
+    assert np.array_equal(grp.ensemble(0), o.state()[0]) and np.array_equal(grp.ensemble(1), o.state()[0])
+    assert grp.stats() == o.stats()
+    grp.close()
+
+
+_C5 = {}
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_c5_eight_emulated_ranks_full_size(k, orc, gpu_ctx, monkeypatch, K):
     """BASELINE.json configs[4] (C5): 524 288 walkers, D = 8, sharded 8 ways, at its full
     size -- 8 ranks on one GPU, exchange by the pull kernel, ntransitions = 16, two
-    generations, bit-exact against the oracle."""
+    generations, bit-exact against the oracle; with the default single exchange chunk and
+    with four pipelined ones."""
     model = _model(k, 8)
     N, nt, gens = 524288, 16, 2
+    if K > 1:
+        monkeypatch.setenv("KABC_EXCHANGE_CHUNKS", str(K))
     grp = k.EnsembleGroup(model, N, seed=1, devices=[0] * 8, backend="p2p").init()
     grp.advance(gens, nt)
-    o = orc.OracleAIS(model, N, seed=1).init()
-    o.generations_sync(gens, nt, collect=False)
-    xo, lpo, llo, _ = o.state()
+    if not _C5:
+        o = orc.OracleAIS(model, N, seed=1).init()
+        o.generations_sync(gens, nt, collect=False)
+        _C5["state"], _C5["stats"] = o.state(), o.stats()
+    xo, lpo, llo, _ = _C5["state"]
     assert np.array_equal(grp.ensemble(7), xo) and np.array_equal(grp.ensemble(0), xo)
     x, lp, ll = grp.state()
     assert np.array_equal(lp, lpo) and np.array_equal(ll, llo)
-    assert grp.stats() == o.stats()
+    assert grp.stats() == _C5["stats"]
     assert [s.owned for s in grp.shards] == [(32768, 32768)] * 8
+    assert [len(s.segments(0)) for s in grp.shards] == [K] * 8
     grp.close()
 
 
@@ -116,10 +172,10 @@ print(json.dumps(dict(st, **extra)), flush=True)
 """
 
 
-def _run_child(tmp_path, mode):
+def _run_child(tmp_path, mode, **extra_env):
     out = str(tmp_path / f"x_{mode}.npy")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1",
-               LOCAL_RANK="0", KABC_NO_TORCH_PRELOAD="1")
+               LOCAL_RANK="0", KABC_NO_TORCH_PRELOAD="1", **extra_env)
     r = subprocess.run([sys.executable, "-c", CHILD.format(root=ROOT, out=out, mode=mode)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -133,6 +189,17 @@ def test_rccl_world1_through_the_c_abi(tmp_path):
     assert s1["proposals"] == s0["proposals"] == 1024 * 5 * 7 and s1["accepted"] == s0["accepted"]
     assert s1["red"] == [1024 * 5 * 7, 3] and s1["mx"] == [1.5, -2.0]
     x2, s2 = _run_child(tmp_path, "all")
+    assert np.array_equal(x2, x0) and s2["accepted"] == s0["accepted"]
+
+
+def test_rccl_world1_pipelined_chunks(tmp_path):
+    """The pipelined path on the RCCL backend: ncclAllGather per exchange chunk on the exchange
+    stream behind one event per chunk (one-process-per-GPU and grouped single-process forms)."""
+    x0, s0 = _run_child(tmp_path, "plain")
+    x1, s1 = _run_child(tmp_path, "rank", KABC_EXCHANGE_CHUNKS="3")
+    assert np.array_equal(x1, x0) and s1["accepted"] == s0["accepted"]
+    assert s1["red"] == [1024 * 5 * 7, 3]
+    x2, s2 = _run_child(tmp_path, "all", KABC_EXCHANGE_CHUNKS="4")
     assert np.array_equal(x2, x0) and s2["accepted"] == s0["accepted"]
 
 

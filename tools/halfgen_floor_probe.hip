@@ -39,6 +39,48 @@ __device__ __forceinline__ void barrier(Bar* b, unsigned G, unsigned nb) {
     __syncthreads();
 }
 
+// two-level arrival: `NG` group counters on their own cache lines (group = workgroup mod NG: with
+// round-robin dispatch that is the XCD), the last arrival of a group bumps the top counter
+struct Bar2 {
+    struct { unsigned long long count; unsigned pad[30]; } grp[16];
+    unsigned long long top;
+    unsigned pad0[30];
+    unsigned gen;
+    unsigned pad1[31];
+};
+template <int NG>
+__device__ __forceinline__ void barrier2(Bar2* b, unsigned G, unsigned nb) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned g = blockIdx.x % NG;
+        const unsigned members = G / NG + (g < G % NG ? 1u : 0u);
+        __threadfence();
+        if (atomicAdd(&b->grp[g].count, 1ull) + 1ull == (unsigned long long)(nb + 1u) * members) {
+            if (atomicAdd(&b->top, 1ull) + 1ull == (unsigned long long)(nb + 1u) * NG) {
+                __threadfence();
+                atomicExch(&b->gen, nb + 1u);
+            }
+        }
+        volatile unsigned* gen = &b->gen;
+        unsigned spins = 0;
+        while (*gen < nb + 1u) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22)) break;
+        }
+        __threadfence();
+    }
+    __syncthreads();
+}
+template <int NG>
+__global__ void __launch_bounds__(256) k_bar2(int iters, Bar2* bar, double* sink) {
+    double acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        acc += threadIdx.x;
+        barrier2<NG>(bar, gridDim.x, (unsigned)it);
+    }
+    if (acc == -1.0) sink[0] = acc;
+}
+
 __device__ __forceinline__ unsigned mix(unsigned a, unsigned b) {
     unsigned h = a * 0x9E3779B1u + b * 0x85EBCA77u;
     h ^= h >> 15;
@@ -129,10 +171,29 @@ int main() {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     printf("{\"unit\": \"us per half-generation\"");
-    for (unsigned G : {64u, 128u, 256u, 512u}) {
+    for (unsigned G : {32u, 64u, 128u, 256u, 512u}) {
         if (run<0>("bar", G, h0, h1, bar, sink, e0, e1)) return 1;
         if (run<1>("rw", G, h0, h1, bar, sink, e0, e1)) return 1;
         if (run<2>("rw_dep2", G, h0, h1, bar, sink, e0, e1)) return 1;
+        {
+            Bar2* b2;
+            CK(hipMalloc(&b2, sizeof(Bar2)));
+            int iters2 = 400;
+            float ms2 = 0.f;
+            for (int v = 0; v < 2; ++v) {
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipMemset(b2, 0, sizeof(Bar2)));
+                    void* args[] = {&iters2, &b2, &sink};
+                    CK(hipEventRecord(e0));
+                    CK(hipLaunchCooperativeKernel(v == 0 ? (void*)k_bar2<8> : (void*)k_bar2<16>, dim3(G), dim3(256), args, 0, 0));
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&ms2, e0, e1));
+                }
+                printf(", \"bar2level%d_%u\": %.3f", v == 0 ? 8 : 16, G, ms2 * 1e3 / iters2);
+            }
+            CK(hipFree(b2));
+        }
         // ordinary launches
         const unsigned rows = G * 64u;
         const int iters = 400;
