@@ -69,6 +69,41 @@ def c4_problem(k):
     return prior, k.costs.HierGaussSim(ybar), dict(nparticles=SMC_N, alpha=0.95, epstol=0.05, seed=1)
 
 
+def readme_problem(k):
+    """BASELINE.json configs[0] = README.md:31-57: tdata = 1000 draws N(2, 0.04); prior
+    Factored(Uniform(1,3), Truncated(Normal(0,0.1),0,100)); cost = hypot of the mean / 50 x std
+    differences of 1000 simulated draws; ApproxKernelizedPosterior(..., 0.005); AIS(10),
+    1000 samples, ntransitions = 100."""
+    import numpy as np
+    tdata = np.random.default_rng(0).normal(2.0, 0.04, 1000)
+    prior = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
+    cost = k.costs.NormalMeanStdSim(1000, tdata.mean(), tdata.std(ddof=1))
+    return k.ApproxKernelizedPosterior(prior, cost, 0.005)
+
+
+def c2_problem(k):
+    """BASELINE.json configs[1] = SURVEY 8d C2: N 4096, D 2, Normal(0,5)^2, ||x - (1,-0.5)||, scale 0.1"""
+    prior = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    return k.ApproxKernelizedPosterior(prior, k.costs.GaussDist([1.0, -0.5]), 0.1)
+
+
+def prior_class_problems(k):
+    """(name, model, N, D): the prior classes the reference's own tests use beside boxes
+    (test/runtests.jl:50-53,78,107,241) at the bench size."""
+    import numpy as np
+    socks = k.Factored(k.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), k.Beta(15, 2))
+    hier = k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 14)
+    ybar = np.random.default_rng(1).normal(size=14)
+    return [
+        ("normal8_gauss_dist", k.ApproxKernelizedPosterior(
+            k.Factored(*[k.Normal(0, 5)] * 8), k.costs.GaussDist(np.zeros(8)), 1.0), 65536, 8),
+        ("socks_negbin_beta", k.ApproxKernelizedPosterior(socks, k.costs.GaussDist([40.0, 0.8]), 3.0),
+         65536, 2),
+        ("c4_hier_prior_sim", k.ApproxKernelizedPosterior(hier, k.costs.HierGaussSim(ybar), 0.3),
+         32768, 16),
+    ]
+
+
 def _cpu_chain(args):
     """One independent serial chain (the MCMCThreads analogue, src/KissABC.jl:108)."""
     nwalkers, seed, budget_s = args
@@ -125,6 +160,28 @@ def cpu_baseline(k, budget_s, with_smc):
             out["julia_reference"] = None   # no julia on this box (none in the build image either)
     except Exception as e:
         out["julia_reference"] = {"error": repr(e)}
+    # the reference's own workloads (BASELINE.json configs[0], [1]) on one host core
+    try:
+        from oracle import oracle as orc
+        t0 = time.perf_counter()
+        o = orc.OracleAIS(readme_problem(k), 10, seed=1).init()
+        o.steps_serial(1000, NT_HEADLINE)
+        w = time.perf_counter() - t0
+        out["readme_c1"] = {"wall_s": w, "transitions_per_s": 1000 * NT_HEADLINE / w, "cores": 1,
+                            "kind": "port", "sample": "oracle ref_serial: AIS(10), 1000 step() calls x "
+                                                      "ntransitions=100, 1000 normals per cost (README.md:31-57)"}
+        o = orc.OracleAIS(c2_problem(k), 4096, seed=1).init()
+        o.steps_serial(4096, NT_HEADLINE, collect=False)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 2.0:
+            o.steps_serial(8192, NT_HEADLINE, collect=False)
+            n += 8192
+        w = time.perf_counter() - t0
+        out["c2"] = {"value": n * NT_HEADLINE / w, "unit": "evals/s", "cores": 1, "kind": "port",
+                     "sample": f"oracle ref_serial: C2 (4096 walkers, D=2), {n} step() calls x "
+                               f"ntransitions=100 in {w:.1f}s"}
+    except Exception as e:
+        out["readme_c1"] = {"error": repr(e)}
     if with_smc:
         try:
             from oracle import oracle as orc
@@ -250,6 +307,60 @@ def main():
         # (min-seconds) evens the timed duration out instead
         regions[nt_r] = timed_region(nt_r, args.steps, args.warmup if nt_r == nt_head else 5)
 
+    def kernel_leg(model, N, Dm, nts=(NT_HEADLINE,)):
+        """half-generation kernel time and evals/s of another single-GPU workload"""
+        e = k.AisEnsemble(model, N, seed=SEED, ctx=ctx).init()
+        res = {}
+        for nt_r in nts:
+            gens = max(8, min(400, int(3e8 / (N * nt_r))))
+            e.advance(3, nt_r)
+            ctx.synchronize()
+            e.set_timing(2 * gens, stride=8)
+            t0 = time.perf_counter()
+            e.advance(gens, nt_r)
+            ctx.synchronize()
+            el = time.perf_counter() - t0
+            kms, nl = e.kernel_ms()
+            e.set_timing(0)
+            Bm = 8 * (3 * Dm + 4)
+            res[str(nt_r)] = {"kernel_avg_us": kms * 1e3, "evals_per_s_kernel": (N // 2) * nt_r / (kms * 1e-3),
+                              "evals_per_s_wall": N * nt_r * gens / el, "bytes_per_eval": Bm,
+                              "roofline_frac": (N // 2) * nt_r * Bm / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        st = e.stats()
+        e.close()
+        res["accept_rate"] = st["accepted"] / max(1, st["proposals"])
+        return res
+
+    extra = {}
+    if world == 1 and not args.no_alt:
+        # BASELINE.json configs[0]: the README example end to end through sample()
+        rm = readme_problem(k)
+        k.sample(rm, k.AIS(10), 1000, ntransitions=NT_HEADLINE, seed=1, ctx=ctx, return_array=True)
+        walls = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            res = k.sample(rm, k.AIS(10), 1000, ntransitions=NT_HEADLINE, seed=1, ctx=ctx, return_array=True)
+            walls.append(time.perf_counter() - t0)
+        w = sorted(walls)[len(walls) // 2]
+        extra["readme_c1"] = {
+            "workload": "README.md:31-57 (BASELINE.json configs[0]): AIS(10), 1000 samples, "
+                        "ntransitions=100, 1000 normals per cost evaluation, through sample()",
+            "wall_ms": w * 1e3, "transitions_per_s": 1000 * NT_HEADLINE / w,
+            "posterior_mean": res.mean(0).tolist(),
+            "reference_documented": "2.0 +- 0.018, 0.0395 +- 0.00093, ~2 s incl. JIT (README.md:57-66)"}
+        if cpu and isinstance(cpu.get("readme_c1"), dict) and "wall_s" in cpu["readme_c1"]:
+            extra["readme_c1"]["cpu_baseline"] = cpu["readme_c1"]
+            extra["readme_c1"]["vs_cpu_port_1core"] = cpu["readme_c1"]["wall_s"] / w
+        # BASELINE.json configs[1]
+        extra["c2"] = dict(kernel_leg(c2_problem(k), 4096, 2, nts=(NT_HEADLINE, 16)),
+                           workload="C2: AIS 4096 walkers, D=2, Normal(0,5)^2, gauss_dist, scale 0.1 "
+                                    "(BASELINE.json configs[1]); 32 workgroups: bound by the latency of "
+                                    "one wavefront's chain of dependent transitions, not by throughput")
+        if cpu and isinstance(cpu.get("c2"), dict) and "value" in cpu["c2"]:
+            extra["c2"]["cpu_baseline"] = cpu["c2"]
+        extra["by_prior_class"] = {
+            name: dict(kernel_leg(m, Nm, Dm), N=Nm, D=Dm) for name, m, Nm, Dm in prior_class_problems(k)}
+
     smc = None
     if world == 1 and not args.no_smc:
         prior, cost, kw = c4_problem(k)
@@ -357,6 +468,7 @@ def main():
                                   "source": pmc_file}},
             "by_ntransitions": by_nt,
         }
+        out.update(extra)
         if smc is not None:
             out["smc_c4"] = smc
         if cpu is not None:

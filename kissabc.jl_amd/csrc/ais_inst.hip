@@ -24,7 +24,7 @@ static void launch_half(const AisArgs& a, hipStream_t s, unsigned nchains) {
 
 template <int COST, int D, int PCX>
 static AisLaunchFn pick() {
-    if constexpr (cost_dim_ok_c(COST, D)) return &launch_half<D, COST, PCX % 3, PCX / 3 + 1>;
+    if constexpr (cost_dim_ok_c(COST, D)) return &launch_half<D, COST, PCX % kPriorClasses, PCX / kPriorClasses + 1>;
     else return nullptr;
 }
 

@@ -139,9 +139,14 @@ __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
 //   BOX     every component is Uniform / DiscreteUniform: logpdf is the constant
 //           c0_1 + ... + c0_D (summed left to right on the host, as
 //           src/priors.jl:30-36 would) inside the box and -Inf outside
-//   SIMPLE  no per-walker transcendental (adds Normal, truncated Normal, Exponential)
-//   GENERAL everything (Beta, NegativeBinomial, Gamma, LogNormal ...)
-enum { kPriorBox = 0, kPriorSimple = 1, kPriorGeneral = 2 };
+//   SIMPLE  every component is constant-in-a-box (Uniform, DiscreteUniform) or Gaussian-in-a-box
+//           (Normal, truncated Normal): one two-way wave-uniform branch per component, the
+//           parameters of four components per batch of LDS reads (gaussbox_logpdf_push)
+//   NORMAL  every component is a plain Normal: SIMPLE without the branch, the support tests and
+//           the push_p rounding (test/runtests.jl:241)
+//   GENERAL everything (Exponential, Beta, NegativeBinomial, Gamma, LogNormal ...)
+enum { kPriorBox = 0, kPriorSimple = 1, kPriorGeneral = 2, kPriorNormal = 3 };
+constexpr int kPriorClasses = 4;
 
 struct BoxPrior {
     const double* lo;   // LDS, [D]
@@ -149,6 +154,67 @@ struct BoxPrior {
     uint32_t dmask;     // bit k: component k is discrete (push_p rounds)
     double lp;          // in-support log-density
 };
+
+// SIMPLE / NORMAL classes: one 64-byte LDS record per component,
+//   Gaussian-in-a-box : { mu, sigma, RN(1/sigma), c0 = log sigma, c1 (0 unless truncated), lo, hi, - }
+//   constant-in-a-box : { lo, hi, -, c0, -, -, -, - }
+// (lo / hi of an untruncated Normal are -Inf / +Inf).  Bit g of gmask: component g is Gaussian;
+// dmask: push_p rounds it.
+struct GaussBoxPrior {
+    const double (*rec)[8];  // LDS, [D][8]
+    uint32_t gmask, dmask;
+};
+
+// push_p (src/types.jl:27-32) + logpdf(d::Factored, x) (src/priors.jl:30-36) for these classes.
+// Returns the left-to-right sum of the components' in-support values and, in `in`, whether
+// every component is inside its support; the caller takes lp = in ? sum : -Inf, which is what
+// the reference's sum is when a term is -Inf (no term can be +Inf).  Same formulas and operation
+// order as comp_logpdf_simple -- -(z^2 + log 2pi)/2 - log sigma [- c1], z = (x - mu)/sigma --
+// with "- c1" also applied to an untruncated Normal, where c1 = 0 and x - 0 = x exactly.
+// What changed against the per-component family switch (round 2): a Normal component executed
+// ~30 instructions, four dependent LDS reads among them, each behind its own wait -- here the
+// parameters of four components arrive in one batch and a component is 9 VALU instructions.
+template <int D, bool ALLNORMAL, bool HASDISC>
+__device__ __forceinline__ double gaussbox_logpdf_push(const GaussBoxPrior& G, const double* x,
+                                                       double* xp, bool& in_out) {
+    constexpr int GRP = D <= 8 ? 4 : 2;  // (D = 16 with four records in flight spilled 150 registers)
+    bool in = true;
+    double s = 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < D; k0 += GRP) {
+        double q[GRP][7];
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+            if (k0 + j < D) {
+#pragma unroll
+                for (int w = 0; w < (ALLNORMAL ? 4 : 7); ++w) q[j][w] = G.rec[k0 + j][w];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+            const int k = k0 + j;
+            if (k < D) {
+                double v = x[k];
+                if constexpr (HASDISC) v = ((G.dmask >> k) & 1u) ? kabc_rint(v) : v;
+                xp[k] = v;
+                double l;
+                if (ALLNORMAL || ((G.gmask >> k) & 1u)) {
+                    if constexpr (!ALLNORMAL) in = in && (v >= q[j][5]) && (v <= q[j][6]);
+                    const double z = kabc_div_rc(v - q[j][0], q[j][1], q[j][2]);
+                    l = -(z * z + KABC_LOG_2PI) / 2.0 - q[j][3];
+                    if constexpr (!ALLNORMAL) l = l - q[j][4];
+                } else {
+                    in = in && (v >= q[j][0]) && (v <= q[j][1]);
+                    l = q[j][3];
+                }
+                s = (k == 0) ? l : s + l;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    in_out = in;
+    return s;
+}
 
 // y inside the box [lo, hi]^D as ONE v_cmpx chain (D = 2..8, the sizes whose bounds live in
 // registers): every comparison narrows EXEC itself, so the 2D s_and_b64 that combine ordinary
@@ -211,6 +277,7 @@ __device__ __forceinline__ bool box_contains<8>(const double* y, const double* l
 // loglike(density, push_p(density, y)) -- src/types.jl:51-58, :84-91
 template <int D, int COST, int PC>
 __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const BoxPrior& B,
+                                        const GaussBoxPrior& GB,
                                         int posterior, double eps, double reps, const double* y,
                                         const double* cost_params, const double* cost_data,
                                         int64_t ndata, kabc_cost_rng_t* rng, double& lp,
@@ -285,8 +352,15 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
             }
         }
         lp = in ? B.lp : -KABC_INF;
+    } else if constexpr (PC == kPriorSimple || PC == kPriorNormal) {
+        bool in;
+        double sum;
+        if constexpr (PC == kPriorNormal) sum = gaussbox_logpdf_push<D, true, false>(GB, y, yp, in);
+        else if (GB.dmask == 0u) sum = gaussbox_logpdf_push<D, false, false>(GB, y, yp, in);  // wave-uniform
+        else sum = gaussbox_logpdf_push<D, false, true>(GB, y, yp, in);
+        lp = in ? sum : -KABC_INF;
     } else {
-        lp = factored_logpdf_push<D, PC == kPriorSimple>(P, y, yp);
+        lp = factored_logpdf_push<D, false>(P, y, yp);
     }
     ev = kabc_isfinite(lp);
     if (posterior == KABC_POSTERIOR_KERNELIZED) {
@@ -518,6 +592,9 @@ ais_half_kernel(const AisArgs A0) {
     // and spill them to VGPR lanes (385 v_readlane per transition).
     __shared__ PriorDev sprior[D];
     __shared__ double sbox_lo[D], sbox_hi[D];
+    // SIMPLE / NORMAL classes: the components' records (GaussBoxPrior)
+    constexpr bool kGaussBox = PC == kPriorSimple || PC == kPriorNormal;
+    __shared__ __attribute__((aligned(16))) double sgb[kGaussBox ? D : 1][8];
     // the producers' copy of the log table (include/kabc_math.h): per-lane lookups
     __shared__ __attribute__((aligned(16))) double slogtab[KABC_MATH_TAB_WORDS];
     // prepared costs (include/kabc_costs.h): the parameter-independent part of the cost
@@ -578,8 +655,29 @@ ais_half_kernel(const AisArgs A0) {
         sbox_lo[threadIdx.x] = A.prior[threadIdx.x].p[0];
         sbox_hi[threadIdx.x] = A.prior[threadIdx.x].p[1];
     }
-    uint32_t dmask = 0;
-    for (int k = 0; k < D; ++k) dmask |= (A.prior[k].discrete ? 1u : 0u) << k;
+    uint32_t dmask = 0, gmask = 0;
+    for (int k = 0; k < D; ++k) {
+        dmask |= (A.prior[k].discrete ? 1u : 0u) << k;
+        const int kd = A.prior[k].kind;
+        gmask |= ((kd == KABC_PRIOR_NORMAL || kd == KABC_PRIOR_TRUNCNORMAL) ? 1u : 0u) << k;
+    }
+    if constexpr (kGaussBox) {
+        if (threadIdx.x < D) {
+            const PriorDev& q = A.prior[threadIdx.x];
+            const bool g = q.kind == KABC_PRIOR_NORMAL || q.kind == KABC_PRIOR_TRUNCNORMAL;
+            const bool tr = q.kind == KABC_PRIOR_TRUNCNORMAL;
+            double* r = sgb[threadIdx.x];
+            r[0] = q.p[0];
+            r[1] = q.p[1];
+            r[2] = q.rb;
+            r[3] = q.c0;
+            r[4] = tr ? q.c1 : 0.0;
+            r[5] = tr ? q.p[2] : -KABC_INF;
+            r[6] = tr ? q.p[3] : KABC_INF;
+            r[7] = g ? 1.0 : 0.0;
+        }
+    }
+    const GaussBoxPrior gbox = {sgb, gmask, dmask};
     // BOX class, D <= 8: the bounds live in registers for the whole launch (32 VGPRs at
     // D = 8) instead of being re-read from LDS in every sub-step (-1.5 %); larger D has
     // no registers to spare
@@ -739,7 +837,7 @@ ais_half_kernel(const AisArgs A0) {
                     }
                     double nlp, nll;
                     bool ev;
-                    loglike<D, COST, PC>(sprior, box, PK, A.eps, A.reps, y, A.cost_params,
+                    loglike<D, COST, PC>(sprior, box, gbox, PK, A.eps, A.reps, y, A.cost_params,
                                          A.cost_data, A.cost_ndata, &rng, nlp, nll, ev);
                     __builtin_amdgcn_sched_barrier(0);
                     n_eval += ev ? 1u : 0u;
@@ -906,9 +1004,9 @@ __global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) 
 // launchers (defined by the instantiation units)
 // nchains = gridDim.y
 using AisLaunchFn = void (*)(const AisArgs&, hipStream_t, unsigned nchains);
-// pcx = prior class + 3 * (posterior kind - 1)
+// pcx = prior class + kPriorClasses * (posterior kind - 1)
 AisLaunchFn find_ais_kernel(int cost_id, int D, int pcx);
-constexpr int kAisVariants = 9;
+constexpr int kAisVariants = 3 * kPriorClasses;
 void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains);
 
 }  // namespace kabc

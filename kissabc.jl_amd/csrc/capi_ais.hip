@@ -139,9 +139,10 @@ struct kabc_ais {
     int64_t dbg_cap;  // in int32 units
     // timing
     bool timing;
-    int32_t timing_stride;   // bracket every stride-th launch only
-    int64_t launch_index;
+    int32_t timing_stride;   // launches per event pair
+    int32_t open_count;      // launches inside the pair that is open (0 = none open)
     std::vector<hipEvent_t> ev;
+    std::vector<int32_t> ev_n;  // launches bracketed by pair i
     size_t ev_used;
     kabc_stats_t last;  // counters at the last kabc_ais_advance return
 };
@@ -271,14 +272,21 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         set_error("DeviceCost id %d does not accept D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
     }
-    bool simple = true, isbox = true;
+    // prior class of the half-generation kernel (ais_kernels.hpp)
+    bool isbox = true, gaussbox = true, allnormal = true;
     for (int k = 0; k < m->D; ++k) {
-        simple = simple && prior_is_simple(m->prior[k].kind);
-        isbox = isbox && (m->prior[k].kind == KABC_PRIOR_UNIFORM ||
-                          m->prior[k].kind == KABC_PRIOR_DISCRETE_UNIFORM);
+        const int kd = m->prior[k].kind;
+        const bool box = kd == KABC_PRIOR_UNIFORM || kd == KABC_PRIOR_DISCRETE_UNIFORM;
+        const bool gauss = kd == KABC_PRIOR_NORMAL || kd == KABC_PRIOR_TRUNCNORMAL;
+        isbox = isbox && box;
+        gaussbox = gaussbox && (box || gauss);
+        allnormal = allnormal && kd == KABC_PRIOR_NORMAL;
     }
-    const int pc = isbox ? kPriorBox : simple ? kPriorSimple : kPriorGeneral;
-    AisLaunchFn fn = dyn ? nullptr : find_ais_kernel(m->cost.id, m->D, pc + 3 * (m->posterior - 1));
+    const int pc = isbox ? kPriorBox : allnormal ? kPriorNormal : gaussbox ? kPriorSimple : kPriorGeneral;
+    AisLaunchFn fn = dyn ? nullptr
+                         : find_ais_kernel(m->cost.id, m->D, pc + kPriorClasses * (m->posterior - 1));
+    if (!fn && !dyn && pc == kPriorNormal)  // plugins instantiate SIMPLE only
+        fn = find_ais_kernel(m->cost.id, m->D, kPriorSimple + kPriorClasses * (m->posterior - 1));
     if (!fn && !dyn) {
         set_error("no gfx950 kernel instantiated for cost id %d, D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
@@ -366,7 +374,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->aux_cap = 0;
     h->timing = false;
     h->timing_stride = 1;
-    h->launch_index = 0;
+    h->open_count = 0;
     h->ev_used = 0;
     h->last = kabc_stats_t{0, 0, 0};
     h->d_cost_params = h->d_cost_data = nullptr;
@@ -630,6 +638,18 @@ kabc_status_t kabc_ais_init_multi(kabc_ais_t** hs, int32_t n, int32_t retry_samp
     return KABC_OK;
 }
 
+// ends the open event pair (if any) behind the last launch: a pair never spans a point where the
+// host synchronises or leaves the library, so the gaps between calls stay out of the figures
+static kabc_status_t timing_close_pair(kabc_ais_t* h) {
+    if (h->open_count > 0) {
+        KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], h->ctx->stream));
+        h->ev_n[h->ev_used / 2] = h->open_count;
+        h->ev_used += 2;
+        h->open_count = 0;
+    }
+    return KABC_OK;
+}
+
 // one launch: `ntransitions` transitions for the owned rows of segment `sg` of `half`
 static kabc_status_t launch_half_seg(kabc_ais_t* h, int32_t half, const kabc_ais::Seg& sg,
                                      int32_t ntransitions, double* dev_trace_rows) {
@@ -644,9 +664,8 @@ static kabc_status_t launch_half_seg(kabc_ais_t* h, int32_t half, const kabc_ais
     // timing: one hipEvent pair brackets `timing_stride` consecutive launches (the
     // marker packets cost ~3 us per pair; amortised over the group they stop
     // inflating the per-kernel figure)
-    const int64_t li = h->launch_index++;
     const bool t_on = h->timing && (h->ev_used + 2 <= h->ev.size());
-    if (t_on && li % h->timing_stride == 0) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
+    if (t_on && h->open_count == 0) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
     if (h->dyn) {
         AisDynArgs a = dyn_args(h, half, sg);
         a.trace = dev_trace_rows ? dev_trace_rows + sg.off * h->D : nullptr;
@@ -750,10 +769,8 @@ static kabc_status_t launch_half_seg(kabc_ais_t* h, int32_t half, const kabc_ais
             h->launch(a, s, (unsigned)h->nchains);
         }
     }
-    if (t_on && li % h->timing_stride == h->timing_stride - 1) {
-        KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used + 1], s));
-        h->ev_used += 2;
-    }
+    if (t_on && ++h->open_count >= h->timing_stride)
+        if (kabc_status_t st = timing_close_pair(h)) return st;
     KABC_HIP_CHECK(hipGetLastError());
     return KABC_OK;
 }
@@ -956,6 +973,7 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
         KABC_HIP_CHECK(sub_err);
         KABC_HIP_CHECK(drain_err);
     }
+    if (kabc_status_t stc = timing_close_pair(h)) return stc;
     DevCounters c;
     if (read_counters(h, &c)) return KABC_ERR_DEVICE;
     kabc_status_t st = check_device_error(h, c);
@@ -1019,6 +1037,7 @@ kabc_status_t kabc_ais_advance_multi(kabc_ais_t** hs, int32_t n, int64_t ngenera
     for (int i = 0; i < n; ++i) {
         kabc_ais_t* h = hs[i];
         KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+        if (kabc_status_t stc = timing_close_pair(h)) return stc;
         DevCounters c;
         if (read_counters(h, &c)) return KABC_ERR_DEVICE;
         if (kabc_status_t st = check_device_error(h, c)) return st;
@@ -1149,8 +1168,8 @@ int32_t kabc_ais_owned_segments(const kabc_ais_t* h, int32_t half, int64_t* firs
 
 kabc_status_t kabc_ais_set_timing_stride(kabc_ais_t* h, int32_t stride) {
     if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    if (kabc_status_t st = timing_close_pair(h)) return st;
     h->timing_stride = stride > 0 ? stride : 1;
-    h->launch_index = 0;
     return KABC_OK;
 }
 
@@ -1160,12 +1179,14 @@ kabc_status_t kabc_ais_set_timing(kabc_ais_t* h, int32_t max_launches) {
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     h->ev.clear();
     h->ev_used = 0;
+    h->open_count = 0;
     h->timing = max_launches > 0;
     for (int i = 0; i < 2 * max_launches; ++i) {
         hipEvent_t e;
         KABC_HIP_CHECK(hipEventCreate(&e));
         h->ev.push_back(e);
     }
+    h->ev_n.assign((size_t)(max_launches > 0 ? max_launches : 0), 0);
     return KABC_OK;
 }
 
@@ -1174,17 +1195,18 @@ double kabc_ais_kernel_ms(kabc_ais_t* h, int64_t* nlaunches) {
     if (!h || h->ev_used == 0) return 0.0;
     (void)hipSetDevice(h->ctx->device);
     if (hipStreamSynchronize(h->ctx->stream) != hipSuccess) return 0.0;
+    if (h->open_count > 0) (void)timing_close_pair(h);
+    if (hipStreamSynchronize(h->ctx->stream) != hipSuccess) return 0.0;
     double total = 0.0;
     int64_t n = 0;
     for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]) == hipSuccess) {
             total += ms;
-            ++n;
+            n += h->ev_n[i / 2];
         }
     }
     h->ev_used = 0;
-    n *= h->timing_stride;
     if (nlaunches) *nlaunches = n;
     return n ? total / (double)n : 0.0;
 }

@@ -380,7 +380,7 @@ static void model_push_p(const orc_ais_t* h, const double* x, double* out) {
 
 /* is_valid_logdensity: src/types.jl:60 (isfinite(sum(ld))), :93-94 */
 static int is_valid(const orc_ais_t* h, ld_t v) {
-    if (h->posterior != KABC_POSTERIOR_THRESHOLD) return kabc_isfinite(v.lp + v.ll); /* :142, :203 */
+    if (h->posterior != KABC_POSTERIOR_THRESHOLD) return kabc_isfinite(v.lp + v.ll); /* src/types.jl:60, :121 */
     return kabc_isfinite(v.ll) && kabc_isfinite(v.lp);
 }
 
