@@ -20,8 +20,12 @@
 #ifndef KABC_H
 #define KABC_H
 
+#ifndef __HIPCC_RTC__
 #include <stddef.h>
 #include <stdint.h>
+#else /* hipRTC has no system headers */
+#include "kabc_rtc_types.h"
+#endif
 
 #ifdef __cplusplus
 extern "C" {

@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # kernel (make -C kissabc.jl_amd/csrc PROBES=1; built on first use)
 PROBES = os.environ.get("KABC_PROBES") == "1"
 LIB_PATH = os.path.join(_HERE, "lib", "libkabc_hip_probes.so" if PROBES else "libkabc_hip.so")
+# KABC_LIB: an experimental build of the library (make VARIANT=...), for A/B runs on one box
+LIB_PATH = os.environ.get("KABC_LIB") or LIB_PATH
 _lib = None
 
 

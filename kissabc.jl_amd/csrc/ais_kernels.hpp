@@ -1001,6 +1001,7 @@ __global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) 
     ll_out[r] = ll;
 }
 
+#ifndef __HIPCC_RTC__  // host side
 // launchers (defined by the instantiation units)
 // nchains = gridDim.y
 using AisLaunchFn = void (*)(const AisArgs&, hipStream_t, unsigned nchains);
@@ -1008,5 +1009,7 @@ using AisLaunchFn = void (*)(const AisArgs&, hipStream_t, unsigned nchains);
 AisLaunchFn find_ais_kernel(int cost_id, int D, int pcx);
 constexpr int kAisVariants = 3 * kPriorClasses;
 void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains);
+
+#endif
 
 }  // namespace kabc

@@ -8,10 +8,12 @@
 // Random draws are counter-based (include/kabc_philox.h): no RNG state in memory.
 #pragma once
 
+#ifndef __HIPCC_RTC__ /* hipRTC: built-in runtime declarations, no system headers */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include <utility>
+#endif
 
 #include "kabc.h"
 #include "kabc_costs.h"

@@ -41,7 +41,10 @@
 
 namespace kabc {
 
-constexpr int kLoopBlock = 256;
+#ifndef KABC_LOOP_BLOCK
+#define KABC_LOOP_BLOCK 256
+#endif
+constexpr int kLoopBlock = KABC_LOOP_BLOCK;
 constexpr int kLoopWaves = kLoopBlock / kWave;
 constexpr int kLoopMaxG = 256;              // N <= 65 536 (the mask lives in LDS)
 constexpr int kLoopMaxWords = kLoopMaxG * kLoopWaves;
@@ -535,7 +538,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
         uint4 c4v = make_uint4(0u, 0u, 0u, 0u);
         unsigned w_below = 0, w_above = 0;
         if (pred) {
-            c4v = *reinterpret_cast<const uint4*>(&g->hist[slot1][tid * 4]);
+            if (tid < kLoopBins / 4) c4v = *reinterpret_cast<const uint4*>(&g->hist[slot1][tid * 4]);
             w_below = g->hist[slot1][kLoopBins];
             w_above = g->hist[slot1][kLoopBins + 1];
         }
@@ -625,7 +628,8 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                         error = 3;
                         break;
                     }
-                    c4v = *reinterpret_cast<const uint4*>(&g->hist[hslot][tid * 4]);
+                    c4v = (tid < kLoopBins / 4) ? *reinterpret_cast<const uint4*>(&g->hist[hslot][tid * 4])
+                                                : make_uint4(0u, 0u, 0u, 0u);
                     ++q;
                     KABC_LOOP_RECYCLE()
                 }

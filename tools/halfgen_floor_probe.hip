@@ -81,6 +81,67 @@ __global__ void __launch_bounds__(256) k_bar2(int iters, Bar2* bar, double* sink
     if (acc == -1.0) sink[0] = acc;
 }
 
+// variants of the plain barrier: SLEEP = s_sleep argument between polls (1 = 64 cycles);
+// NF > 1: the releasing workgroup writes NF generation words on their own cache lines and a
+// workgroup polls word (blockIdx mod NF) -- fewer pollers per line
+struct BarF {
+    unsigned long long count;
+    unsigned pad0[30];
+    struct { unsigned gen; unsigned pad[31]; } f[16];
+};
+template <int SLEEP, int NF>
+__device__ __forceinline__ void barrier_v(BarF* b, unsigned G, unsigned nb) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&b->count, 1ull) + 1ull == (unsigned long long)(nb + 1u) * G) {
+            __threadfence();
+#pragma unroll
+            for (int j = 0; j < NF; ++j) atomicExch(&b->f[j].gen, nb + 1u);
+        }
+        volatile unsigned* gen = &b->f[blockIdx.x % NF].gen;
+        unsigned spins = 0;
+        while (*gen < nb + 1u) {
+            __builtin_amdgcn_s_sleep(SLEEP);
+            if (++spins > (1u << 22)) break;
+        }
+        __threadfence();
+    }
+    __syncthreads();
+}
+template <int SLEEP, int NF>
+__global__ void __launch_bounds__(256) k_barv(int iters, BarF* bar, double* sink) {
+    double acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        acc += threadIdx.x;
+        barrier_v<SLEEP, NF>(bar, gridDim.x, (unsigned)it);
+    }
+    if (acc == -1.0) sink[0] = acc;
+}
+// no fences at all: what the arrival / release protocol alone costs
+template <int SLEEP>
+__global__ void __launch_bounds__(256) k_bar_nofence(int iters, BarF* b, double* sink) {
+    double acc = 0;
+    const unsigned G = gridDim.x;
+    for (int it = 0; it < iters; ++it) {
+        acc += threadIdx.x;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned nb = (unsigned)it;
+            if (__hip_atomic_fetch_add(&b->count, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull ==
+                (unsigned long long)(nb + 1u) * G)
+                __hip_atomic_store(&b->f[0].gen, nb + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(&b->f[0].gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nb + 1u) {
+                __builtin_amdgcn_s_sleep(SLEEP);
+                if (++spins > (1u << 22)) break;
+            }
+        }
+        __syncthreads();
+    }
+    if (acc == -1.0) sink[0] = acc;
+}
+
 __device__ __forceinline__ unsigned mix(unsigned a, unsigned b) {
     unsigned h = a * 0x9E3779B1u + b * 0x85EBCA77u;
     h ^= h >> 15;
@@ -193,6 +254,30 @@ int main() {
                 printf(", \"bar2level%d_%u\": %.3f", v == 0 ? 8 : 16, G, ms2 * 1e3 / iters2);
             }
             CK(hipFree(b2));
+        }
+        {
+            BarF* bf;
+            CK(hipMalloc(&bf, sizeof(BarF)));
+            int itv = 400;
+            float msv = 0.f;
+            struct { const char* name; void* fn; } vs[] = {
+                {"bar_sleep4", (void*)k_barv<4, 1>}, {"bar_sleep16", (void*)k_barv<16, 1>},
+                {"bar_sleep1_8flags", (void*)k_barv<1, 8>}, {"bar_sleep4_8flags", (void*)k_barv<4, 8>},
+                {"bar_sleep4_16flags", (void*)k_barv<4, 16>}, {"bar_nofence_sleep1", (void*)k_bar_nofence<1>},
+                {"bar_nofence_sleep4", (void*)k_bar_nofence<4>}};
+            for (auto& v : vs) {
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipMemset(bf, 0, sizeof(BarF)));
+                    void* args[] = {&itv, &bf, &sink};
+                    CK(hipEventRecord(e0));
+                    CK(hipLaunchCooperativeKernel(v.fn, dim3(G), dim3(256), args, 0, 0));
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    CK(hipEventElapsedTime(&msv, e0, e1));
+                }
+                printf(", \"%s_%u\": %.3f", v.name, G, msv * 1e3 / itv);
+            }
+            CK(hipFree(bf));
         }
         // ordinary launches
         const unsigned rows = G * 64u;
