@@ -112,6 +112,12 @@ typedef struct kabc_ctx kabc_ctx_t;
 typedef struct kabc_ais kabc_ais_t;
 
 int32_t kabc_version(void);
+/* sizeof() of the i-th struct of this header as the library was compiled, in declaration order:
+ * 0 kabc_prior_t, 1 kabc_cost_t, 2 kabc_model_t, 3 kabc_stats_t, 4 kabc_smc_opts_t,
+ * 5 kabc_smc_iter_t, 6 kabc_smc_result_t, 7 kabc_abcde_opts_t, 8 kabc_abcde_result_t,
+ * 9 kabc_pfilter_opts_t, 10 kabc_pfilter_result_t; -1 beyond.  A binding that mirrors the
+ * structs by hand (ctypes, Julia `struct`) checks itself against this at load time. */
+int32_t kabc_abi_sizeof(int32_t which);
 const char* kabc_last_error(void);
 /* number of visible gfx950 devices (0 when none; never an error) */
 int32_t kabc_device_count(void);
@@ -161,6 +167,22 @@ kabc_status_t kabc_math_probe(kabc_ctx_t* ctx, int32_t fn, int64_t n, const doub
  * kissabc.jl_amd/csrc/user_plugin.inc with hipcc --offload-arch=gfx950; on success
  * *out_cost_id (>= 100) is the id to put into kabc_cost_t.id. */
 kabc_status_t kabc_register_cost_plugin(const char* path, int32_t* out_cost_id);
+/* The same, without hipcc and without a file: `src` (the snippet -- KABC_HD double
+ * kabc_user_cost(...), optionally KABC_USER_AUX_WORDS + kabc_user_cost_prepare) is compiled IN
+ * PROCESS by hipRTC for gfx950.  dims[ndims]: the values of length(prior) the cost accepts
+ * (1..KABC_MAX_DIM); posterior_mask: bit (kind - 1) per kabc_posterior_kind_t the cost will be
+ * used with, 0 = all.  The snippet itself is compiled at once (its errors come back here, with
+ * the compiler's message in kabc_last_error()); the kernels are compiled at first use, one
+ * family and dimension at a time (about 1-3 s each: kabc_ais_create / kabc_smc_run / ... of
+ * the first model that uses the cost).  SURVEY 8f-1; src/types.jl:42,55. */
+kabc_status_t kabc_compile_cost_plugin(const char* src, const int32_t* dims, int32_t ndims,
+                                       int32_t posterior_mask, int32_t* out_cost_id);
+/* Compile (and load on the current device) one kernel family of a user cost ahead of its first
+ * use.  family: 0 AIS half-generation (variant = prior class + 4 * (posterior kind - 1); prior
+ * class 0 box, 1 constant/Gaussian-in-a-box, 2 general), 1 AIS init, 2 smc propose+accept
+ * (variant = 1 for priors without Beta / Gamma / LogNormal / NegativeBinomial components, else
+ * 0), 3 smc init, 4 smc persistent loop, 5 / 6 ABCDE init / generation, 7 pfilter attempt. */
+kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family, int32_t D, int32_t variant);
 
 /* ---- AIS: sample(model, AIS(N), Ns; ntransitions, discard_initial, retry_sampling)
  *

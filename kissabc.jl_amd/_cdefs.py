@@ -101,6 +101,7 @@ class PfilterResult(C.Structure):
 VP = C.c_void_p
 PROTOTYPES = {
     "kabc_version": (C.c_int32, []),
+    "kabc_abi_sizeof": (C.c_int32, [C.c_int32]),
     "kabc_last_error": (C.c_char_p, []),
     "kabc_device_count": (C.c_int32, []),
     "kabc_ctx_create": (C.c_int, [C.c_int32, VP, C.POINTER(VP)]),
@@ -116,6 +117,9 @@ PROTOTYPES = {
     "kabc_factored_rand": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.c_uint64, C.c_uint32,
                                      C.c_int64, C.c_int64, C.c_uint64, c_double_p]),
     "kabc_register_cost_plugin": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "kabc_plugin_precompile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "kabc_compile_cost_plugin": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                         C.POINTER(C.c_int32)]),
     "kabc_ais_create": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_uint64, C.POINTER(VP)]),
     "kabc_ais_create_batch": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_int32,
                                         C.POINTER(C.c_uint64), C.POINTER(VP)]),

@@ -5,6 +5,9 @@
 #pragma once
 
 #include "kabc_device.hpp"
+#ifndef __HIPCC_RTC__
+#include "launcher.hpp"
+#endif
 
 namespace kabc {
 
@@ -268,6 +271,10 @@ __global__ void __launch_bounds__(256) abcde_final_kernel(const AbcdeFinalArgs A
 
 #endif  // KABC_ABCDE_SINGLE_UNIT
 
+#ifndef __HIPCC_RTC__  // host side
 using AbcdeLaunchFn = void (*)(const AbcdeArgs&, hipStream_t);
+using AbcdeLaunch = Launcher<AbcdeArgs>;  // host function or run-time compiled kernel
+inline dim3 abcde_geom(const AbcdeArgs& a) { return dim3((unsigned)((a.N + kAbcdeBlock - 1) / kAbcdeBlock)); }
+#endif
 
 }  // namespace kabc

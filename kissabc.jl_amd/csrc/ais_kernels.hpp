@@ -11,6 +11,9 @@
 #pragma once
 
 #include "kabc_device.hpp"
+#ifndef __HIPCC_RTC__
+#include "launcher.hpp"
+#endif
 
 namespace kabc {
 
@@ -1005,8 +1008,16 @@ __global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) 
 // launchers (defined by the instantiation units)
 // nchains = gridDim.y
 using AisLaunchFn = void (*)(const AisArgs&, hipStream_t, unsigned nchains);
+using AisLaunch = Launcher<AisArgs, unsigned>;       // host function or run-time compiled kernel
+using AisInitLaunch = Launcher<InitArgs, unsigned>;
+inline dim3 ais_half_geom(const AisArgs& a, unsigned nchains) {
+    return dim3((unsigned)((a.rows_owned + kBatch - 1) / kBatch), nchains);
+}
+inline dim3 ais_init_geom(const InitArgs& a, unsigned nchains) {
+    return dim3((unsigned)((a.rows_owned + kInitBlock - 1) / kInitBlock), nchains);
+}
 // pcx = prior class + kPriorClasses * (posterior kind - 1)
-AisLaunchFn find_ais_kernel(int cost_id, int D, int pcx);
+AisLaunch find_ais_kernel(int cost_id, int D, int pcx);
 constexpr int kAisVariants = 3 * kPriorClasses;
 void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains);
 

@@ -154,10 +154,13 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         set_error("DeviceCost id %d does not accept D = %d", cost->id, D);
         return KABC_ERR_UNSUPPORTED;
     }
-    AbcdeLaunchFn f_init, f_gen;
+    AbcdeLaunch f_init, f_gen;
     if (const CostPlugin* p = find_plugin(cost->id)) {
-        f_init = p->abcde_init ? (AbcdeLaunchFn)p->abcde_init(D) : nullptr;
-        f_gen = p->abcde_gen ? (AbcdeLaunchFn)p->abcde_gen(D) : nullptr;
+        const PluginKernel ki = plugin_kernel(p, kPfAbcdeInit, D, 0), kg = plugin_kernel(p, kPfAbcdeGen, D, 0);
+        f_init = ki.host ? AbcdeLaunch((AbcdeLaunchFn)ki.host)
+                         : ki.mod ? AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
+        f_gen = kg.host ? AbcdeLaunch((AbcdeLaunchFn)kg.host)
+                        : kg.mod ? AbcdeLaunch(kg.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
         if (!f_init || !f_gen) {
             set_error("cost plugin has no ABCDE kernels for D = %d", D);
             return KABC_ERR_UNSUPPORTED;

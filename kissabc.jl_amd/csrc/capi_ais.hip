@@ -30,7 +30,7 @@ KABC_DECL_COST(11)
 
 AisDynLaunchFn find_ais_dyn_kernel();
 
-AisLaunchFn find_ais_kernel(int cost_id, int D, int pc) {
+AisLaunch find_ais_kernel(int cost_id, int D, int pc) {
     switch (cost_id) {
         case 1: return find_ais_kernel_cost_1(D, pc);
         case 2: return find_ais_kernel_cost_2(D, pc);
@@ -44,8 +44,10 @@ AisLaunchFn find_ais_kernel(int cost_id, int D, int pc) {
         case 10: return find_ais_kernel_cost_10(D, pc);
         case 11: return find_ais_kernel_cost_11(D, pc);
         default: {
-            const CostPlugin* p = find_plugin(cost_id);
-            return p ? (AisLaunchFn)p->ais(D, pc) : nullptr;
+            const PluginKernel k = plugin_kernel(find_plugin(cost_id), kPfAis, D, pc);
+            if (k.host) return AisLaunch((AisLaunchFn)k.host);
+            if (k.mod) return AisLaunch(k.mod, &ais_half_geom, (unsigned)kAisBlock);
+            return nullptr;
         }
     }
 }
@@ -67,8 +69,10 @@ static void launch_init_table(int D, const InitArgs& a, hipStream_t s, unsigned 
 
 void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains) {
     if (const CostPlugin* p = find_plugin(a.cost_id)) {
+        const PluginKernel k = plugin_kernel(p, kPfAisInit, D, 0);
         using Fn = void (*)(const InitArgs&, hipStream_t, unsigned);
-        if (Fn f = (Fn)p->ais_init(D)) f(a, s, nchains);
+        if (k.host) AisInitLaunch((Fn)k.host)(a, s, nchains);
+        else if (k.mod) AisInitLaunch(k.mod, &ais_init_geom, (unsigned)kInitBlock)(a, s, nchains);
         return;
     }
     launch_init_table(D, a, s, nchains, std::make_integer_sequence<int, KABC_MAX_DIM>{});
@@ -122,7 +126,7 @@ struct kabc_ais {
     PriorDev* d_prior;            // [KABC_MAX_DIM] prepared components
     uint64_t seed, t;
     int32_t rank, world;
-    AisLaunchFn launch;
+    AisLaunch launch;
     double box_lp;
     bool initialised;
     // sample-trace streaming: device chunks filled in rotation by the kernels and
@@ -283,8 +287,9 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         allnormal = allnormal && kd == KABC_PRIOR_NORMAL;
     }
     const int pc = isbox ? kPriorBox : allnormal ? kPriorNormal : gaussbox ? kPriorSimple : kPriorGeneral;
-    AisLaunchFn fn = dyn ? nullptr
-                         : find_ais_kernel(m->cost.id, m->D, pc + kPriorClasses * (m->posterior - 1));
+    static_assert(kPriorClasses == 4, "capi_plugin.hip decodes pcx with 4 prior classes");
+    AisLaunch fn = dyn ? AisLaunch()
+                       : find_ais_kernel(m->cost.id, m->D, pc + kPriorClasses * (m->posterior - 1));
     if (!fn && !dyn && pc == kPriorNormal)  // plugins instantiate SIMPLE only
         fn = find_ais_kernel(m->cost.id, m->D, kPriorSimple + kPriorClasses * (m->posterior - 1));
     if (!fn && !dyn) {

@@ -162,6 +162,17 @@ __global__ void math_probe_kernel(int fn, int64_t n, const double* __restrict__ 
 extern "C" {
 
 int32_t kabc_version(void) { return KABC_VERSION; }
+
+int32_t kabc_abi_sizeof(int32_t which) {
+    static const int32_t sz[] = {
+        (int32_t)sizeof(kabc_prior_t),        (int32_t)sizeof(kabc_cost_t),
+        (int32_t)sizeof(kabc_model_t),        (int32_t)sizeof(kabc_stats_t),
+        (int32_t)sizeof(kabc_smc_opts_t),     (int32_t)sizeof(kabc_smc_iter_t),
+        (int32_t)sizeof(kabc_smc_result_t),   (int32_t)sizeof(kabc_abcde_opts_t),
+        (int32_t)sizeof(kabc_abcde_result_t), (int32_t)sizeof(kabc_pfilter_opts_t),
+        (int32_t)sizeof(kabc_pfilter_result_t)};
+    return (which >= 0 && which < (int32_t)(sizeof sz / sizeof sz[0])) ? sz[which] : -1;
+}
 const char* kabc_last_error(void) { return get_error(); }
 
 int32_t kabc_device_count(void) {

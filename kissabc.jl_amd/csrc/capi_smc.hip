@@ -41,7 +41,7 @@ KABC_DECL_LOOP(9)
 KABC_DECL_LOOP(10)
 KABC_DECL_LOOP(11)
 
-SmcLoopLaunchFn find_smc_loop_kernel(int cost_id, int D, bool simple) {
+SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple) {
     switch (cost_id) {
         case 1: return find_smc_loop_kernel_cost_1(D, simple);
         case 2: return find_smc_loop_kernel_cost_2(D, simple);
@@ -55,13 +55,15 @@ SmcLoopLaunchFn find_smc_loop_kernel(int cost_id, int D, bool simple) {
         case 10: return find_smc_loop_kernel_cost_10(D, simple);
         case 11: return find_smc_loop_kernel_cost_11(D, simple);
         default: {
-            const CostPlugin* p = find_plugin(cost_id);
-            return (p && p->smc_loop) ? (SmcLoopLaunchFn)p->smc_loop(D, simple ? 1 : 0) : nullptr;
+            const PluginKernel k = plugin_kernel(find_plugin(cost_id), kPfSmcLoop, D, simple ? 1 : 0);
+            if (k.host) return SmcLoopLaunch((SmcLoopLaunchFn)k.host);
+            if (k.mod) return SmcLoopLaunch(k.mod);
+            return nullptr;
         }
     }
 }
 
-SmcLaunchFn find_smc_kernel(int cost_id, int D, bool simple) {
+SmcLaunch find_smc_kernel(int cost_id, int D, bool simple) {
     switch (cost_id) {
         case 1: return find_smc_kernel_cost_1(D, simple);
         case 2: return find_smc_kernel_cost_2(D, simple);
@@ -75,8 +77,10 @@ SmcLaunchFn find_smc_kernel(int cost_id, int D, bool simple) {
         case 10: return find_smc_kernel_cost_10(D, simple);
         case 11: return find_smc_kernel_cost_11(D, simple);
         default: {
-            const CostPlugin* p = find_plugin(cost_id);
-            return p ? (SmcLaunchFn)p->smc(D, simple ? 1 : 0) : nullptr;
+            const PluginKernel k = plugin_kernel(find_plugin(cost_id), kPfSmc, D, simple ? 1 : 0);
+            if (k.host) return SmcLaunch((SmcLaunchFn)k.host);
+            if (k.mod) return SmcLaunch(k.mod, &smc_mcmc_geom, (unsigned)kSmcBlock);
+            return nullptr;
         }
     }
 }
@@ -246,7 +250,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     }
     bool simple = true;
     for (int k = 0; k < D; ++k) simple = simple && prior_is_simple(prior[k].kind);
-    SmcLaunchFn mcmc = dyn ? nullptr : find_smc_kernel(cost->id, D, simple);
+    SmcLaunch mcmc = dyn ? SmcLaunch() : find_smc_kernel(cost->id, D, simple);
     SmcDynLaunchFn dyn_fn = nullptr;
     if (dyn) {
         if (cost->id >= KABC_COST_USER) {
@@ -381,7 +385,9 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
         if (const CostPlugin* pl = find_plugin(cost->id)) {
             using Fn = void (*)(const SmcInitArgs&, hipStream_t);
-            if (Fn f = (Fn)pl->smc_init(D)) f(a, s);
+            const PluginKernel k = plugin_kernel(pl, kPfSmcInit, D, simple ? 1 : 0);
+            if (k.host) SmcInitLaunch((Fn)k.host)(a, s);
+            else if (k.mod) SmcInitLaunch(k.mod, &smc_init_geom, (unsigned)kSmcBlock)(a, s);
         } else {
             launch_smc_init(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
         }
@@ -445,8 +451,8 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         const char* env = std::getenv("KABC_SMC_LOOP");  // read per call: tests flip it
         const bool allow = !(env && env[0] == '0');
         const unsigned G = (unsigned)((N + kLoopBlock - 1) / kLoopBlock);
-        SmcLoopLaunchFn loop_fn =
-            (allow && !dyn && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple) : nullptr;
+        SmcLoopLaunch loop_fn =
+            (allow && !dyn && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple) : SmcLoopLaunch();
         if (loop_fn) {
             SmcLoopScratch* lsc;
             KABC_HIP_CHECK(bufs.alloc(&lsc, 1));
@@ -700,11 +706,14 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         set_error("DeviceCost id %d does not accept D = %d", cost->id, D);
         return KABC_ERR_UNSUPPORTED;
     }
-    AbcdeLaunchFn f_init;
-    PfLaunchFn f_att;
+    AbcdeLaunch f_init;
+    PfLaunch f_att;
     if (const CostPlugin* p = find_plugin(cost->id)) {
-        f_init = p->abcde_init ? (AbcdeLaunchFn)p->abcde_init(D) : nullptr;
-        f_att = p->pf_attempt ? (PfLaunchFn)p->pf_attempt(D) : nullptr;
+        const PluginKernel ki = plugin_kernel(p, kPfAbcdeInit, D, 0), ka = plugin_kernel(p, kPfAttempt, D, 0);
+        f_init = ki.host ? AbcdeLaunch((AbcdeLaunchFn)ki.host)
+                         : ki.mod ? AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
+        f_att = ka.host ? PfLaunch((PfLaunchFn)ka.host)
+                        : ka.mod ? PfLaunch(ka.mod, &pf_geom, (unsigned)kPfBlock) : PfLaunch();
         if (!f_init || !f_att) {
             set_error("cost plugin has no pfilter kernels for D = %d", D);
             return KABC_ERR_UNSUPPORTED;

@@ -113,6 +113,10 @@ __global__ void __launch_bounds__(kPfBlock) pf_attempt_kernel(const PfArgs A) {
     }
 }
 
+#ifndef __HIPCC_RTC__  // host side
 using PfLaunchFn = void (*)(const PfArgs&, hipStream_t);
+using PfLaunch = Launcher<PfArgs>;
+inline dim3 pf_geom(const PfArgs& a) { return dim3((unsigned)((a.N + kPfBlock - 1) / kPfBlock)); }
+#endif
 
 }  // namespace kabc

@@ -4,8 +4,11 @@
 
 namespace kabc {
 
+struct RtcPlugin;  // a cost compiled in-process by hipRTC (capi_plugin.hip)
+
 struct CostPlugin {
-    void* dl;
+    void* dl;        // plugin .so built by hipcc (kabc_register_cost_plugin), else NULL
+    RtcPlugin* rtc;  // hipRTC plugin (kabc_compile_cost_plugin), else NULL
     int32_t id;
     int32_t (*dim_ok)(int32_t D);
     void* (*ais)(int32_t D, int32_t prior_class);   // -> AisLaunchFn
@@ -22,5 +25,17 @@ struct CostPlugin {
 
 const CostPlugin* find_plugin(int cost_id);
 bool cost_dim_ok_rt(int cost_id, int D);
+
+// One kernel family of a plugin: a host launch function (.so plugins) or a module kernel
+// (hipRTC plugins, compiled at first use -- a family and dimension per compilation, 1-3 s).
+// `variant`: AIS pcx (prior class + kPriorClasses * (posterior kind - 1)); smc: simple prior 0/1.
+enum PluginFamily {
+    kPfAis = 0, kPfAisInit, kPfSmc, kPfSmcInit, kPfSmcLoop, kPfAbcdeInit, kPfAbcdeGen, kPfAttempt
+};
+struct PluginKernel {
+    void* host = nullptr;
+    void* mod = nullptr;
+};
+PluginKernel plugin_kernel(const CostPlugin* p, int family, int D, int variant);
 
 }  // namespace kabc

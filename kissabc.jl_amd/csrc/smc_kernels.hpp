@@ -13,6 +13,9 @@
 #pragma once
 
 #include "kabc_device.hpp"
+#ifndef __HIPCC_RTC__
+#include "launcher.hpp"
+#endif
 
 namespace kabc {
 
@@ -936,7 +939,13 @@ __global__ void smc_iter_end_kernel(SmcCtrl* ctrl, kabc_smc_iter_t* log, int64_t
 
 #endif  // KABC_SMC_SINGLE_UNIT
 
+#ifndef __HIPCC_RTC__  // host side
 using SmcLaunchFn = void (*)(const SmcMcmcArgs&, hipStream_t);
-SmcLaunchFn find_smc_kernel(int cost_id, int D, bool simple_prior);
+using SmcLaunch = Launcher<SmcMcmcArgs>;       // host function or run-time compiled kernel
+using SmcInitLaunch = Launcher<SmcInitArgs>;
+inline dim3 smc_mcmc_geom(const SmcMcmcArgs& a) { return dim3((unsigned)((a.N + kSmcBlock - 1) / kSmcBlock)); }
+inline dim3 smc_init_geom(const SmcInitArgs& a) { return dim3((unsigned)((a.N + kSmcBlock - 1) / kSmcBlock)); }
+SmcLaunch find_smc_kernel(int cost_id, int D, bool simple_prior);
+#endif
 
 }  // namespace kabc

@@ -1019,6 +1019,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
     }
 }
 
+#ifndef __HIPCC_RTC__  // host side
 // the persistent ε-loop kernel: cooperative launch (all G workgroups co-resident or an error)
 template <int D, int COST, bool SIMPLE>
 inline hipError_t launch_smc_loop(const SmcLoopArgs& a, unsigned G, hipStream_t s) {
@@ -1040,6 +1041,23 @@ inline hipError_t launch_smc_loop(const SmcLoopArgs& a, unsigned G, hipStream_t 
 }
 
 using SmcLoopLaunchFn = hipError_t (*)(const SmcLoopArgs&, unsigned, hipStream_t);
-SmcLoopLaunchFn find_smc_loop_kernel(int cost_id, int D, bool simple_prior);
+// host launch function or a run-time compiled kernel (hipRTC plugin)
+struct SmcLoopLaunch {
+    SmcLoopLaunchFn fn = nullptr;
+    void* mod = nullptr;
+    SmcLoopLaunch() = default;
+    SmcLoopLaunch(std::nullptr_t) {}
+    SmcLoopLaunch(SmcLoopLaunchFn f) : fn(f) {}
+    explicit SmcLoopLaunch(void* m) : mod(m) {}
+    explicit operator bool() const { return fn != nullptr || mod != nullptr; }
+    hipError_t operator()(const SmcLoopArgs& a, unsigned G, hipStream_t s) const {
+        if (fn) return fn(a, G, s);
+        if (G > (unsigned)kLoopMaxG) return hipErrorCooperativeLaunchTooLarge;
+        return rtc_launch_cooperative(mod, G, (unsigned)kLoopBlock, &a, s);
+    }
+};
+SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple_prior);
+
+#endif
 
 }  // namespace kabc

@@ -70,6 +70,15 @@ mutable struct KabcSmcOpts
     seed::UInt64
     max_iterations::Int64
 end
+struct KabcSmcIter       # kabc_smc_iter_t (one entry of the optional iteration log)
+    eps::Float64
+    ess::Int64
+    accepted::Int64
+    resampled::Int32
+    flag::Int32
+    mcmc_passes::Int32
+    reserved::Int32
+end
 mutable struct KabcSmcResult
     theta::Ptr{Float64}
     cost::Ptr{Float64}
@@ -162,27 +171,34 @@ WienerRms(tdata) = devcost(11, Float64[], tdata,                                
                   sum(abs, sqrt.(μ^2 .* t .^ 2 .+ σ^2 .* t) .* (0.95 + 0.1 * rand()) .- tdata) / length(tdata)))
 
 """
-    UserCost(csrc, dims; params, data, cpu)
+    UserCost(csrc, dims; params, data, cpu, posteriors)
 A DeviceCost from a C snippet defining `kabc_user_cost` (include/kabc_costs.h,
-KABC_COST_USER): compiled with hipcc for gfx950 together with csrc/user_plugin.inc and
-registered with `kabc_register_cost_plugin`.  `cpu` is the Julia closure with the same
-formula (used when the model runs through KissABC's own AIS/smc).  With
-posterior kind CommonLogDensity the snippet returns the log-density.
+KABC_COST_USER), compiled IN PROCESS by hipRTC through `kabc_compile_cost_plugin`
+(include/kabc.h): the snippet is checked here, each kernel family is compiled when a model
+first uses it.  `cpu` is the Julia closure with the same formula (used when the model runs
+through KissABC's own AIS/smc).  With posterior kind CommonLogDensity the snippet returns the
+log-density.  `posteriors`: bit mask of the posterior kinds to build AIS kernels for
+(1 kernelized, 2 threshold, 4 common; 0 = all).
 """
-function UserCost(csrc::String, dims; params = Float64[], data = Float64[], cpu = x -> NaN)
-    root = normpath(joinpath(@__DIR__, "..", ".."))
-    cond = join(("(D) == $d" for d in dims), " || ")
-    text = "#define KABC_USER_DIM_OK(D) ($cond)\n#include <hip/hip_runtime.h>\n" *
-           "#include \"kabc_philox.h\"\n" * csrc *
-           "\n#define KABC_USER_COST_DEFINED 1\n#include \"user_plugin.inc\"\n"
-    dir = mktempdir(); src = joinpath(dir, "user.hip"); so = joinpath(dir, "libkabc_user.so")
-    write(src, text)
-    run(`/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math --offload-arch=gfx950
-         -I $(joinpath(root, "include")) -I $(joinpath(root, "kissabc.jl_amd", "csrc"))
-         -shared -o $so $src`)
+function UserCost(csrc::String, dims; params = Float64[], data = Float64[], cpu = x -> NaN,
+                  posteriors::Integer = 0)
+    d = Int32[Int32(x) for x in dims]
     id = Ref{Int32}(0)
-    check(ccall((:kabc_register_cost_plugin, libkabc), Cint, (Cstring, Ref{Int32}), so, id))
+    check(ccall((:kabc_compile_cost_plugin, libkabc), Cint,
+                (Cstring, Ptr{Int32}, Int32, Int32, Ref{Int32}), csrc, d, length(d), posteriors, id))
     devcost(id[], params, data, cpu)
+end
+
+# the struct mirrors above against the library's own sizeof (kabc_abi_sizeof, include/kabc.h):
+# a layout drift between this file and kabc.h fails at load time, not as memory corruption
+function __init__()
+    mirrors = (KabcPrior, KabcCost, KabcModel, KabcStats, KabcSmcOpts, KabcSmcIter, KabcSmcResult,
+               KabcAbcdeOpts, KabcAbcdeResult, KabcPfilterOpts, KabcPfilterResult)
+    for (i, T) in enumerate(mirrors)
+        want = ccall((:kabc_abi_sizeof, libkabc), Int32, (Int32,), Int32(i - 1))
+        want == sizeof(T) || error("KissABCHip: sizeof($T) = $(sizeof(T)) but libkabc_hip has $want " *
+                                   "(include/kabc.h changed; update the struct mirrors)")
+    end
 end
 
 # ---- Factored / Distributions -> kabc_prior_t --------------------------------

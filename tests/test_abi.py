@@ -28,7 +28,14 @@ def test_library_exports_every_declared_symbol(k):
 
 
 def test_struct_layouts(k):
-    from kissabc_jl_amd import _cdefs as cd
+    from kissabc_jl_amd import _cdefs as cd, _lib
+    # the hand-written ctypes mirrors against the library's own sizeof (kabc_abi_sizeof): the
+    # same self-check julia/KissABCHip.jl runs in __init__
+    lib = _lib.load()
+    mirrors = [cd.Prior, cd.Cost, cd.Model, cd.Stats, cd.SmcOpts, cd.SmcIter, cd.SmcResult,
+               cd.AbcdeOpts, cd.AbcdeResult, cd.PfilterOpts, cd.PfilterResult]
+    assert [lib.kabc_abi_sizeof(i) for i in range(len(mirrors))] == [C.sizeof(m) for m in mirrors]
+    assert lib.kabc_abi_sizeof(len(mirrors)) == -1
     assert C.sizeof(cd.Prior) == 40
     assert C.sizeof(cd.Cost) == 32
     assert C.sizeof(cd.Model) == 24 + 32

@@ -213,3 +213,62 @@ def test_prepared_user_cost_equals_builtin_and_oracle(k, orc, gpu_ctx):
     assert got.shape == ref.shape and np.isfinite(ref).all()
     assert np.array_equal(got, orc.OracleAIS(mu, N, seed=2).init().generations_sync(gens, nt))
     assert np.array_equal(ref, orc.OracleAIS(mb, N, seed=2).init().generations_sync(gens, nt))
+
+
+# ---- kabc_compile_cost_plugin: the snippet compiled in process by hipRTC ---------------------
+def test_hiprtc_checks_the_snippet_at_registration(k):
+    """No GPU needed: hipRTC is a compiler.  A broken snippet comes back at once with the
+    compiler's message; a good one gets an id and nothing else is compiled yet."""
+    import time
+    bad = ROSEN_SRC.replace("kabc_sqrt(s)", "kabc_sqrt(s) + undeclared_thing")
+    with pytest.raises(k.KabcError, match="undeclared_thing"):
+        k.costs.UserCost(bad, dims=[2], posteriors=["kernelized"])
+    t0 = time.perf_counter()
+    c = k.costs.UserCost(ROSEN_SRC + "// registration test\n", dims=[2, 8], posteriors=["kernelized"])
+    assert c.id >= 100 and time.perf_counter() - t0 < 5.0
+    with pytest.raises(k.KabcError, match="1..16"):          # longer vectors: the hipcc-built form
+        import ctypes as C
+        from kissabc_jl_amd import _lib
+        out = C.c_int32()
+        _lib.check(_lib.load().kabc_compile_cost_plugin(ROSEN_SRC.encode(), (C.c_int32 * 1)(40), 1, 0,
+                                                        C.byref(out)))
+
+
+def test_hiprtc_compiles_every_kernel_family(k):
+    """Each family of a user cost compiles under hipRTC from the library's own headers (on a box
+    without a GPU the code object is produced and only its load fails; with one it loads)."""
+    import ctypes as C
+    from kissabc_jl_amd import _lib
+    lib = _lib.load()
+    c = k.costs.UserCost(SIM_SRC + "// family test\n", dims=[3], params=[0.5], data=[0.0] * 8, name="ar1")
+    for family, variant in [(0, 1), (1, 0), (2, 1), (3, 1), (4, 0), (5, 0), (6, 0), (7, 0)]:
+        st = lib.kabc_plugin_precompile(c.id, family, 3, variant)
+        msg = lib.kabc_last_error().decode()
+        assert st == 0 or "compiled (" in msg, (family, variant, msg[:2000])
+    assert lib.kabc_plugin_precompile(c.id, 0, 5, 1) != 0      # D = 5 was not listed
+
+
+@pytest.mark.gpu
+def test_hiprtc_and_hipcc_plugins_agree(k, orc, gpu_ctx, monkeypatch):
+    """The two forms of a user cost -- hipRTC in process (default) and the plugin .so built by
+    hipcc -- run the same kernels: identical trajectories (AIS and smc), and a first AIS use of
+    the hipRTC form within a few seconds."""
+    import time
+    U = k.Factored(*[k.Uniform(-5, 5)] * 8)
+    src = ROSEN_SRC + "// rtc-vs-hipcc\n"
+    rtc = k.costs.UserCost(src, dims=[8], posteriors=["kernelized"])
+    t0 = time.perf_counter()
+    a = k.AisEnsemble(k.ApproxKernelizedPosterior(U, rtc, 1.0), 700, seed=9).init().advance(3, 5, collect=True)
+    first_use = time.perf_counter() - t0
+    monkeypatch.setenv("KABC_USER_PLUGIN", "hipcc")
+    so = k.costs.UserCost(src, dims=[8], posteriors=["kernelized"])
+    assert so.id != rtc.id
+    b = k.AisEnsemble(k.ApproxKernelizedPosterior(U, so, 1.0), 700, seed=9).init().advance(3, 5, collect=True)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, k.AisEnsemble(k.ApproxKernelizedPosterior(U, k.costs.Rosenbrock(), 1.0), 700,
+                                           seed=9).init().advance(3, 5, collect=True))
+    ra = k.smc(U, rtc, nparticles=3000, epstol=2.0, seed=4, return_array=True)
+    rb = k.smc(U, so, nparticles=3000, epstol=2.0, seed=4, return_array=True)
+    assert ra.eps == rb.eps and np.array_equal(ra.info["theta_all"], rb.info["theta_all"])
+    assert first_use < 10.0, first_use                          # two kernels through hipRTC + the run
+    print(f"first AIS use of a hipRTC cost: {first_use:.2f} s")
