@@ -412,6 +412,22 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
                            const kabc_cost_t* cost, const kabc_smc_opts_t* opts,
                            kabc_smc_result_t* result);
 
+/* smc with its COST LOOP sharded over the communicator's ranks -- the reference's own parallel
+ * leg (`parallel = true`: Threads.@threads over the cost evaluations, src/smc.jl:120-123,168).
+ * Every rank holds the whole ensemble and runs the epsilon-selection redundantly (identical
+ * inputs, identical results); the propose / prior-MH / cost / accept pass is split by blocks
+ * of 64 particles and ends with one grouped in-place all-gather of the rows it produced.
+ * Worth it for an EXPENSIVE simulator only (from ~10 us per evaluation: a C4-sized pass
+ * gathers 4.6 MB); a cheap cost is faster on one GPU (kabc_smc_run's persistent loop kernel).
+ * Collective: every rank calls it with the same arguments and receives the same result.
+ * Draws are keyed by particle: the result equals kabc_smc_run's bit for bit.
+ * Communicators: kabc_comm_init_rank (one process per GPU, RCCL); the P2P communicators of
+ * kabc_comm_init_all when each rank is driven by its own host thread (how the test-suite
+ * runs several ranks on one GPU).  length(prior) <= KABC_MAX_DIM. */
+kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
+                                const kabc_cost_t* cost, const kabc_smc_opts_t* opts,
+                                kabc_smc_result_t* result);
+
 /* ---- ABCDE(prior, cost, ϵ_target; kwargs...) -- src/smc.jl:347-430 -----------
  * ABC differential evolution (exported, undocumented and untested in the reference:
  * parity is oracle-vs-device only).  Generation-synchronous and double-buffered in

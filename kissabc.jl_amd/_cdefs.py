@@ -170,6 +170,8 @@ PROTOTYPES = {
                                    C.POINTER(PfilterOpts), C.POINTER(PfilterResult)]),
     "kabc_smc_run": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),
                                C.POINTER(SmcOpts), C.POINTER(SmcResult)]),
+    "kabc_smc_run_dist": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),
+                               C.POINTER(SmcOpts), C.POINTER(SmcResult)]),
 }
 
 

@@ -347,9 +347,12 @@ class SmcResult(collections.namedtuple("SmcResult", ["P", "C", "eps", "info"])):
 
 def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.015, epstol=0.0,
         r_epstol=None, min_r_ess=None, max_stretch=2.0, verbose=False, parallel=False, seed=0,
-        ctx=None, return_array=False):
+        ctx=None, return_array=False, comm=None):
     """smc(prior, cost; ...) -- src/smc.jl:92-206, same keywords and defaults.
     `parallel` is accepted and ignored (every particle is a GPU lane).
+    `comm` (a comm.Comm): the cost loop is sharded over the communicator's ranks
+    (kabc_smc_run_dist -- the reference's `parallel = true` leg across GPUs, for expensive
+    simulators); collective, every rank gets the same result, equal to the single-GPU one.
     Returns (P, C, ϵ) as the reference does (+ an `info` dict)."""
     fac = as_factored(prior)
     scalar = isinstance(prior, UnivariateDistribution)
@@ -382,7 +385,10 @@ def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.01
     r.iter_log = log
     r.iter_log_cap = 4096
     cc = cost.to_c()
-    _lib.check(lib.kabc_smc_run(ctx.handle, fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    if comm is not None:
+        _lib.check(lib.kabc_smc_run_dist(comm.handle, fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    else:
+        _lib.check(lib.kabc_smc_run(ctx.handle, fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
     mask = alive.astype(bool)
     kept = theta[mask]
     nit = min(r.iterations, 4096)

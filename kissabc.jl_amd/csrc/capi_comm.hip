@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <string>
 
@@ -104,7 +105,25 @@ struct P2PGroup {
     int refs = 0;
     kabc_comm* member[KABC_COMM_MAX_WORLD] = {};
     hipEvent_t ev[KABC_COMM_MAX_WORLD] = {};  // ev[r]: rank r's rows of the gathered half are final
+    // ranks driven by one host thread each (comm_allgather_many): rendezvous + published bases
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long phase = 0;
+    double* pub[KABC_COMM_MAX_WORLD][8] = {};
 };
+
+static void p2p_host_barrier(P2PGroup* g) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    const unsigned long long ph = g->phase;
+    if (++g->arrived == g->world) {
+        g->arrived = 0;
+        ++g->phase;
+        g->cv.notify_all();
+    } else {
+        g->cv.wait(lk, [&] { return g->phase != ph; });
+    }
+}
 
 // exchange stream + events of a communicator, created at first use (on the context's device)
 static kabc_status_t exchange_setup(kabc_comm* c) {
@@ -203,6 +222,60 @@ kabc_status_t comm_allgather_inplace_multi(kabc_comm** comms, double** bases, in
         kabc_comm* c = comms[i];
         ncclResult_t r = R->AllGather(bases[i] + (size_t)c->rank * count, bases[i], count,
                                       ncclDouble, (ncclComm_t)c->nccl, c->ctx->stream);
+        if (r != ncclSuccess) {
+            (void)R->GroupEnd();
+            set_error("RCCL error %d (%s) in grouped ncclAllGather", (int)r, R->GetErrorString(r));
+            return KABC_ERR_DEVICE;
+        }
+    }
+    KABC_NCCL_CHECK(R, R->GroupEnd());
+    return KABC_OK;
+}
+
+kabc_status_t comm_allgather_many(kabc_comm* c, double** bases, const size_t* counts, int n) {
+    if (n < 1 || n > 8) {
+        set_error("comm_allgather_many: 1..8 buffers");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (c->backend == KABC_COMM_P2P) {
+        // one host thread per rank: publish, meet, pull, meet (synchronous: this form exists so
+        // that the multi-rank logic can run -- and be tested -- on one GPU)
+        P2PGroup* g = c->grp;
+        KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
+        for (int j = 0; j < n; ++j) g->pub[c->rank][j] = bases[j];
+        KABC_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));  // this rank's segments are final
+        p2p_host_barrier(g);
+        kabc_status_t st = KABC_OK;
+        for (int j = 0; j < n && st == KABC_OK && c->world > 1; ++j) {
+            if (counts[j] == 0) continue;
+            PullArgs a;
+            std::memset(&a, 0, sizeof a);
+            for (int r = 0; r < c->world; ++r) a.src[r] = g->pub[r][j];
+            a.dst = bases[j];
+            a.count = counts[j];
+            a.self = c->rank;
+            a.world = c->world;
+            unsigned gx = (unsigned)((counts[j] / 2 + 255) / 256);
+            gx = gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+            hipLaunchKernelGGL(p2p_pull_kernel, dim3(gx, (unsigned)(c->world - 1)), dim3(256), 0,
+                               c->ctx->stream, a);
+            if (hipGetLastError() != hipSuccess) st = KABC_ERR_DEVICE;
+        }
+        const hipError_t e = hipStreamSynchronize(c->ctx->stream);
+        p2p_host_barrier(g);  // nobody overwrites a source before every pull has finished
+        if (st != KABC_OK || e != hipSuccess) {
+            set_error("P2P all-gather failed: %s", hipGetErrorString(e));
+            return KABC_ERR_DEVICE;
+        }
+        return KABC_OK;
+    }
+    Rccl* R;
+    if (kabc_status_t st = need_rccl(&R)) return st;
+    KABC_NCCL_CHECK(R, R->GroupStart());
+    for (int j = 0; j < n; ++j) {
+        if (counts[j] == 0) continue;
+        const ncclResult_t r = R->AllGather(bases[j] + (size_t)c->rank * counts[j], bases[j], counts[j],
+                                            ncclDouble, (ncclComm_t)c->nccl, c->ctx->stream);
         if (r != ncclSuccess) {
             (void)R->GroupEnd();
             set_error("RCCL error %d (%s) in grouped ncclAllGather", (int)r, R->GetErrorString(r));

@@ -87,7 +87,8 @@ SmcLaunch find_smc_kernel(int cost_id, int D, bool simple) {
 
 template <int D>
 static void launch_smc_init_d(const SmcInitArgs& a, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.N + kSmcBlock - 1) / kSmcBlock);
+    const unsigned grid = smc_grid(a);
+    if (grid == 0) return;
     hipLaunchKernelGGL((smc_init_kernel<D>), dim3(grid), dim3(kSmcBlock), 0, s, a);
 }
 template <int... Ds>
@@ -199,9 +200,37 @@ void kabc_smc_default_opts(kabc_smc_opts_t* o) {
     o->max_iterations = 0;
 }
 
+// set while a run is repeated on the kernel-per-phase path after the persistent loop kernel gave up
+static thread_local bool tl_smc_no_loop = false;
+
+static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc_prior_t* prior,
+                                  int32_t D, const kabc_cost_t* cost, const kabc_smc_opts_t* o,
+                                  kabc_smc_result_t* res);
+
 kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
                            const kabc_cost_t* cost, const kabc_smc_opts_t* o,
                            kabc_smc_result_t* res) {
+    return smc_run_impl(ctx, nullptr, prior, D, cost, o, res);
+}
+
+kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
+                                const kabc_cost_t* cost, const kabc_smc_opts_t* o,
+                                kabc_smc_result_t* res) {
+    if (!comm) {
+        set_error("kabc_smc_run_dist: communicator is NULL");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (D > KABC_MAX_DIM) {
+        set_error("kabc_smc_run_dist: length(prior) <= %d (the run-time-dimension kernels are single-GPU)",
+                  KABC_MAX_DIM);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    return smc_run_impl(comm->ctx, comm, prior, D, cost, o, res);
+}
+
+static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc_prior_t* prior,
+                                  int32_t D, const kabc_cost_t* cost, const kabc_smc_opts_t* o,
+                                  kabc_smc_result_t* res) {
     if (!ctx || !prior || !cost || !o || !res) {
         set_error("kabc_smc_run: NULL argument");
         return KABC_ERR_INVALID_ARG;
@@ -288,27 +317,47 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     unsigned long long* slots;
     kabc_smc_iter_t* d_log = nullptr;
     const int64_t log_cap = res->iter_log ? res->iter_log_cap : 0;
+    // Sharded cost loop (kabc_smc_run_dist; the reference's own parallel leg, src/smc.jl:120-123,
+    // 168): every rank keeps the whole ensemble and runs the selection redundantly; the
+    // propose / prior-MH / COST / accept pass is split by workgroups of 64 particles -- rank r
+    // takes [r * wg_per, (r + 1) * wg_per) -- and each pass ends with one grouped in-place
+    // all-gather of the rows it produced (theta, X, logprior, the per-workgroup cost statistics
+    // and counter lines).  Buffers are padded to `world` equal segments.
+    const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
+    const int64_t nwg_all = (N + kSmcBlock - 1) / kSmcBlock;
+    const int64_t wg_per = (nwg_all + world - 1) / world;
+    const int64_t wg_lo = std::min<int64_t>((int64_t)rank * wg_per, nwg_all);
+    const int64_t wg_n = std::min<int64_t>(wg_lo + wg_per, nwg_all) - wg_lo;
+    const size_t Npad = comm ? (size_t)(wg_per * world) * kSmcBlock : (size_t)N;
     for (int b = 0; b < 2; ++b) {
-        KABC_HIP_CHECK(bufs.alloc(&th[b], (size_t)N * D));
-        KABC_HIP_CHECK(bufs.alloc(&X[b], (size_t)N));
-        KABC_HIP_CHECK(bufs.alloc(&lp[b], (size_t)N));
+        KABC_HIP_CHECK(bufs.alloc(&th[b], Npad * D));
+        KABC_HIP_CHECK(bufs.alloc(&X[b], Npad));
+        KABC_HIP_CHECK(bufs.alloc(&lp[b], Npad));
     }
     KABC_HIP_CHECK(bufs.alloc(&alive, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&ctrl, 1));
-    KABC_HIP_CHECK(bufs.alloc(&slots, (size_t)kSmcSlots * 8));
+    KABC_HIP_CHECK(bufs.alloc(&slots, (size_t)kSmcSlots * 8 * world));
     SmcSelScratch* sel_scratch;
     KABC_HIP_CHECK(bufs.alloc(&sel_scratch, 1));
     KABC_HIP_CHECK(hipMemsetAsync(sel_scratch, 0, sizeof(SmcSelScratch), s));
     const unsigned selG = select_blocks(N);
     unsigned long long* part;  // per-workgroup cost statistics for the select kernel
     const int64_t npart = (N + kSmcBlock - 1) / kSmcBlock;
-    KABC_HIP_CHECK(bufs.alloc(&part, (size_t)npart * 4));
+    KABC_HIP_CHECK(bufs.alloc(&part, (size_t)(comm ? wg_per * world : npart) * 4));
     KABC_HIP_CHECK(bufs.alloc(&d_out, (size_t)N * D));
     KABC_HIP_CHECK(bufs.alloc(&d_Xout, (size_t)N));
     if (log_cap > 0) KABC_HIP_CHECK(bufs.alloc(&d_log, (size_t)log_cap));
     KABC_HIP_CHECK(hipMemsetAsync(ctrl, 0, sizeof(SmcCtrl), s));
-    KABC_HIP_CHECK(hipMemsetAsync(slots, 0, sizeof(unsigned long long) * kSmcSlots * 8, s));
+    KABC_HIP_CHECK(hipMemsetAsync(slots, 0, sizeof(unsigned long long) * kSmcSlots * 8 * world, s));
+    // the all-gather at the end of a sharded pass / of the sharded init (buffer set `b`)
+    auto exchange = [&](int b, bool with_slots) -> kabc_status_t {
+        double* bases[5] = {th[b], X[b], lp[b], reinterpret_cast<double*>(part),
+                            reinterpret_cast<double*>(slots)};
+        const size_t counts[5] = {(size_t)wg_per * kSmcBlock * D, (size_t)wg_per * kSmcBlock,
+                                  (size_t)wg_per * kSmcBlock, (size_t)wg_per * 4, (size_t)kSmcSlots * 8};
+        return comm_allgather_many(comm, bases, counts, with_slots ? 5 : 4);
+    };
     if (cost->nparams > 0) {
         KABC_HIP_CHECK(bufs.alloc(&d_params, (size_t)cost->nparams));
         KABC_HIP_CHECK(hipMemcpyAsync(d_params, cost->params, sizeof(double) * cost->nparams,
@@ -382,6 +431,18 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         a.cost_id = cost->id;
         a.prior = P;
         a.part = part;
+        if (comm) {  // this rank's workgroups only; everybody is alive at the start (:125)
+            a.sharded = 1;
+            a.wg0 = wg_lo;
+            a.nwg = wg_n;
+            KABC_HIP_CHECK(hipMemsetAsync(alive, 1, (size_t)N, s));
+            SmcCtrl c0 = {};
+            c0.eps = INFINITY;
+            c0.eps_prev = INFINITY;
+            c0.cost_evals = (unsigned long long)N;
+            KABC_HIP_CHECK(hipMemcpyAsync(ctrl, &c0, sizeof c0, hipMemcpyHostToDevice, s));
+            KABC_HIP_CHECK(hipStreamSynchronize(s));  // (c0 is on this stack frame)
+        }
         std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
         if (const CostPlugin* pl = find_plugin(cost->id)) {
             using Fn = void (*)(const SmcInitArgs&, hipStream_t);
@@ -392,6 +453,8 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
             launch_smc_init(D, a, s, std::make_integer_sequence<int, KABC_MAX_DIM>{});
         }
         KABC_HIP_CHECK(hipGetLastError());
+        if (comm)
+            if (kabc_status_t st = exchange(0, false)) return st;
     }
     SmcSelectArgs sa;
     sa.Xbuf[0] = X[0];
@@ -432,6 +495,12 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     ma.max_stretch = o->max_stretch;
     ma.prior = P;
     ma.part = part;
+    if (comm) {
+        ma.sharded = 1;
+        ma.wg0 = wg_lo;
+        ma.nwg = wg_n;
+        ma.slots = slots + (size_t)rank * kSmcSlots * 8;  // this rank's block of counter lines
+    }
     SmcLoopParams lpz;
     lpz.mcmc_tol = o->mcmc_tol;
     lpz.epstol = o->epstol;
@@ -449,7 +518,7 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     bool looped = false;
     {
         const char* env = std::getenv("KABC_SMC_LOOP");  // read per call: tests flip it
-        const bool allow = !(env && env[0] == '0');
+        const bool allow = !(env && env[0] == '0') && !tl_smc_no_loop && !comm;
         const unsigned G = (unsigned)((N + kLoopBlock - 1) / kLoopBlock);
         SmcLoopLaunch loop_fn =
             (allow && !dyn && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple) : SmcLoopLaunch();
@@ -525,10 +594,47 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     // The ε-loop is decided on the device (smc_pass_end_kernel / smc_iter_end_kernel);
     // the host enqueues kBatch iterations and then reads the 128-byte control block
     // once.  Kernels enqueued past the end of the loop are no-ops.
+    // Path 2, sharded (kabc_smc_run_dist): the same kernels; the host looks at the control block
+    // after every pass -- it has to know which buffer set the pass wrote (that is what is
+    // gathered) and whether the next pass is still open; with a simulator expensive enough to
+    // be worth sharding, a host round trip per pass is noise.
+    while (comm && !looped) {
+        KABC_HIP_CHECK(launch_select(sa, selG, s));
+        KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+        KABC_HIP_CHECK(hipStreamSynchronize(s));
+        if (hc.done) break;
+        bool ended = false;
+        for (int r = 0; r < R && !hc.done && hc.pass_open; ++r) {
+            const bool timed = (mcmc_timed == 0 && r == 0);
+            if (timed) KABC_HIP_CHECK(hipEventRecord(ev0, s));
+            mcmc(ma, s);
+            if (timed) KABC_HIP_CHECK(hipEventRecord(ev1, s));
+            KABC_HIP_CHECK(hipGetLastError());
+            if (kabc_status_t st = exchange(1 - hc.cur, true)) return st;
+            ended = (r == R - 1);
+            hipLaunchKernelGGL(smc_pass_end_kernel, dim3(1), dim3(kSmcSlots), 0, s, ctrl, slots, N,
+                               o->mcmc_tol, ended ? 1 : 0, d_log, log_cap, lpz, world);
+            KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+            if (timed) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+                    mcmc_ms += ms;
+                    ++mcmc_timed;
+                }
+            }
+        }
+        if (!ended && !hc.done) {
+            hipLaunchKernelGGL(smc_iter_end_kernel, dim3(1), dim3(1), 0, s, ctrl, d_log, log_cap, N, lpz);
+            KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+        }
+        if (hc.done) break;
+    }
     const int kGroup = 4;                        // retry passes enqueued between host checks
     const int kBatch = (R <= kGroup) ? 16 : 1;   // iterations per host sync
     bool first = true;
-    while (!looped) {
+    while (!looped && !comm) {
         for (int it = 0; it < kBatch; ++it) {
             KABC_HIP_CHECK(launch_select(sa, selG, s));
             bool ended = false;  // the iteration's end rode on the last pass_end launch
@@ -574,9 +680,11 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
                       "or the device is wedged)");
             rc = KABC_ERR_DEVICE;
         } else if (hc.error == 4) {
-            set_error("smc loop kernel: internal capacity exceeded (candidate list); rerun with "
-                      "KABC_SMC_LOOP=0");
-            rc = KABC_ERR_DEVICE;
+            // more particles share one histogram bin of the costs than the loop kernel's candidate
+            // list holds (heavy ties): a limit of that kernel, not of the problem.  The run is
+            // repeated below on the kernel-per-phase path -- every draw is counter-based, so the
+            // repetition is the same run.
+            rc = KABC_ERR_UNSUPPORTED;
         } else {
             set_error("collection must be non-empty");
             rc = KABC_ERR_INVALID_STATE;
@@ -623,6 +731,14 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
         res->proposals = hc.proposals;
         res->kernel_ms_mcmc = mcmc_timed ? mcmc_ms / (double)mcmc_timed : 0.0;
         res->mcmc_launches = (int64_t)hc.pass;
+    }
+    // (test hook: KABC_SMC_LOOP_GIVE_UP=1 makes every loop-kernel run count as given up)
+    if (looped && !tl_smc_no_loop && std::getenv("KABC_SMC_LOOP_GIVE_UP")) hc.error = 4;
+    if (hc.error == 4 && looped && !tl_smc_no_loop) {
+        tl_smc_no_loop = true;
+        const kabc_status_t st2 = kabc_smc_run(ctx, prior, D, cost, o, res);
+        tl_smc_no_loop = false;
+        return st2;
     }
     if (sa.stamps) {
         unsigned long long st[8];

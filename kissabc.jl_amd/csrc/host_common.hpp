@@ -85,5 +85,10 @@ kabc_status_t comm_exchange_chunk_multi(kabc_comm** comms, double** bases, int n
 // half-generation reads the gathered half; `all_ranks`: also until no peer still reads this
 // rank's rows -- before the host may touch them)
 kabc_status_t comm_exchange_fence(kabc_comm* c);
+// In-place all-gather of n buffers at once on the context stream ([world][count[j]] doubles at
+// bases[j], this rank's segment at rank * count[j]): the sharded cost loop of smc.  RCCL: one
+// group; P2P communicators of a single-process group: every rank is driven by its OWN host
+// thread and the threads meet here (host rendezvous, pull kernels, synchronous).
+kabc_status_t comm_allgather_many(kabc_comm* c, double** bases, const size_t* counts, int n);
 kabc_status_t comm_exchange_fence_multi(kabc_comm** comms, int n, bool all_ranks);
 }  // namespace kabc

@@ -10,7 +10,7 @@ namespace kabc {
 
 template <int D, int COST, bool SIMPLE>
 static void launch_mcmc(const SmcMcmcArgs& a, hipStream_t s) {
-    const unsigned grid = (unsigned)((a.N + kSmcBlock - 1) / kSmcBlock);
+    const unsigned grid = smc_grid(a);
     if (grid == 0) return;
     hipLaunchKernelGGL((smc_mcmc_kernel<D, COST, SIMPLE>), dim3(grid), dim3(kSmcBlock), 0, s, a);
 }

@@ -64,6 +64,10 @@ struct SmcInitArgs {
     PriorSet prior;
     kabc_prior_t raw[KABC_MAX_DIM];
     unsigned long long* part;  // [workgroups][4] cost statistics of the block, see smc_block_stats
+    // cost loop sharded over ranks (kabc_smc_run_dist): this launch covers the workgroups
+    // [wg0, wg0 + nwg) of the ensemble (64 particles each) when `sharded` is set, else all
+    int64_t wg0, nwg;
+    int32_t sharded;
 };
 
 constexpr int kSelBins = 1024;      // histogram bins per narrowing round
@@ -124,6 +128,8 @@ struct SmcMcmcArgs {
     double max_stretch;
     PriorSet prior;
     unsigned long long* part;  // [workgroups][4], see smc_block_stats
+    int64_t wg0, nwg;          // sharded cost loop: the workgroups of this launch ...
+    int32_t sharded;           // ... when set, else all
 };
 
 struct SmcFinalArgs {
@@ -156,8 +162,10 @@ __device__ __forceinline__ double val_of(uint64_t k) {
 // count, NaN count and key range of the ALIVE costs of their 64 particles -- so that the
 // single-workgroup select kernel reads N/64 partials instead of scanning X once more
 // (that scan was 12 of its 54 us at C4).  Called by all 64 threads of the workgroup.
-__device__ __forceinline__ void smc_block_stats(unsigned long long* part, bool alive, double x) {
+__device__ __forceinline__ void smc_block_stats(unsigned long long* part, bool alive, double x,
+                                                int64_t wg = -1) {
     if (!part) return;
+    if (wg < 0) wg = (int64_t)blockIdx.x;
     const uint64_t k = key_of(x);
     unsigned long long cnt = wave_sum(alive ? 1ull : 0ull);
     unsigned long long nan = wave_sum((alive && x != x) ? 1ull : 0ull);
@@ -168,7 +176,7 @@ __device__ __forceinline__ void smc_block_stats(unsigned long long* part, bool a
         kmaxn = b < kmaxn ? b : kmaxn;
     }
     if ((threadIdx.x & (kWave - 1)) == 0) {
-        unsigned long long* p = part + (size_t)blockIdx.x * 4;
+        unsigned long long* p = part + (size_t)wg * 4;
         p[0] = cnt;
         p[1] = nan;
         p[2] = kmin;
@@ -178,7 +186,8 @@ __device__ __forceinline__ void smc_block_stats(unsigned long long* part, bool a
 
 template <int D>
 __global__ void __launch_bounds__(kSmcBlock) smc_init_kernel(const SmcInitArgs A) {
-    const int64_t i = (int64_t)blockIdx.x * kSmcBlock + threadIdx.x;
+    const int64_t wg = A.wg0 + (int64_t)blockIdx.x;
+    const int64_t i = wg * kSmcBlock + threadIdx.x;
     double c = 0.0;
     if (i < A.N) {
         double x[D], xp[D];
@@ -194,15 +203,15 @@ __global__ void __launch_bounds__(kSmcBlock) smc_init_kernel(const SmcInitArgs A
         A.X[i] = c;
         A.lpi[i] = lp;
         A.alive[i] = 1;
-        if (i == 0) {
-            SmcCtrl cc = {};
-            cc.eps = KABC_INF;       // ϵ = Inf  (src/smc.jl:127)
-            cc.eps_prev = KABC_INF;
-            cc.cost_evals = (unsigned long long)A.N;
-            *A.ctrl = cc;
-        }
     }
-    smc_block_stats(A.part, i < A.N, c);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // (every rank of a sharded run keeps its own ctrl)
+        SmcCtrl cc = {};
+        cc.eps = KABC_INF;       // ϵ = Inf  (src/smc.jl:127)
+        cc.eps_prev = KABC_INF;
+        cc.cost_evals = (unsigned long long)A.N;
+        *A.ctrl = cc;
+    }
+    smc_block_stats(A.part, i < A.N, c, wg);
 }
 
 #ifdef KABC_SMC_SINGLE_UNIT  // non-template kernels: defined once, in capi_smc.hip
@@ -768,7 +777,8 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
 
 template <int D, int COST, bool SIMPLE>
 __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A) {
-    const int64_t i = (int64_t)blockIdx.x * kSmcBlock + threadIdx.x;
+    const int64_t wg = A.wg0 + (int64_t)blockIdx.x;
+    const int64_t i = wg * kSmcBlock + threadIdx.x;
     unsigned long long n_eval = 0, n_acc = 0, n_prop = 0;
     if (A.ctrl->done || !A.ctrl->pass_open) return;  // uniform no-op
     const int cur = A.ctrl->cur;
@@ -843,7 +853,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
         A.lpi[1 - cur][i] = lpi;
         Xfin = Xi;
     }
-    smc_block_stats(A.part, alive_i, Xfin);
+    smc_block_stats(A.part, alive_i, Xfin, wg);
     // one counter line per workgroup (mod kSmcSlots): same-line atomics from 512
     // workgroups cost ~20 us per launch
     const unsigned long long se = wave_sum(n_eval), sa = wave_sum(n_acc), sp = wave_sum(n_prop);
@@ -900,15 +910,21 @@ __global__ void __launch_bounds__(kSmcSlots) smc_pass_end_kernel(SmcCtrl* ctrl,
                                                                  int end_iter,
                                                                  kabc_smc_iter_t* log,
                                                                  int64_t log_cap,
-                                                                 SmcLoopParams P) {
+                                                                 SmcLoopParams P, int nregions = 1) {
     __shared__ unsigned long long sh[3][kSmcSlots / kWave];
     if (ctrl->done) return;
     const int tid = threadIdx.x;
     if (ctrl->pass_open) {  // uniform: thread 0 changes it only after the barrier below
+        // (nregions > 1: a sharded cost loop -- one block of counter lines per rank, gathered)
         unsigned long long v[3];
         for (int j = 0; j < 3; ++j) {
-            v[j] = wave_sum(slots[(size_t)tid * 8 + j]);
-            slots[(size_t)tid * 8 + j] = 0;
+            unsigned long long t = 0;
+            for (int r = 0; r < nregions; ++r) {
+                unsigned long long* q = slots + ((size_t)r * kSmcSlots + tid) * 8 + j;
+                t += *q;
+                *q = 0;
+            }
+            v[j] = wave_sum(t);
         }
         if ((tid & (kWave - 1)) == 0)
             for (int j = 0; j < 3; ++j) sh[j][tid >> 6] = v[j];
@@ -943,8 +959,13 @@ __global__ void smc_iter_end_kernel(SmcCtrl* ctrl, kabc_smc_iter_t* log, int64_t
 using SmcLaunchFn = void (*)(const SmcMcmcArgs&, hipStream_t);
 using SmcLaunch = Launcher<SmcMcmcArgs>;       // host function or run-time compiled kernel
 using SmcInitLaunch = Launcher<SmcInitArgs>;
-inline dim3 smc_mcmc_geom(const SmcMcmcArgs& a) { return dim3((unsigned)((a.N + kSmcBlock - 1) / kSmcBlock)); }
-inline dim3 smc_init_geom(const SmcInitArgs& a) { return dim3((unsigned)((a.N + kSmcBlock - 1) / kSmcBlock)); }
+// launch grid: the workgroups [wg0, wg0 + nwg) of a sharded run, else all ceil(N / 64)
+template <class Args>
+inline unsigned smc_grid(const Args& a) {
+    return (unsigned)(a.sharded ? a.nwg : (a.N + kSmcBlock - 1) / kSmcBlock);
+}
+inline dim3 smc_mcmc_geom(const SmcMcmcArgs& a) { return dim3(smc_grid(a)); }
+inline dim3 smc_init_geom(const SmcInitArgs& a) { return dim3(smc_grid(a)); }
 SmcLaunch find_smc_kernel(int cost_id, int D, bool simple_prior);
 #endif
 

@@ -228,3 +228,51 @@ def test_bench_under_the_drivers_launcher():
     d = _bench({}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                     "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29571"])
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
+
+
+@pytest.mark.parametrize("world,N,name", [(2, 3000, "gauss"), (4, 1000, "mixture_retrys"), (3, 5001, "hier")])
+def test_smc_sharded_cost_loop_matches_single_gpu_and_oracle(k, orc, gpu_ctx, world, N, name):
+    """kabc_smc_run_dist: the reference's parallel leg (src/smc.jl:120-123,168) across ranks --
+    every rank holds the ensemble, evaluates prior-MH + cost for its blocks of 64 particles,
+    one grouped all-gather per pass.  Ranks are host threads on the P2P backend (one GPU);
+    every rank returns the single-GPU result, which equals the oracle's, bit for bit (uneven and
+    empty shards, retry passes, stochastic costs)."""
+    import threading
+    rng = np.random.default_rng(3)
+    if name == "gauss":
+        prior, cost = k.Factored(k.Normal(0, 2), k.Normal(0, 2)), k.costs.GaussDist([0.5, -0.25])
+        kw = dict(nparticles=N, epstol=0.05, seed=8)
+    elif name == "mixture_retrys":
+        prior, cost = k.Uniform(-10, 10), k.costs.Mixture(0.0)
+        kw = dict(nparticles=N, mcmc_retrys=3, epstol=0.2, seed=5)
+    else:
+        prior = k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 6)
+        cost = k.costs.HierGaussSim(rng.normal(size=6))
+        kw = dict(nparticles=N, epstol=0.4, seed=2)
+    ref = orc.smc(prior, cost, **kw)
+    single = k.smc(prior, cost, return_array=True, **kw)
+    assert single.eps == ref["eps"] and np.array_equal(single.info["theta_all"], ref["theta_all"])
+    comms = k.comm.init_all([0] * world, "p2p")
+    out, err = [None] * world, []
+
+    def run(r):
+        try:
+            out[r] = k.smc(prior, cost, return_array=True, comm=comms[r], **kw)
+        except Exception as e:          # a failing rank must not leave the others in the rendezvous
+            err.append(repr(e))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=600)
+    assert not err and all(o is not None for o in out), err
+    for r in range(world):
+        assert out[r].eps == ref["eps"], r
+        assert np.array_equal(out[r].info["theta_all"], ref["theta_all"]), r
+        assert np.array_equal(out[r].C, single.C) and np.array_equal(out[r].info["alive"], single.info["alive"])
+        assert out[r].info["iterations"] == ref["iterations"]
+        assert out[r].info["cost_evals"] == single.info["cost_evals"]
+        assert out[r].info["proposals"] == single.info["proposals"]
+    for c in comms:
+        c.close()

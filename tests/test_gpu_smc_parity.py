@@ -149,3 +149,17 @@ def test_kernel_path_beyond_the_loop_kernel(k, orc, gpu_ctx, monkeypatch):
     assert got.info["log"] == ref["log"] and got.eps == ref["eps"]
     assert np.array_equal(got.info["theta_all"], ref["theta_all"])
     assert np.array_equal(got.info["alive"], ref["alive"])
+
+
+def test_loop_kernel_giving_up_repeats_the_run_on_the_kernel_path(k, orc, gpu_ctx, monkeypatch):
+    """The persistent loop kernel has an internal capacity (candidates of one histogram bin).
+    When it is exceeded the run is not an error of the user's problem: kabc_smc_run repeats it on
+    the kernel-per-phase path inside the same call (the draws are counter-based: same run)."""
+    prior = k.Factored(k.Normal(0, 2), k.Normal(0, 2))
+    cost = k.costs.GaussDist([0.5, -0.25])
+    kw = dict(nparticles=3000, epstol=0.05, seed=8)
+    ref = orc.smc(prior, cost, **kw)
+    monkeypatch.setenv("KABC_SMC_LOOP_GIVE_UP", "1")
+    r = k.smc(prior, cost, return_array=True, **kw)
+    assert r.eps == ref["eps"] and np.array_equal(r.info["theta_all"], ref["theta_all"])
+    assert r.info["iterations"] == ref["iterations"]

@@ -43,11 +43,23 @@ if f and w:
                "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024),
                "algorithmic_bytes_per_launch": 32768 * 100 * 224, "ntransitions": 100},
               open(os.path.join(O, "pmc_traffic_nt100.json"), "w"), indent=1)
+fs, nfs = means("pmc_fetch_smc", "smc_loop")
+ws, nws = means("pmc_write_smc", "smc_loop")
+if fs and ws:
+    json.dump({"command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) -- python3 tools/smc_c4_probe.py",
+               "kernel": "smc_loop_kernel<16, hier_gauss_sim, SIMPLE> (one launch = the whole C4 run, 190 iterations; "
+                         "mean over the warm-up and the timed launch)",
+               "dispatches": nfs["FETCH_SIZE"], "FETCH_SIZE_KB_mean": fs["FETCH_SIZE"], "WRITE_SIZE_KB_mean": ws["WRITE_SIZE"],
+               "gfx950_correction": "FETCH_SIZE x2 for wide reads (MI355X_MICROARCH.md, HBM)",
+               "hbm_bytes_per_launch": int(2 * fs["FETCH_SIZE"] * 1024 + ws["WRITE_SIZE"] * 1024),
+               "algorithmic_bytes_per_launch": 6225920 * 545},
+              open(os.path.join(O, "pmc_traffic_smc_loop.json"), "w"), indent=1)
+print("smc traffic", fs, ws)
 c, _ = means("pmc_cyc")
 print("insts", json.dumps(insts)[:600])
 print("traffic", f, w)
 print("cycles", c)
-for d in ("stats_nt1", "stats_nt16", "stats_nt100", "smc_stats", "smc_stats_kernels"):
+for d in ("stats_nt1", "stats_nt16", "stats_nt100", "smc_stats", "smc_stats_kernels", "readme_stats"):
     for fn in glob.glob(os.path.join(O, d, "**", "*kernel_stats.csv"), recursive=True):
         print(d, fn)
         print("".join(open(fn).readlines()[:6]))
