@@ -387,6 +387,13 @@ def main():
                             "frac": ups * Bs / 1e9 / HBM_PEAK_GBS,
                             "note": "end to end (select + propose/accept + control), wall clock"},
                "mcmc_kernel_avg_ms": r.info["kernel_ms_mcmc"]}
+        # HBM bytes of the loop kernel (one launch = the whole run) from the committed PMC passes
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_smc_loop.json"))):
+            tj = json.load(open(tf))
+            smc["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+            smc["roofline"]["traffic_vs_algorithmic"] = (tj.get("hbm_bytes_per_launch", 0) /
+                                                         max(1, r.info["proposals"] * Bs))
+            smc["roofline"]["traffic_source"] = os.path.basename(tf)
         if cpu and isinstance(cpu.get("smc_c4"), dict) and "wall_s" in cpu["smc_c4"]:
             smc["cpu_baseline"] = cpu["smc_c4"]
             smc["vs_cpu_port_1core"] = cpu["smc_c4"]["wall_s"] / w
