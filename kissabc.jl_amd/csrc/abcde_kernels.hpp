@@ -51,7 +51,51 @@ struct AbcdeArgs {
     const unsigned* wm_nz;               // [levels]: zeros of the level
     int32_t wm_levels;
     int64_t wm_words;
+    // length(prior) > KABC_MAX_DIM (kernels instantiated with D = 0): the dimension and the
+    // prior as device arrays; rows and proposals then live in per-thread arrays of
+    // KABC_MAX_DIM_DYN doubles (scratch memory) -- a fallback, several times slower per particle
+    int32_t D_rt;
+    const PriorDev* dprior;      // [D_rt] prepared components
+    const kabc_prior_t* draw;    // [D_rt] raw components (prior sampling)
 };
+
+// ---- helpers of the kernels that exist both with a compile-time D (1..KABC_MAX_DIM) and,
+// instantiated with D = 0, with a run-time one (ABCDE, pfilter) -------------------------------
+template <int D>
+struct DimOf {
+    static constexpr int cap = D ? D : KABC_MAX_DIM_DYN;
+    __device__ __forceinline__ static int get(int d_rt) { return D ? D : d_rt; }
+};
+template <int D>
+__device__ __forceinline__ void load_row_n(const double* __restrict__ p, double* out, int n) {
+    if constexpr (D != 0) load_row<D>(p, out);
+    else
+        for (int k = 0; k < n; ++k) out[k] = p[k];
+}
+template <int D>
+__device__ __forceinline__ void store_row_n(double* __restrict__ p, const double* v, int n) {
+    if constexpr (D != 0) store_row<D>(p, v);
+    else
+        for (int k = 0; k < n; ++k) p[k] = v[k];
+}
+// push_p + logpdf(d::Factored, x): compile-time D from the by-value PriorSet, run-time D from
+// the device array (same formulas: comp_logpdf_general_body)
+template <int D>
+__device__ __forceinline__ double logpdf_push_n(const PriorSet& P, const PriorDev* dP, int n,
+                                                const double* x, double* xp) {
+    if constexpr (D != 0) return factored_logpdf_push<D>(P, x, xp);
+    else {
+        double s = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const PriorDev q = dP[k];
+            const double v = q.discrete ? kabc_rint(x[k]) : x[k];
+            xp[k] = v;
+            const double l = comp_logpdf_general_body(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, v);
+            s = (k == 0) ? l : s + l;
+        }
+        return s;
+    }
+}
 
 // k-th smallest (0-based) of the first c indices of the cost-sorted order
 __device__ __forceinline__ unsigned wm_quantile(const AbcdeArgs& A, unsigned c, unsigned k) {
@@ -80,19 +124,22 @@ constexpr int kAbcdeBlock = 64;
 constexpr unsigned kAbcdeMaxInitTries = 100000u;
 
 // θs, logπ, Δs with the re-draw loop of :351-366
-template <int D>
+template <int DT>
 __global__ void __launch_bounds__(kAbcdeBlock) abcde_init_kernel(const AbcdeArgs A) {
     const int64_t i = (int64_t)blockIdx.x * kAbcdeBlock + threadIdx.x;
     if (i >= A.N) return;
-    double x[D], xp[D];
+    constexpr int CAP = DimOf<DT>::cap;
+    const int D = DimOf<DT>::get(A.D_rt);
+    double x[CAP], xp[CAP];
     double lp = 0.0, dl = 0.0;
     for (unsigned attempt = 0;; ++attempt) {
         for (int k = 0; k < D; ++k) {
             kabc_slotwin_t win = {A.seed, (uint64_t)attempt, (uint32_t)i, A.dom_init,
                                   (uint32_t)k * KABC_SLOTS_PER_DIM};
-            x[k] = kabc_sample_prior(&A.raw[k], &win);
+            const kabc_prior_t pr = DT ? A.raw[k] : A.draw[k];
+            x[k] = kabc_sample_prior(&pr, &win);
         }
-        lp = factored_logpdf_push<D>(A.prior, x, xp);
+        lp = logpdf_push_n<DT>(A.prior, A.dprior, D, x, xp);
         kabc_cost_rng_t rng = {A.seed, (uint64_t)attempt, (uint32_t)i, A.dom_init_cost, 0u};
         // first pass: the cost is only evaluated when logπ is finite (:357-359);
         // in the re-draw loop it always is (:364).  cost(θ.x): NOT push_p'ed.
@@ -105,7 +152,7 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_init_kernel(const AbcdeArgs
             break;
         }
     }
-    store_row<D>(A.theta[0] + i * D, x);
+    store_row_n<DT>(A.theta[0] + i * D, x, D);
     A.delta[0][i] = dl;
     A.lpi[0][i] = lp;
 }
@@ -152,9 +199,11 @@ __global__ void __launch_bounds__(1024) abcde_extrema_kernel(const AbcdeArgs A) 
 #endif  // KABC_ABCDE_SINGLE_UNIT
 
 // one generation (:383-412); reads buffer cur, writes buffer 1-cur
-template <int D>
+template <int DT>
 __global__ void __launch_bounds__(kAbcdeBlock) abcde_gen_kernel(const AbcdeArgs A) {
     const int64_t i = (int64_t)blockIdx.x * kAbcdeBlock + threadIdx.x;
+    constexpr int CAP = DimOf<DT>::cap;
+    const int D = DimOf<DT>::get(A.D_rt);
     if (A.ctrl->done) return;
     const int cur = A.ctrl->cur;
     const uint64_t g = (uint64_t)A.ctrl->iters;
@@ -164,8 +213,8 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_gen_kernel(const AbcdeArgs 
     unsigned long long sims = 0;
     if (i < A.N) {
         const int64_t N = A.N;
-        double th[D];
-        load_row<D>(TH + i * D, th);
+        double th[CAP];
+        load_row_n<DT>(TH + i * D, th, D);
         double di = DL[i], li = LP[i];
         const bool skip = A.earlystop && di <= A.eps_target;  // :384-386
         if (!skip) {
@@ -209,13 +258,13 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_gen_kernel(const AbcdeArgs 
             int64_t b = (int64_t)kabc_index(kabc_lo64(B1), (uint64_t)(N - 2));
             b += (b >= lo);
             b += (b >= hi);
-            double ts[D], ta[D], tb[D], tp[D], xp[D];
-            load_row<D>(TH + s * D, ts);
-            load_row<D>(TH + a * D, ta);
-            load_row<D>(TH + b * D, tb);
+            double ts[CAP], ta[CAP], tb[CAP], tp[CAP], xp[CAP];
+            load_row_n<DT>(TH + s * D, ts, D);
+            load_row_n<DT>(TH + a * D, ta, D);
+            load_row_n<DT>(TH + b * D, tb, D);
 #pragma unroll
             for (int k = 0; k < D; ++k) tp[k] = ts[k] + (ta[k] - tb[k]) * A.gamma;  // :402
-            const double lpp = factored_logpdf_push<D>(A.prior, tp, xp);
+            const double lpp = logpdf_push_n<DT>(A.prior, A.dprior, D, tp, xp);
             const double wp = lpp - li;
             double mn = wp;
             if (!(wp < 0.0)) mn = (wp != wp) ? wp : 0.0;  // min(0, w_prior), NaN propagates
@@ -234,7 +283,7 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_gen_kernel(const AbcdeArgs 
                 }
             }
         }
-        store_row<D>(A.theta[1 - cur] + i * D, th);
+        store_row_n<DT>(A.theta[1 - cur] + i * D, th, D);
         A.delta[1 - cur][i] = di;
         A.lpi[1 - cur][i] = li;
     }
@@ -257,6 +306,7 @@ struct AbcdeFinalArgs {
     int64_t N;
     int32_t D;
     PriorSet prior;
+    const PriorDev* dprior;  // [D] on the device when D > KABC_MAX_DIM (else NULL: `prior`)
 };
 __global__ void __launch_bounds__(256) abcde_final_kernel(const AbcdeFinalArgs A) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -264,7 +314,8 @@ __global__ void __launch_bounds__(256) abcde_final_kernel(const AbcdeFinalArgs A
     const int cur = A.ctrl->cur;
     for (int k = 0; k < A.D; ++k) {
         const double v = A.theta[cur][i * A.D + k];
-        A.out[i * A.D + k] = A.prior.c[k].discrete ? kabc_rint(v) : v;
+        const bool disc = A.dprior ? (A.dprior[k].discrete != 0) : (A.prior.c[k].discrete != 0);
+        A.out[i * A.D + k] = disc ? kabc_rint(v) : v;
     }
     A.dout[i] = A.delta[cur][i];
 }

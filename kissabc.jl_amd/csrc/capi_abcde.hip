@@ -136,8 +136,15 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         return KABC_ERR_INVALID_ARG;
     }
     const int64_t N = o->nparticles;
-    if (D < 1 || D > KABC_MAX_DIM) {
-        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM);
+    if (D < 1 || D > KABC_MAX_DIM_DYN) {
+        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM_DYN);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    // length(prior) > KABC_MAX_DIM: the run-time-dimension instantiation (D = 0) of the kernels,
+    // prior components as device arrays (built-in DeviceCosts)
+    const bool dyn = D > KABC_MAX_DIM;
+    if (dyn && cost->id >= KABC_COST_USER) {
+        set_error("ABCDE with length(prior) = %d > %d: built-in DeviceCosts only", D, KABC_MAX_DIM);
         return KABC_ERR_UNSUPPORTED;
     }
     if (N < 3 || N >= (1ll << 31)) {  // three distinct indices s, a, b are drawn (:394-401)
@@ -146,7 +153,13 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     }
     AbcdeArgs A;
     std::memset(&A, 0, sizeof A);
-    if (!prepare_priors(prior, D, A.prior)) {
+    std::vector<PriorDev> Pdyn((size_t)(dyn ? D : 0));
+    bool prior_ok = true;
+    if (dyn)
+        for (int k = 0; k < D && prior_ok; ++k) prior_ok = prepare_prior(prior[k], Pdyn[k]);
+    else
+        prior_ok = prepare_priors(prior, D, A.prior);
+    if (!prior_ok) {
         set_error("invalid prior parameters");
         return KABC_ERR_INVALID_ARG;
     }
@@ -155,7 +168,10 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         return KABC_ERR_UNSUPPORTED;
     }
     AbcdeLaunch f_init, f_gen;
-    if (const CostPlugin* p = find_plugin(cost->id)) {
+    if (dyn) {
+        f_init = AbcdeLaunch(&l_init<0>);
+        f_gen = AbcdeLaunch(&l_gen<0>);
+    } else if (const CostPlugin* p = find_plugin(cost->id)) {
         const PluginKernel ki = plugin_kernel(p, kPfAbcdeInit, D, 0), kg = plugin_kernel(p, kPfAbcdeGen, D, 0);
         f_init = ki.host ? AbcdeLaunch((AbcdeLaunchFn)ki.host)
                          : ki.mod ? AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
@@ -169,7 +185,7 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         f_init = pick_init(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
         f_gen = pick_gen(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
     }
-    std::memcpy(A.raw, prior, sizeof(kabc_prior_t) * D);
+    if (!dyn) std::memcpy(A.raw, prior, sizeof(kabc_prior_t) * D);
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     std::vector<void*> bufs;
@@ -194,6 +210,17 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     KABC_HIP_CHECK(alloc((void**)&d_out, sizeof(double) * N * D));
     KABC_HIP_CHECK(alloc((void**)&d_dout, sizeof(double) * N));
     KABC_HIP_CHECK(hipMemsetAsync(A.ctrl, 0, sizeof(AbcdeCtrl), s));
+    PriorDev* d_prior = nullptr;
+    kabc_prior_t* d_raw = nullptr;
+    if (dyn) {
+        KABC_HIP_CHECK(alloc((void**)&d_prior, sizeof(PriorDev) * D));
+        KABC_HIP_CHECK(alloc((void**)&d_raw, sizeof(kabc_prior_t) * D));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_prior, Pdyn.data(), sizeof(PriorDev) * D, hipMemcpyHostToDevice, s));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_raw, prior, sizeof(kabc_prior_t) * D, hipMemcpyHostToDevice, s));
+    }
+    A.D_rt = D;
+    A.dprior = d_prior;
+    A.draw = d_raw;
     if (cost->nparams > 0) {
         KABC_HIP_CHECK(alloc((void**)&d_params, sizeof(double) * cost->nparams));
         KABC_HIP_CHECK(hipMemcpyAsync(d_params, cost->params, sizeof(double) * cost->nparams,
@@ -267,6 +294,7 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     F.N = N;
     F.D = D;
     F.prior = A.prior;
+    F.dprior = d_prior;
     hipLaunchKernelGGL(abcde_final_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, F);
     KABC_HIP_CHECK(hipGetLastError());
     AbcdeCtrl hc;

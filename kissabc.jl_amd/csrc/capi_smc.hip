@@ -805,16 +805,26 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         set_error("kabc_pfilter_run: NULL argument");
         return KABC_ERR_INVALID_ARG;
     }
-    if (D < 1 || D > KABC_MAX_DIM) {
-        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM);
+    if (D < 1 || D > KABC_MAX_DIM_DYN) {
+        set_error("length(prior) = %d is outside the device path's range 1..%d", D, KABC_MAX_DIM_DYN);
         return KABC_ERR_UNSUPPORTED;
     }
     if (!(o->q > 0 && o->q <= 1) || o->nparticles < 1) {
         set_error("pfilter needs 0 < q <= 1 and N >= 1");
         return KABC_ERR_INVALID_ARG;
     }
+    // length(prior) > KABC_MAX_DIM: the run-time-dimension instantiation (D = 0) of the kernels,
+    // prior components as device arrays
+    const bool dyn = D > KABC_MAX_DIM;
     PriorSet P;
-    if (!prepare_priors(prior, D, P)) {
+    std::memset(&P, 0, sizeof P);
+    std::vector<PriorDev> Pdyn((size_t)(dyn ? D : 0));
+    bool prior_ok = true;
+    if (dyn)
+        for (int k = 0; k < D && prior_ok; ++k) prior_ok = prepare_prior(prior[k], Pdyn[k]);
+    else
+        prior_ok = prepare_priors(prior, D, P);
+    if (!prior_ok) {
         set_error("invalid prior parameters");
         return KABC_ERR_INVALID_ARG;
     }
@@ -824,7 +834,14 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     }
     AbcdeLaunch f_init;
     PfLaunch f_att;
-    if (const CostPlugin* p = find_plugin(cost->id)) {
+    if (dyn && cost->id >= KABC_COST_USER) {
+        set_error("pfilter with length(prior) = %d > %d: built-in DeviceCosts only", D, KABC_MAX_DIM);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    if (dyn) {
+        f_init = AbcdeLaunch(&pf_l_init<0>);
+        f_att = PfLaunch(&pf_l_attempt<0>);
+    } else if (const CostPlugin* p = find_plugin(cost->id)) {
         const PluginKernel ki = plugin_kernel(p, kPfAbcdeInit, D, 0), ka = plugin_kernel(p, kPfAttempt, D, 0);
         f_init = ki.host ? AbcdeLaunch((AbcdeLaunchFn)ki.host)
                          : ki.mod ? AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
@@ -865,6 +882,14 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     KABC_HIP_CHECK(hipMemsetAsync(sel, 0, sizeof(SmcCtrl), s));
     KABC_HIP_CHECK(hipMemsetAsync(pctrl, 0, sizeof(PfCtrl), s));
     KABC_HIP_CHECK(hipMemsetAsync(actrl, 0, sizeof(AbcdeCtrl), s));
+    PriorDev* d_prior = nullptr;
+    kabc_prior_t* d_raw = nullptr;
+    if (dyn) {
+        KABC_HIP_CHECK(bufs.alloc(&d_prior, (size_t)D));
+        KABC_HIP_CHECK(bufs.alloc(&d_raw, (size_t)D));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_prior, Pdyn.data(), sizeof(PriorDev) * D, hipMemcpyHostToDevice, s));
+        KABC_HIP_CHECK(hipMemcpyAsync(d_raw, prior, sizeof(kabc_prior_t) * D, hipMemcpyHostToDevice, s));
+    }
     if (cost->nparams > 0) {
         KABC_HIP_CHECK(bufs.alloc(&d_params, (size_t)cost->nparams));
         KABC_HIP_CHECK(hipMemcpyAsync(d_params, cost->params, sizeof(double) * cost->nparams,
@@ -892,7 +917,10 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         a.dom_init = KABC_DOM_PF_INIT;
         a.dom_init_cost = KABC_DOM_PF_INIT_COST;
         a.prior = P;
-        std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
+        a.D_rt = D;
+        a.dprior = d_prior;
+        a.draw = d_raw;
+        if (!dyn) std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
         f_init(a, s);
         KABC_HIP_CHECK(hipGetLastError());
         AbcdeCtrl hc;
@@ -938,6 +966,8 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     pa.cost_id = cost->id;
     pa.proposal_width = o->proposal_width;
     pa.prior = P;
+    pa.D_rt = D;
+    pa.dprior = d_prior;
     int64_t iters = 0;
     double eps = 0.0, eff = 0.0;
     SmcCtrl hsel;
@@ -994,7 +1024,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     fa.N = N;
     fa.D = D;
     fa.prior = P;
-    fa.dprior = nullptr;
+    fa.dprior = d_prior;
     hipLaunchKernelGGL(smc_finalize_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, fa);
     KABC_HIP_CHECK(hipGetLastError());
     if (res->theta)

@@ -7,6 +7,7 @@
 #pragma once
 
 #include "kabc_device.hpp"
+#include "abcde_kernels.hpp"
 #include "smc_kernels.hpp"
 
 namespace kabc {
@@ -36,6 +37,8 @@ struct PfArgs {
     int32_t cost_id;
     double proposal_width;
     PriorSet prior;
+    int32_t D_rt;               // length(prior) > KABC_MAX_DIM: kernels instantiated with D = 0
+    const PriorDev* dprior;     // [D_rt] prepared components on the device
 };
 
 constexpr int kPfBlock = 64;
@@ -54,9 +57,11 @@ __global__ void __launch_bounds__(256) pf_mark_kernel(uint8_t* pending, const ui
 
 #endif  // KABC_SMC_SINGLE_UNIT
 
-template <int D>
+template <int DT>
 __global__ void __launch_bounds__(kPfBlock) pf_attempt_kernel(const PfArgs A) {
     const int64_t i = (int64_t)blockIdx.x * kPfBlock + threadIdx.x;
+    constexpr int CAP = DimOf<DT>::cap;
+    const int D = DimOf<DT>::get(A.D_rt);
     unsigned long long reps = 0, evals = 0, done = 0;
     if (i < A.N && A.pending[i]) {
         const uint64_t nok = (uint64_t)A.sel->ess;
@@ -78,14 +83,14 @@ __global__ void __launch_bounds__(kPfBlock) pf_attempt_kernel(const PfArgs A) {
         double z0, z1;
         kabc_normal_pair(kabc_lo64(B2), kabc_hi64(B2), &z0, &z1);
         const double sc = z0 * A.proposal_width;  // randn(trng)*proposal_width
-        double tb[D], tc[D], td[D], p[D], xp[D];
-        load_row<D>(A.theta + b * D, tb);
-        load_row<D>(A.theta + c * D, tc);
-        load_row<D>(A.theta + d * D, td);
+        double tb[CAP], tc[CAP], td[CAP], p[CAP], xp[CAP];
+        load_row_n<DT>(A.theta + b * D, tb, D);
+        load_row_n<DT>(A.theta + c * D, tc, D);
+        load_row_n<DT>(A.theta + d * D, td, D);
 #pragma unroll
         for (int k = 0; k < D; ++k) p[k] = tb[k] + (td[k] - tc[k]) * sc;  // :312
         reps = 1;
-        const double ll = factored_logpdf_push<D>(A.prior, p, xp);
+        const double ll = logpdf_push_n<DT>(A.prior, A.dprior, D, p, xp);
         const double wp = ll - A.lpi[i];
         double mn = wp;
         if (!(wp < 0.0)) mn = (wp != wp) ? wp : 0.0;  // min(0.0, ll - logπ[i])
@@ -96,7 +101,7 @@ __global__ void __launch_bounds__(kPfBlock) pf_attempt_kernel(const PfArgs A) {
                                              A.cost_ndata, &rng);  // cost(p.x): NOT push_p'ed
             evals = 1;
             if (!(Cp > eps)) {  // :320-322
-                store_row<D>(A.theta + i * D, p);
+                store_row_n<DT>(A.theta + i * D, p, D);
                 A.C[i] = Cp;
                 A.lpi[i] = ll;
                 A.pending[i] = 0;

@@ -65,3 +65,19 @@ def test_abcde_rank_structure_bit_exact(k, orc, gpu_ctx, name):
     ref = orc.abcde(pri, cost, eps, seed=9, **kw)
     assert np.array_equal(got.P, ref["P"]) and np.array_equal(got.C, ref["C"])
     assert got.info["generations_run"] == ref["generations_run"] and got.info["nsims"] == ref["nsims"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [17, 40])
+def test_abcde_beyond_16_parameters_bit_exact(k, orc, gpu_ctx, D):
+    """length(prior) > 16 (the reference has no bound, src/priors.jl:10-13): the run-time-dimension
+    instantiation of the same kernels (rows in per-thread arrays), bit-exact; mixed families."""
+    comps = [k.Normal(0, 2), k.Uniform(-3, 3), k.Gamma(2.5, 0.7), k.DiscreteUniform(-4, 4)]
+    pri = k.Factored(*[comps[j % 4] for j in range(D)])
+    cost = k.costs.GaussDist(np.linspace(-0.5, 1.5, D))
+    kw = dict(nparticles=400, generations=25, proposal_width=0.9)
+    got = k.ABCDE(pri, cost, 3.0, seed=5, return_array=True, **kw)
+    ref = orc.abcde(pri, cost, 3.0, seed=5, **kw)
+    assert got.P.shape == (400, D)
+    assert np.array_equal(got.P, ref["P"]) and np.array_equal(got.C, ref["C"])
+    assert got.info["generations_run"] == ref["generations_run"] and got.info["nsims"] == ref["nsims"]

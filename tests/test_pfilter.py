@@ -38,3 +38,20 @@ def test_pfilter_bit_exact(k, orc, gpu_ctx, name):
     assert np.array_equal(got.C, ref["C"])
     assert got.info["eps"] == ref["eps"] and got.info["iterations"] == ref["iterations"]
     assert got.info["nreps"] == ref["nreps"] and got.info["eff"] == ref["eff"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D", [17, 33])
+def test_pfilter_beyond_16_parameters_bit_exact(k, orc, gpu_ctx, D):
+    """length(prior) > 16: the run-time-dimension instantiation of the attempt / init kernels
+    (and the N*q <= 4 length(prior) enlargement rule at these sizes), bit-exact."""
+    comps = [k.Normal(0, 2), k.Uniform(-3, 3), k.LogNormal(0.1, 0.4), k.DiscreteUniform(-4, 4)]
+    pri = k.Factored(*[comps[j % 4] for j in range(D)])
+    cost = k.costs.NormShell(2.0 * np.sqrt(D))
+    kw = dict(max_iters=6, proposal_width=0.6, eff_tol=0.0)
+    got = k.pfilter(pri, cost, 200, seed=6, return_array=True, **kw)
+    ref = orc.pfilter(pri, cost, 200, seed=6, **kw)
+    assert got.P.shape == ref["P"].shape and got.P.shape[1] == D
+    assert np.array_equal(got.P, ref["P"]) and np.array_equal(got.C, ref["C"])
+    assert got.info["eps"] == ref["eps"] and got.info["iterations"] == ref["iterations"]
+    assert got.info["nreps"] == ref["nreps"]
