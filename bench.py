@@ -170,6 +170,12 @@ def cpu_baseline(k, budget_s, with_smc):
         out["readme_c1"] = {"wall_s": w, "transitions_per_s": 1000 * NT_HEADLINE / w, "cores": 1,
                             "kind": "port", "sample": "oracle ref_serial: AIS(10), 1000 step() calls x "
                                                       "ntransitions=100, 1000 normals per cost (README.md:31-57)"}
+        t0 = time.perf_counter()
+        rs = orc.smc(readme_problem(k).prior, readme_problem(k).cost, nparticles=100, seed=1)
+        w = time.perf_counter() - t0
+        out["readme_smc"] = {"wall_s": w, "iterations": rs["iterations"], "cores": 1, "kind": "port",
+                             "sample": "oracle smc (src/smc.jl:92-206) with its defaults (100 particles) on the "
+                                       "README simulator (README.md:80-84)"}
         o = orc.OracleAIS(c2_problem(k), 4096, seed=1).init()
         o.steps_serial(4096, NT_HEADLINE, collect=False)
         n, t0 = 0, time.perf_counter()
@@ -351,6 +357,23 @@ def main():
         if cpu and isinstance(cpu.get("readme_c1"), dict) and "wall_s" in cpu["readme_c1"]:
             extra["readme_c1"]["cpu_baseline"] = cpu["readme_c1"]
             extra["readme_c1"]["vs_cpu_port_1core"] = cpu["readme_c1"]["wall_s"] / w
+        # README.md:80-84: `smc(prior, cost)` with its defaults on the same simulator
+        for _ in range(2):
+            k.smc(rm.prior, rm.cost, nparticles=100, seed=1, ctx=ctx, return_array=True)
+        walls = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            rs = k.smc(rm.prior, rm.cost, nparticles=100, seed=1, ctx=ctx, return_array=True)
+            walls.append(time.perf_counter() - t0)
+        w = sorted(walls)[len(walls) // 2]
+        extra["readme_smc"] = {"workload": "README.md:80-84: smc(prior, cost), defaults (100 particles), "
+                                           "1000 normals per cost evaluation",
+                               "wall_ms": w * 1e3, "iterations": rs.info["iterations"], "eps": rs.eps,
+                               "posterior_mean": rs.P.mean(0).tolist(),
+                               "reference_documented": "2.0 +- 0.0062, 0.0401 +- 0.00081, eps 0.0111 (README.md:84)"}
+        if cpu and isinstance(cpu.get("readme_smc"), dict) and "wall_s" in cpu["readme_smc"]:
+            extra["readme_smc"]["cpu_baseline"] = cpu["readme_smc"]
+            extra["readme_smc"]["vs_cpu_port_1core"] = cpu["readme_smc"]["wall_s"] / w
         # BASELINE.json configs[1]
         extra["c2"] = dict(kernel_leg(c2_problem(k), 4096, 2, nts=(NT_HEADLINE, 16)),
                            workload="C2: AIS 4096 walkers, D=2, Normal(0,5)^2, gauss_dist, scale 0.1 "

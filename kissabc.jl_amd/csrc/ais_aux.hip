@@ -15,11 +15,13 @@ __global__ void __launch_bounds__(kAuxBlock) aux_normal_meanstd_kernel(const Aux
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & (kWave - 1);
     const int64_t item = (int64_t)blockIdx.x * (kAuxBlock / kWave) + wave;
     if (item >= A.rows * A.nt) return;
+    if (A.skip_if && *A.skip_if) return;
     const int64_t s = item / A.rows, r = item - s * A.rows;
     const uint64_t seed = A.seeds ? A.seeds[blockIdx.y] : A.seed;
     double* aux = A.aux + (A.seeds ? (int64_t)blockIdx.y * A.stride_aux : 0);
-    kabc_cost_rng_t rng = {seed, A.t0 + (uint64_t)s, A.id_base + (uint32_t)(A.row_first + r),
-                           KABC_DOM_AIS_COST, 0u, 0u, nullptr, slogtab};
+    const uint64_t t0 = A.t_dev ? (uint64_t)*A.t_dev + 1u : A.t0;
+    kabc_cost_rng_t rng = {seed, t0 + (uint64_t)s, A.id_base + (uint32_t)(A.row_first + r),
+                           A.domain ? A.domain : KABC_DOM_AIS_COST, 0u, 0u, nullptr, slogtab};
     const int n = (int)A.cost_params[0];
     static_assert(KABC_SIM_LANES == kWave, "one slice of the draws per lane");
     double sz, szz;
@@ -31,8 +33,9 @@ __global__ void __launch_bounds__(kAuxBlock) aux_normal_meanstd_kernel(const Aux
         szz = szz + __shfl_xor(szz, off, kWave);
     }
     if (lane == 0) {
-        aux[(s * 2 + 0) * A.rows + r] = sz;
-        aux[(s * 2 + 1) * A.rows + r] = szz;
+        const int64_t ws = A.word_stride ? A.word_stride : A.rows;
+        aux[(s * 2 + 0) * ws + r] = sz;
+        aux[(s * 2 + 1) * ws + r] = szz;
     }
 }
 

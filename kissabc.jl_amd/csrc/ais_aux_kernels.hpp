@@ -31,6 +31,13 @@ struct AuxArgs {
     int32_t nt;
     const uint64_t* seeds;   // batched chains (blockIdx.y = chain), else NULL
     int64_t stride_aux;      // doubles per chain
+    // smc (kernel-per-phase path): the stream domain (0 = KABC_DOM_AIS_COST), the pass counter
+    // read from the device (t = *t_dev + 1: the host enqueues passes without knowing which of them
+    // still run), the distance between the words of one row (0 = rows) and the run's control block
+    uint32_t domain;
+    const unsigned long long* t_dev;
+    int64_t word_stride;
+    const int32_t* skip_if;  // the kernel is a no-op while *skip_if != 0 (smc: the loop is over)
 };
 
 // does a grid-wide pre-pass exist for this cost?  (built-ins only: a user cost's prepare step is

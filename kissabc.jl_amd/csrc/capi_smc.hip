@@ -6,6 +6,7 @@
 #include <vector>
 
 #define KABC_SMC_SINGLE_UNIT 1
+#include "ais_aux_kernels.hpp"
 #include "host_common.hpp"
 #include "plugin_registry.hpp"
 #include "smc_loop_kernel.hpp"
@@ -501,6 +502,35 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         ma.nwg = wg_n;
         ma.slots = slots + (size_t)rank * kSmcSlots * 8;  // this rank's block of counter lines
     }
+    // A prepared built-in cost (README.md:43-49's simulator): its parameter-independent sums for
+    // EVERY particle of a pass come from a grid-wide pre-pass, one wavefront per cost evaluation
+    // (ais_aux_kernels.hpp), instead of 500 Box-Muller pairs one after the other in the particle's
+    // own lane.  That needs a launch per pass: such costs take the kernel-per-phase path.
+    const int auxW = dyn ? 0 : aux_prepass_words(cost->id);
+    double* d_aux = nullptr;
+    AuxArgs xa;
+    std::memset(&xa, 0, sizeof xa);
+    if (auxW) {
+        KABC_HIP_CHECK(bufs.alloc(&d_aux, (size_t)auxW * N));
+        xa.aux = d_aux + (comm ? wg_lo * kSmcBlock : 0);
+        xa.cost_params = d_params;
+        xa.cost_data = d_data;
+        xa.cost_ndata = cost->ndata;
+        xa.row_first = comm ? wg_lo * kSmcBlock : 0;
+        xa.rows = comm ? std::min<int64_t>(wg_n * kSmcBlock, N - wg_lo * kSmcBlock) : N;
+        if (xa.rows < 0) xa.rows = 0;
+        xa.seed = o->seed;
+        xa.nt = 1;
+        xa.domain = KABC_DOM_SMC_COST;
+        xa.t_dev = &ctrl->pass;
+        xa.word_stride = N;
+        xa.skip_if = &ctrl->done;
+        ma.aux = d_aux;
+    }
+    auto run_pass = [&](hipStream_t st) {  // one propose / accept pass (+ its pre-pass)
+        if (auxW) launch_aux_prepass(cost->id, xa, st, 1);
+        mcmc(ma, st);
+    };
     SmcLoopParams lpz;
     lpz.mcmc_tol = o->mcmc_tol;
     lpz.epstol = o->epstol;
@@ -518,7 +548,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     bool looped = false;
     {
         const char* env = std::getenv("KABC_SMC_LOOP");  // read per call: tests flip it
-        const bool allow = !(env && env[0] == '0') && !tl_smc_no_loop && !comm;
+        const bool allow = !(env && env[0] == '0') && !tl_smc_no_loop && !comm && !auxW;
         const unsigned G = (unsigned)((N + kLoopBlock - 1) / kLoopBlock);
         SmcLoopLaunch loop_fn =
             (allow && !dyn && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple) : SmcLoopLaunch();
@@ -607,7 +637,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         for (int r = 0; r < R && !hc.done && hc.pass_open; ++r) {
             const bool timed = (mcmc_timed == 0 && r == 0);
             if (timed) KABC_HIP_CHECK(hipEventRecord(ev0, s));
-            mcmc(ma, s);
+            run_pass(s);
             if (timed) KABC_HIP_CHECK(hipEventRecord(ev1, s));
             KABC_HIP_CHECK(hipGetLastError());
             if (kabc_status_t st = exchange(1 - hc.cur, true)) return st;
@@ -644,7 +674,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                     const bool timed = (it == 0 && r == 0);
                     if (timed) KABC_HIP_CHECK(hipEventRecord(ev0, s));
                     if (dyn) dyn_fn(da, s, 0);
-                    else mcmc(ma, s);
+                    else run_pass(s);
                     if (timed) KABC_HIP_CHECK(hipEventRecord(ev1, s));
                     ended = (r == R - 1);
                     hipLaunchKernelGGL(smc_pass_end_kernel, dim3(1), dim3(kSmcSlots), 0, s, ctrl,

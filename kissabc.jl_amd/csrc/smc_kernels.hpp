@@ -130,6 +130,8 @@ struct SmcMcmcArgs {
     unsigned long long* part;  // [workgroups][4], see smc_block_stats
     int64_t wg0, nwg;          // sharded cost loop: the workgroups of this launch ...
     int32_t sharded;           // ... when set, else all
+    // prepared cost words of this pass for every particle, [W][N] (ais_aux_kernels.hpp), or NULL
+    const double* aux;
 };
 
 struct SmcFinalArgs {
@@ -833,6 +835,10 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
                 if (!(lM < 0.0)) lM = (lM != lM) ? lM : 0.0;
                 if (lprob < lM) {
                     kabc_cost_rng_t rng = {A.seed, pass, w, KABC_DOM_SMC_COST, 0u};
+                    if (A.aux) {
+                        rng.aux = A.aux + i;
+                        rng.aux_stride = (uint32_t)A.N;
+                    }
                     const double Xp =
                         eval_cost<COST, D>(xp, A.cost_params, A.cost_data, A.cost_ndata, &rng);
                     n_eval = 1;

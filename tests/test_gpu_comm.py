@@ -230,7 +230,8 @@ def test_bench_under_the_drivers_launcher():
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0
 
 
-@pytest.mark.parametrize("world,N,name", [(2, 3000, "gauss"), (4, 1000, "mixture_retrys"), (3, 5001, "hier")])
+@pytest.mark.parametrize("world,N,name", [(2, 3000, "gauss"), (4, 1000, "mixture_retrys"), (3, 5001, "hier"),
+                                          (3, 700, "readme_sim")])
 def test_smc_sharded_cost_loop_matches_single_gpu_and_oracle(k, orc, gpu_ctx, world, N, name):
     """kabc_smc_run_dist: the reference's parallel leg (src/smc.jl:120-123,168) across ranks --
     every rank holds the ensemble, evaluates prior-MH + cost for its blocks of 64 particles,
@@ -245,6 +246,10 @@ def test_smc_sharded_cost_loop_matches_single_gpu_and_oracle(k, orc, gpu_ctx, wo
     elif name == "mixture_retrys":
         prior, cost = k.Uniform(-10, 10), k.costs.Mixture(0.0)
         kw = dict(nparticles=N, mcmc_retrys=3, epstol=0.2, seed=5)
+    elif name == "readme_sim":   # the expensive simulator sharding is for; its pre-pass per shard
+        prior = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
+        cost = k.costs.NormalMeanStdSim(400, 2.0012, 0.0401)
+        kw = dict(nparticles=N, epstol=0.03, seed=3)
     else:
         prior = k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 6)
         cost = k.costs.HierGaussSim(rng.normal(size=6))

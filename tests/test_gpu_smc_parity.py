@@ -28,6 +28,14 @@ def _cases(k):
                             dict(nparticles=4096, alpha=0.95, epstol=0.05)),
         "gauss_d2_minress": (N2, k.costs.GaussDist([1.0, -0.5]),
                              dict(nparticles=3000, min_r_ess=0.55, epstol=0.02)),
+        # README.md:31-49,80-84: `smc(prior, cost)` with its defaults on the 1000-draw simulator
+        # (a prepared cost: the pre-pass of every pass, one wavefront per evaluation), and a
+        # larger ensemble with retry passes and an odd number of draws
+        "readme_defaults": (k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100)),
+                            k.costs.NormalMeanStdSim(1000, 2.0012, 0.0401), dict()),
+        "readme_sim_retrys": (k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100)),
+                              k.costs.NormalMeanStdSim(301, 2.0012, 0.0401),
+                              dict(nparticles=1500, mcmc_retrys=2, epstol=0.02)),
     }
 
 
@@ -41,7 +49,8 @@ def smc_path(request, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["banana", "banana_inf", "dirac", "defaults_du",
-                                  "mixture_retrys", "C4_hier16_small", "gauss_d2_minress"])
+                                  "mixture_retrys", "C4_hier16_small", "gauss_d2_minress",
+                                  "readme_defaults", "readme_sim_retrys"])
 def test_smc_bit_exact(k, orc, gpu_ctx, name, smc_path):
     prior, cost, kw = _cases(k)[name]
     got = k.smc(prior, cost, seed=5, return_array=True, **kw)
