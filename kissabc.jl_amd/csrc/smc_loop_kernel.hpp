@@ -69,6 +69,17 @@ struct SmcLoopScratch {  // zeroed by the host before the launch
     // that just ended), [1] evaluated | proposed << 21, [2] min alive key, [3] ~max alive key
     unsigned long long part[2][kLoopMaxG][4];
     unsigned long long succ[2][kLoopMaxG];  // gather round: min alive key above the bin
+    // XCD-aware barrier (below): one 128-byte line per word
+    struct Line {
+        unsigned long long v, pad[15];
+    };
+    Line xmembers[16];  // workgroups per XCD (counted once, in the prologue)
+    Line nxcd;          // XCDs that hold at least one workgroup
+    Line xcount[16];    // arrivals per XCD
+    Line gcount;        // XCDs that have arrived
+    Line gen2;          // generation of the XCD-aware barrier
+    Line ticket[16];    // first workgroup of an XCD to leave a barrier
+    Line xflag[16];     // the XCD's L2 has been invalidated for generation v
 };
 
 struct SmcLoopArgs {
@@ -131,56 +142,130 @@ __device__ __forceinline__ unsigned long long wave_sum_all(unsigned long long v)
     return v;
 }
 
-// Device-wide barrier number `nb` (0-based) of the G resident workgroups.  A monotonically
-// increasing arrival counter (no reset) and a generation word on its own cache line: the
-// workgroup whose arrival completes the count publishes generation nb + 1, the others poll
-// that word (polling the counter itself slows the arrivals: measured 2x).  No load precedes
-// the atomic: every workgroup knows nb.  wait() returns false on time-out / abort (uniform
-// over the workgroup).
-// (the part thread 0 runs once every wavefront's global writes have left: after a __syncthreads)
-__device__ __forceinline__ void loop_barrier_arrive_t0(SmcLoopScratch* g, unsigned G, unsigned nb) {
-    const unsigned long long target = (unsigned long long)(nb + 1u) * G;
-    __threadfence();  // release: this workgroup's global writes are out before it arrives
-    if (atomicAdd(&g->bar_count, 1ull) + 1ull == target) {
-        __threadfence();
-        atomicExch(&g->bar_gen, nb + 1u);
-    }
-}
-__device__ __forceinline__ void loop_barrier_arrive(SmcLoopScratch* g, unsigned G, unsigned nb) {
+// ---- device-wide barriers ---------------------------------------------------------------
+// PLAIN barrier number `nb` (0-based) of the G resident workgroups: a monotonically increasing
+// arrival counter (no reset) and a generation word on its own cache line; every workgroup gives
+// an agent-scope release before it arrives and an agent-scope acquire after it leaves.  On
+// gfx950 those two fences are most of the barrier (tools/halfgen_floor_probe.hip: 5.3 us at 128
+// workgroups, 2.4 us without them): a release writes the XCD's whole L2 back, an acquire
+// invalidates it, and every one of the 16 workgroups of an XCD does both.  Used ONCE, in the
+// prologue (it publishes the XCD populations the barrier below needs).
+__device__ __forceinline__ bool loop_plain_barrier(SmcLoopScratch* g, unsigned G, unsigned nb, int* s_ok) {
     __syncthreads();
-    if (threadIdx.x == 0) loop_barrier_arrive_t0(g, G, nb);
-}
-__device__ __forceinline__ bool loop_barrier_wait(SmcLoopScratch* g, unsigned nb, int* s_ok) {
     if (threadIdx.x == 0) {
         int ok = 1;
+        __threadfence();
+        if (atomicAdd(&g->bar_count, 1ull) + 1ull == (unsigned long long)(nb + 1u) * G) {
+            __threadfence();
+            atomicExch(&g->bar_gen, nb + 1u);
+        }
         volatile unsigned* gen = &g->bar_gen;
-        volatile unsigned* ab = &g->abort_flag;
-        if (*gen < nb + 1u) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            unsigned spins = 0;
-            while (*gen < nb + 1u) {
-                __builtin_amdgcn_s_sleep(1);
-                if ((++spins & 1023u) == 0u) {
-                    if (*ab || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {  // 5 s @ 100 MHz
-                        atomicExch(&g->abort_flag, 1u);
-                        ok = 0;
-                        break;
-                    }
-                }
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        while (*gen < nb + 1u) {
+            __builtin_amdgcn_s_sleep(1);
+            if ((++spins & 1023u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {
+                atomicExch(&g->abort_flag, 1u);
+                ok = 0;
+                break;
             }
         }
-        if (*ab) ok = 0;
-        __threadfence();  // acquire
+        __threadfence();
         *s_ok = ok;
     }
     __syncthreads();
     return *s_ok != 0;
 }
-// split phase: work placed between arrive and wait runs in the shadow of the barrier's
-// latency (the arrivals of the other workgroups, the release of the last one)
-__device__ __forceinline__ bool loop_barrier(SmcLoopScratch* g, unsigned G, unsigned nb, int* s_ok) {
-    loop_barrier_arrive(g, G, nb);
-    return loop_barrier_wait(g, nb, s_ok);
+
+// XCD-AWARE barrier (round 3; tools/xcd_barrier_probe.hip: rows written, barrier, random rows of
+// other workgroups read and checked -- 9.4 -> 4.1 us per iteration at 128 workgroups, 33 -> 6.4 us
+// at 512, no mismatch).  The cross-XCD coherence is paid once per XCD instead of once per
+// workgroup:
+//   arrive : a workgroup waits for its own stores (they are then in its XCD's L2, which all its
+//            XCD's workgroups share) and counts itself on the XCD's counter; the LAST workgroup
+//            of an XCD writes that L2 back (buffer_wbl2 sc1: every workgroup's dirty lines) and
+//            counts the XCD on the global counter; the last XCD publishes the generation.
+//   wait   : every workgroup polls the generation and then invalidates its CU's L1 and the XCD's
+//            L2 (buffer_inv sc1), as before.
+// The XCD of a workgroup is HW_REG_XCC_ID; the populations are counted in the kernel's prologue
+// (nothing is assumed about the dispatcher's placement).  Arrive and wait stay separate calls:
+// work placed between them runs in the shadow of the barrier.  wait() returns false on time-out
+// / abort (uniform over the workgroup); the spins are bounded (5 s of s_memrealtime).
+struct LoopXcd {
+    unsigned xcd, members, nxcd;
+};
+__device__ __forceinline__ unsigned loop_xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xfu;
+}
+__device__ __forceinline__ unsigned long long loop_ld(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// thread 0; false on time-out or abort
+__device__ __forceinline__ bool loop_spin(SmcLoopScratch* g, const unsigned long long* p,
+                                          unsigned long long want) {
+    if (loop_ld(p) >= want) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    volatile unsigned* ab = &g->abort_flag;
+    unsigned spins = 0;
+    while (loop_ld(p) < want) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 1023u) == 0u) {
+            if (*ab || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) {  // 5 s @ 100 MHz
+                atomicExch(&g->abort_flag, 1u);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+// (the part thread 0 runs once every wavefront's global writes have completed: after a
+// __syncthreads; its own stores since then -- the workgroup's record -- are waited for here)
+__device__ __forceinline__ void loop_barrier_arrive_t0(SmcLoopScratch* g, const LoopXcd& X, unsigned nb) {
+#ifdef KABC_XBAR_PLAIN  // the round-2 barrier, for A/B runs: every workgroup releases at agent scope
+    __threadfence();
+    if (atomicAdd(&g->gcount.v, 1ull) + 1ull == (unsigned long long)(nb + 1u) * gridDim.x) {
+        __threadfence();
+        __hip_atomic_store(&g->gen2.v, (unsigned long long)(nb + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#ifdef KABC_XBAR_EARLYWB
+    // start writing back what is dirty NOW (not waited for): the last arrival's write-back then
+    // finds little left, as with the plain barrier, where early arrivals flush while they wait
+    asm volatile("buffer_wbl2 sc1" ::: "memory");
+#endif
+    if (atomicAdd(&g->xcount[X.xcd].v, 1ull) + 1ull == (unsigned long long)(nb + 1u) * X.members) {
+        asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+        if (atomicAdd(&g->gcount.v, 1ull) + 1ull == (unsigned long long)(nb + 1u) * X.nxcd)
+            __hip_atomic_store(&g->gen2.v, (unsigned long long)(nb + 1u), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void loop_barrier_arrive(SmcLoopScratch* g, const LoopXcd& X, unsigned nb) {
+    __syncthreads();
+    if (threadIdx.x == 0) loop_barrier_arrive_t0(g, X, nb);
+}
+__device__ __forceinline__ bool loop_barrier_wait(SmcLoopScratch* g, const LoopXcd& X, unsigned nb, int* s_ok) {
+    if (threadIdx.x == 0) {
+        bool ok = loop_spin(g, &g->gen2.v, nb + 1u);
+        // agent-scope acquire: this CU's vector L1 and the XCD's L2.  (There is no L1-only
+        // invalidate on gfx950 -- buffer_inv sc0 is workgroup scope, a no-op outside
+        // threadgroup-split mode -- so the acquire side stays per workgroup; the saving of this
+        // barrier is the release side.)
+        asm volatile("buffer_inv sc1" ::: "memory");
+        volatile unsigned* ab = &g->abort_flag;
+        if (*ab) ok = false;
+        *s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+__device__ __forceinline__ bool loop_barrier(SmcLoopScratch* g, const LoopXcd& X, unsigned nb, int* s_ok) {
+    loop_barrier_arrive(g, X, nb);
+    return loop_barrier_wait(g, X, nb, s_ok);
 }
 
 // m-th (0-based) set bit of the LDS mask through the exclusive popcount prefix
@@ -370,6 +455,13 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
     if (tid < D * (int)(sizeof(PriorDev) / 8))
         reinterpret_cast<double*>(s_prior)[tid] = reinterpret_cast<const double*>(A.prior)[tid];
     __syncthreads();
+    // the XCD populations of the XCD-aware barrier: counted here, published by one plain barrier
+    LoopXcd X;
+    X.xcd = loop_xcc_id();
+    if (tid == 0 && atomicAdd(&g->xmembers[X.xcd].v, 1ull) == 0ull) atomicAdd(&g->nxcd.v, 1ull);
+    const bool prologue_ok = loop_plain_barrier(g, G, 0u, &s_ok);
+    X.members = (unsigned)loop_ld(&g->xmembers[X.xcd].v);
+    X.nxcd = (unsigned)loop_ld(&g->nxcd.v);
     // loop state, identical in every workgroup
     unsigned q = 0;  // barriers passed
     int cur = 0;
@@ -378,7 +470,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
     long long iteration = 0, ess = 0, n_alive_now = N;
     unsigned long long pass = 0, acc_iter = 0, tot_evals = (unsigned long long)N, tot_props = 0;
     int passes_iter = 0;
-    int error = 0;
+    int error = prologue_ok ? 0 : 3;
     // own particle
     double Xi = in ? A.X[0][i] : 0.0;
     bool alive_i = in;
@@ -406,7 +498,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
         }
     };
 
-    while (true) {
+    while (error == 0) {
         // ================= publish: record of this workgroup (+ histogram of the predicted window)
         const uint64_t key = loop_key(Xi);
         bool pred = false;
@@ -504,7 +596,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             if (ab) atomicAdd(&g->hist[slot][kLoopBins + 1], ab);
             s_acc[0] = s_acc[1] = 0ull;
             s_acc[2] = s_acc[3] = ~0ull;
-            loop_barrier_arrive_t0(g, G, q);
+            loop_barrier_arrive_t0(g, X, q);
         }
         KABC_LSTAMP(0)
         if constexpr (kPre > 0) {
@@ -518,7 +610,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                 }
             }
         }
-        if (!loop_barrier_wait(g, q, &s_ok)) {
+        if (!loop_barrier_wait(g, X, q, &s_ok)) {
             error = 3;
             break;
         }
@@ -624,7 +716,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                     const unsigned hslot = q & (kLoopSlots - 1);
                     if (alive_i && key >= rlo && key <= rhi)
                         atomicAdd(&g->hist[hslot][(unsigned)((key - rlo) >> shift)], 1u);
-                    if (!loop_barrier(g, G, q, &s_ok)) {
+                    if (!loop_barrier(g, X, q, &s_ok)) {
                         error = 3;
                         break;
                     }
@@ -702,9 +794,9 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                 }
             }
             KABC_LSTAMP(4)
-            loop_barrier_arrive(g, G, q);
+            loop_barrier_arrive(g, X, q);
             expand_rest();
-            if (!loop_barrier_wait(g, q, &s_ok)) {
+            if (!loop_barrier_wait(g, X, q, &s_ok)) {
                 error = 3;
                 break;
             }
