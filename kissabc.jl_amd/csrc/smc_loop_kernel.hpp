@@ -544,15 +544,31 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                 atomicMin(&s_acc[3], kmxn);
             }
         }
-        // ---- everything the NEXT pass draws.  The streams are counter-based (seed, particle,
-        // pass, slot), so nothing here depends on the ensemble: partner indices (:163-164), the
-        // stretch normal, log(rand), and the leading normal pairs of the cost's own stream.  If
-        // the loop ends instead, the work is discarded.  The first part runs HERE, before this
-        // workgroup arrives at B1: the pass's row stores and the histogram atomics are still on
-        // their way to memory (the __syncthreads below waits for them), and this is ~3 us of
-        // pure arithmetic to put in front of that wait; the rest runs in the shadow of B1 itself.
-        constexpr int kPre0 = kPreA < 2 ? kPreA : 2;  // cost blocks expanded before arriving
         KABC_LSTAMP(21)
+        __syncthreads();  // s_acc complete; every wavefront's global writes have completed
+        if (tid == 0) {
+            const unsigned slot = q & (kLoopSlots - 1);
+            const unsigned long long a = s_acc[0], b = s_acc[1];
+            const unsigned bl = (unsigned)((b >> 42) & 0x7ffull), ab = (unsigned)(b >> 53);
+            unsigned long long* P = g->part[q & 1][bid];
+            P[0] = a;
+            P[1] = b & ((1ull << 42) - 1ull);
+            P[2] = s_acc[2];
+            P[3] = s_acc[3];
+            if (bl) atomicAdd(&g->hist[slot][kLoopBins], bl);
+            if (ab) atomicAdd(&g->hist[slot][kLoopBins + 1], ab);
+            s_acc[0] = s_acc[1] = 0ull;
+            s_acc[2] = s_acc[3] = ~0ull;
+            loop_barrier_arrive_t0(g, X, q);
+        }
+        KABC_LSTAMP(0)
+        // ---- everything the NEXT pass draws, in the shadow of B1.  The streams are counter-based
+        // (seed, particle, pass, slot), so nothing here depends on the ensemble: partner indices
+        // (:163-164), the stretch normal, log(rand), and the leading normal pairs of the cost's own
+        // stream.  If the loop ends instead, the work is discarded.  (Round 2 ran the first part of
+        // this BEFORE arriving: with a release fence per workgroup an arrival waited ~3 us for the
+        // write-back anyway.  With the XCD-aware release an arrival is 1 us, and 3 us of arithmetic
+        // in front of it would delay the XCD's last arrival -- the one that starts the write-back.)
         if (in) {
             nps = pass + (iteration > 0 ? 2u : 1u);
             const uint32_t w = (uint32_t)i;
@@ -571,10 +587,10 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             kabc_normal_pair(kabc_lo64(B1), kabc_hi64(B1), &z0, &z1);
             nx_s = A.max_stretch * z0 / kabc_sqrt((double)D);
             nx_lprob = kabc_log(kabc_u01(kabc_lo64(B2)));
-            // the cost's normal pairs: the first half around B1, the rest in the shadow of B2
+            // the cost's normal pairs: the first half here, the rest in the shadow of B2
             if constexpr (kPre > 0) {
 #pragma unroll
-                for (int j = 0; j < kPre0; ++j) {
+                for (int j = 0; j < kPreA; ++j) {
                     const kabc_u128_t Bn = kabc_stream_block(seed_v, w, nps, (uint32_t)j, KABC_DOM_SMC_COST);
                     kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
                                          kabc_log_tab);
@@ -582,34 +598,6 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             }
         }
         KABC_LSTAMP(22)
-        __syncthreads();  // s_acc complete; every wavefront's global writes have left
-        if (tid == 0) {
-            const unsigned slot = q & (kLoopSlots - 1);
-            const unsigned long long a = s_acc[0], b = s_acc[1];
-            const unsigned bl = (unsigned)((b >> 42) & 0x7ffull), ab = (unsigned)(b >> 53);
-            unsigned long long* P = g->part[q & 1][bid];
-            P[0] = a;
-            P[1] = b & ((1ull << 42) - 1ull);
-            P[2] = s_acc[2];
-            P[3] = s_acc[3];
-            if (bl) atomicAdd(&g->hist[slot][kLoopBins], bl);
-            if (ab) atomicAdd(&g->hist[slot][kLoopBins + 1], ab);
-            s_acc[0] = s_acc[1] = 0ull;
-            s_acc[2] = s_acc[3] = ~0ull;
-            loop_barrier_arrive_t0(g, X, q);
-        }
-        KABC_LSTAMP(0)
-        if constexpr (kPre > 0) {
-            if (in) {
-#pragma unroll
-                for (int j = kPre0; j < kPreA; ++j) {
-                    const kabc_u128_t Bn =
-                        kabc_stream_block(seed_v, (uint32_t)i, nps, (uint32_t)j, KABC_DOM_SMC_COST);
-                    kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
-                                         kabc_log_tab);
-                }
-            }
-        }
         if (!loop_barrier_wait(g, X, q, &s_ok)) {
             error = 3;
             break;
