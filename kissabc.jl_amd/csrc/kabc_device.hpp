@@ -164,6 +164,88 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorSet& P, const 
     return factored_logpdf_push<D, SIMPLE>(P.c, x, xp);
 }
 
+// Constant- or Gaussian-in-a-box components (the AIS kernel's SIMPLE / NORMAL prior classes, the smc
+// loop kernel's SIMPLE class): one 64-byte LDS record per component,
+//   Gaussian-in-a-box : { mu, sigma, RN(1/sigma), c0 = log sigma, c1 (0 unless truncated), lo, hi, - }
+//   constant-in-a-box : { lo, hi, -, c0, -, -, -, - }
+// (lo / hi of an untruncated Normal are -Inf / +Inf).  Bit g of gmask: component g is Gaussian;
+// dmask: push_p rounds it.
+struct GaussBoxPrior {
+    const double (*rec)[8];  // LDS, [D][8]
+    uint32_t gmask, dmask;
+};
+__device__ __forceinline__ bool gaussbox_is_gauss(int kind) {
+    return kind == KABC_PRIOR_NORMAL || kind == KABC_PRIOR_TRUNCNORMAL;
+}
+// the record of one prepared component (thread k of a workgroup fills record k)
+__device__ __forceinline__ void gaussbox_stage(double* r, const PriorDev& q) {
+    const bool tr = q.kind == KABC_PRIOR_TRUNCNORMAL;
+    r[0] = q.p[0];
+    r[1] = q.p[1];
+    r[2] = q.rb;
+    r[3] = q.c0;
+    r[4] = tr ? q.c1 : 0.0;
+    r[5] = tr ? q.p[2] : -KABC_INF;
+    r[6] = tr ? q.p[3] : KABC_INF;
+    r[7] = gaussbox_is_gauss(q.kind) ? 1.0 : 0.0;
+}
+// host-side: can every component of the prior be a record of this kind?
+inline bool prior_is_gaussbox(int kind) {
+    return kind == KABC_PRIOR_UNIFORM || kind == KABC_PRIOR_DISCRETE_UNIFORM ||
+           kind == KABC_PRIOR_NORMAL || kind == KABC_PRIOR_TRUNCNORMAL;
+}
+
+// push_p (src/types.jl:27-32) + logpdf(d::Factored, x) (src/priors.jl:30-36) for these classes.
+// Returns the left-to-right sum of the components' in-support values and, in `in`, whether
+// every component is inside its support; the caller takes lp = in ? sum : -Inf, which is what
+// the reference's sum is when a term is -Inf (no term can be +Inf).  Same formulas and operation
+// order as comp_logpdf_simple -- -(z^2 + log 2pi)/2 - log sigma [- c1], z = (x - mu)/sigma --
+// with "- c1" also applied to an untruncated Normal, where c1 = 0 and x - 0 = x exactly.
+// What changed against the per-component family switch (round 2): a Normal component executed
+// ~30 instructions, four dependent LDS reads among them, each behind its own wait -- here the
+// parameters of four components arrive in one batch and a component is 9 VALU instructions.
+template <int D, bool ALLNORMAL, bool HASDISC>
+__device__ __forceinline__ double gaussbox_logpdf_push(const GaussBoxPrior& G, const double* x,
+                                                       double* xp, bool& in_out) {
+    constexpr int GRP = D <= 8 ? 4 : 2;  // (D = 16 with four records in flight spilled 150 registers)
+    bool in = true;
+    double s = 0.0;
+#pragma unroll
+    for (int k0 = 0; k0 < D; k0 += GRP) {
+        double q[GRP][7];
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+            if (k0 + j < D) {
+#pragma unroll
+                for (int w = 0; w < (ALLNORMAL ? 4 : 7); ++w) q[j][w] = G.rec[k0 + j][w];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+            const int k = k0 + j;
+            if (k < D) {
+                double v = x[k];
+                if constexpr (HASDISC) v = ((G.dmask >> k) & 1u) ? kabc_rint(v) : v;
+                xp[k] = v;
+                double l;
+                if (ALLNORMAL || ((G.gmask >> k) & 1u)) {
+                    if constexpr (!ALLNORMAL) in = in && (v >= q[j][5]) && (v <= q[j][6]);
+                    const double z = kabc_div_rc(v - q[j][0], q[j][1], q[j][2]);
+                    l = -(z * z + KABC_LOG_2PI) / 2.0 - q[j][3];
+                    if constexpr (!ALLNORMAL) l = l - q[j][4];
+                } else {
+                    in = in && (v >= q[j][0]) && (v <= q[j][1]);
+                    l = q[j][3];
+                }
+                s = (k == 0) ? l : s + l;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    in_out = in;
+    return s;
+}
+
 // words of parameter-independent "prepared" state of a cost (include/kabc_costs.h)
 #ifndef KABC_USER_AUX_WORDS
 #define KABC_USER_AUX_WORDS_OR_0 0
