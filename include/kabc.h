@@ -419,7 +419,9 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
  * of 64 particles and ends with one grouped in-place all-gather of the rows it produced.
  * Worth it for an EXPENSIVE simulator only (from ~10 us per evaluation: a C4-sized pass
  * gathers 4.6 MB); a cheap cost is faster on one GPU (kabc_smc_run's persistent loop kernel).
- * Collective: every rank calls it with the same arguments and receives the same result.
+ * Collective: every rank calls it with the same arguments and receives the same result; a rank
+ * that fails before a pass's all-gather leaves the others waiting in it (RCCL) -- treat any
+ * non-OK status as fatal for the whole job.
  * Draws are keyed by particle: the result equals kabc_smc_run's bit for bit.
  * Communicators: kabc_comm_init_rank (one process per GPU, RCCL); the P2P communicators of
  * kabc_comm_init_all when each rank is driven by its own host thread (how the test-suite

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -113,16 +114,20 @@ struct P2PGroup {
     double* pub[KABC_COMM_MAX_WORLD][8] = {};
 };
 
-static void p2p_host_barrier(P2PGroup* g) {
+// false: a rank did not show up within 120 s (it failed before its collective: the caller
+// returns an error instead of waiting for ever)
+static bool p2p_host_barrier(P2PGroup* g) {
     std::unique_lock<std::mutex> lk(g->mu);
     const unsigned long long ph = g->phase;
     if (++g->arrived == g->world) {
         g->arrived = 0;
         ++g->phase;
         g->cv.notify_all();
-    } else {
-        g->cv.wait(lk, [&] { return g->phase != ph; });
+        return true;
     }
+    if (g->cv.wait_for(lk, std::chrono::seconds(120), [&] { return g->phase != ph; })) return true;
+    --g->arrived;
+    return false;
 }
 
 // exchange stream + events of a communicator, created at first use (on the context's device)
@@ -244,7 +249,10 @@ kabc_status_t comm_allgather_many(kabc_comm* c, double** bases, const size_t* co
         KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
         for (int j = 0; j < n; ++j) g->pub[c->rank][j] = bases[j];
         KABC_HIP_CHECK(hipStreamSynchronize(c->ctx->stream));  // this rank's segments are final
-        p2p_host_barrier(g);
+        if (!p2p_host_barrier(g)) {
+            set_error("P2P all-gather: a rank of the group did not arrive within 120 s");
+            return KABC_ERR_DEVICE;
+        }
         kabc_status_t st = KABC_OK;
         for (int j = 0; j < n && st == KABC_OK && c->world > 1; ++j) {
             if (counts[j] == 0) continue;
@@ -262,7 +270,8 @@ kabc_status_t comm_allgather_many(kabc_comm* c, double** bases, const size_t* co
             if (hipGetLastError() != hipSuccess) st = KABC_ERR_DEVICE;
         }
         const hipError_t e = hipStreamSynchronize(c->ctx->stream);
-        p2p_host_barrier(g);  // nobody overwrites a source before every pull has finished
+        // nobody overwrites a source before every pull has finished
+        if (!p2p_host_barrier(g) && st == KABC_OK) st = KABC_ERR_DEVICE;
         if (st != KABC_OK || e != hipSuccess) {
             set_error("P2P all-gather failed: %s", hipGetErrorString(e));
             return KABC_ERR_DEVICE;
