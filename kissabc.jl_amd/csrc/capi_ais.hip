@@ -569,19 +569,43 @@ kabc_status_t kabc_ais_init(kabc_ais_t* h, int32_t retry_sampling) {
         set_error("this handle belongs to a single-process group: use kabc_ais_init_multi");
         return KABC_ERR_INVALID_ARG;
     }
-    if (kabc_status_t st = ais_init_enqueue(h, retry_sampling)) return st;
+    // A rank-local failure must not strand the other ranks in the collectives below: every rank
+    // takes part in them whatever happened locally, and all of them learn about it.
+    kabc_status_t local = ais_init_enqueue(h, retry_sampling);
+    char local_msg[512] = "";
+    if (local) std::snprintf(local_msg, sizeof local_msg, "%s", get_error());
+    if (local && !h->comm) return local;
     DevCounters c;
-    if (read_counters(h, &c)) return KABC_ERR_DEVICE;
+    std::memset(&c, 0, sizeof c);
+    if (local == KABC_OK && read_counters(h, &c)) {
+        local = KABC_ERR_DEVICE;
+        std::snprintf(local_msg, sizeof local_msg, "%s", get_error());
+        if (!h->comm) return local;
+    }
     uint64_t failed = c.init_failed ? 1u : 0u;
     if (h->comm) {
-        // every rank takes part in the exchange whatever its own outcome, and every rank
-        // reports the failure of any (the reference's retry budget is per ensemble)
+        // every rank reports the failure of any (the reference's retry budget is per ensemble)
         for (int hf = 0; hf < 2; ++hf)
             for (int k = 0; k < h->xk; ++k)
                 if (kabc_status_t st = comm_allgather_inplace(h->comm, chunk_base(h, hf, k),
                                                               (size_t)h->cper[hf] * h->D))
-                    return st;
-        if (kabc_status_t st = kabc_comm_allreduce_sum_u64(h->comm, &failed, 1)) return st;
+                    if (local == KABC_OK) {
+                        local = st;
+                        std::snprintf(local_msg, sizeof local_msg, "%s", get_error());
+                    }
+        uint64_t v[2] = {failed, local != KABC_OK ? 1u : 0u};
+        const kabc_status_t st = kabc_comm_allreduce_sum_u64(h->comm, v, 2);
+        if (local) {
+            set_error("%s", local_msg);
+            return local;
+        }
+        if (st) return st;
+        if (v[1]) {
+            set_error("kabc_ais_init failed on %llu other rank(s) of the communicator",
+                      (unsigned long long)v[1]);
+            return KABC_ERR_DEVICE;
+        }
+        failed = v[0];
     }
     if (failed) return ais_init_failed();
     ais_mark_initialised(h);
