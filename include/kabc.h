@@ -63,7 +63,12 @@ typedef enum kabc_prior_kind {
     KABC_PRIOR_EXPONENTIAL = 7,      /* Exponential(theta)      p = (theta)           */
     KABC_PRIOR_GAMMA = 8,            /* Gamma(alpha, theta)     p = (alpha, theta)    */
     KABC_PRIOR_LOGNORMAL = 9,        /* LogNormal(mu, sigma)    p = (mu, sigma)       */
-    KABC_PRIOR__COUNT = 10
+    /* CommonLogDensity(nparameters, sample_init, lπ) with an ARBITRARY sample_init
+     * (src/types.jl:105-113: `rng -> sample`): the initial walkers are drawn by the cost
+     * plugin's own kabc_user_sample_init (include/kabc_costs.h).  Every component of the
+     * "prior" carries this kind; it has no density (KABC_POSTERIOR_COMMON never asks for one). */
+    KABC_PRIOR_USER_INIT = 10,
+    KABC_PRIOR__COUNT = 11
 } kabc_prior_kind_t;
 
 /* one univariate component of Factored(...) */

@@ -35,7 +35,14 @@ enum {
      * (kabc_register_cost_plugin, include/kabc.h).  The snippet defines
      *   KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
      *                                 const double* data, int64_t ndata, kabc_cost_rng_t* rng);
-     * and may use everything in kabc_math.h / kabc_philox.h. */
+     * and may use everything in kabc_math.h / kabc_philox.h.
+     * Optional, for CommonLogDensity with an arbitrary `sample_init` (src/types.jl:105-113): the
+     * snippet also defines
+     *   #define KABC_USER_SAMPLE_INIT 1
+     *   KABC_HD void kabc_user_sample_init(double* x, int D, const double* params,
+     *                                      const double* data, int64_t ndata, kabc_cost_rng_t* rng);
+     * which draws one initial walker from the stream it is given (kabc_cost_rng_normal2 /
+     * kabc_cost_rng_uniform2); the model's prior components then carry KABC_PRIOR_USER_INIT. */
     KABC_COST_USER = 100
 };
 

@@ -13,9 +13,9 @@ from .api import (ABCDE, AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPost
 from . import comm
 from .comm import Comm, EnsembleGroup
 from .costs import DeviceCost
-from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, LogNormal,
-                            MultivariateNormal, MvNormal, NegativeBinomial, Normal, Product, Truncated,
-                            TruncatedNormal, Uniform, truncated)
+from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, InitFromSnippet,
+                            LogNormal, MultivariateNormal, MvNormal, NegativeBinomial, Normal, Product,
+                            Truncated, TruncatedNormal, Uniform, UserInit, truncated)
 
 __all__ = [
     "ABCDE", "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "CommonLogDensity",
@@ -23,5 +23,5 @@ __all__ = [
     "Particles", "sample", "smc", "DeviceCost", "costs", "Factored", "Uniform", "Normal",
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
     "Exponential", "Gamma", "LogNormal", "Product", "MvNormal", "MultivariateNormal", "Context", "KabcError", "default_context", "LIB_PATH",
-    "KABC_MAX_DIM", "comm", "Comm", "EnsembleGroup",
+    "KABC_MAX_DIM", "comm", "Comm", "EnsembleGroup", "UserInit", "InitFromSnippet",
 ]

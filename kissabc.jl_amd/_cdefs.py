@@ -20,6 +20,7 @@ KABC_OK, KABC_ERR_INVALID_ARG, KABC_ERR_RETRY_EXHAUSTED, KABC_ERR_INVALID_STATE,
 # kabc_prior_kind_t
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_BETA, PRIOR_DISCRETE_UNIFORM, \
     PRIOR_NEGBINOMIAL, PRIOR_EXPONENTIAL, PRIOR_GAMMA, PRIOR_LOGNORMAL = range(1, 10)
+PRIOR_USER_INIT = 10
 
 POSTERIOR_KERNELIZED, POSTERIOR_THRESHOLD, POSTERIOR_COMMON = 1, 2, 3
 

@@ -100,8 +100,10 @@ class CommonLogDensity(_ApproxModel):
     """CommonLogDensity(nparameters, sample_init, lπ) -- src/types.jl:105-128, 151-161:
     classical MCMC on a log-density.  On the device path `lπ` is a DeviceCost that
     RETURNS THE LOG-DENSITY (built-in or costs.UserCost) and `sample_init` is a
-    Factored / univariate distribution the initial walkers are drawn from
-    (the reference takes an arbitrary `rng -> sample` closure)."""
+    Factored / univariate distribution the initial walkers are drawn from -- or
+    `InitFromSnippet(nparameters)`: the reference takes an arbitrary `rng -> sample` closure,
+    here the log-density's C snippet may bring its own (`#define KABC_USER_SAMPLE_INIT 1` +
+    `kabc_user_sample_init(x, D, params, data, ndata, rng)`, include/kabc_costs.h)."""
     posterior = cd.POSTERIOR_COMMON
 
     def __init__(self, nparameters, sample_init, lpi):

@@ -892,10 +892,20 @@ __global__ void __launch_bounds__(kInitBlock) ais_init_kernel(const InitArgs A) 
     double lp = 0.0, ll = 0.0;
     uint64_t attempt = 0;
     while (true) {
-        for (int k = 0; k < D; ++k) {
-            kabc_slotwin_t win = {seed, attempt, w, KABC_DOM_AIS_INIT,
-                                  (uint32_t)k * KABC_SLOTS_PER_DIM};
-            x[k] = kabc_sample_prior(&A.raw[k], &win);
+#ifdef KABC_USER_SAMPLE_INIT
+        // CommonLogDensity with the user's own sample_init (src/types.jl:105-113, :50 of
+        // src/KissABC.jl: unconditional_sample): drawn by the plugin's function
+        if (A.raw[0].kind == KABC_PRIOR_USER_INIT) {
+            kabc_cost_rng_t irng = {seed, attempt, w, KABC_DOM_AIS_INIT, 0u};
+            kabc_user_sample_init(x, D, A.cost_params, A.cost_data, A.cost_ndata, &irng);
+        } else
+#endif
+        {
+            for (int k = 0; k < D; ++k) {
+                kabc_slotwin_t win = {seed, attempt, w, KABC_DOM_AIS_INIT,
+                                      (uint32_t)k * KABC_SLOTS_PER_DIM};
+                x[k] = kabc_sample_prior(&A.raw[k], &win);
+            }
         }
         lp = factored_logpdf_push<D>(A.prior, x, xp);
         kabc_cost_rng_t rng = {seed, attempt, w, KABC_DOM_AIS_INIT_COST, 0u};

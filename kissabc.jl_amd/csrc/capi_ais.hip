@@ -276,6 +276,20 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         set_error("DeviceCost id %d does not accept D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
     }
+    {  // sample_init drawn by the cost plugin (KABC_PRIOR_USER_INIT): CommonLogDensity only
+        int n_user = 0;
+        for (int k = 0; k < m->D; ++k) n_user += m->prior[k].kind == KABC_PRIOR_USER_INIT;
+        if (n_user) {
+            const CostPlugin* pl = find_plugin(m->cost.id);
+            if (n_user != m->D || m->posterior != KABC_POSTERIOR_COMMON || dyn || !pl || !pl->has_sample_init) {
+                set_error("KABC_PRIOR_USER_INIT: every component must carry it, the model must be a "
+                          "CommonLogDensity of at most %d parameters, and its log-density a user cost "
+                          "whose snippet defines KABC_USER_SAMPLE_INIT + kabc_user_sample_init",
+                          KABC_MAX_DIM);
+                return KABC_ERR_INVALID_ARG;
+            }
+        }
+    }
     // prior class of the half-generation kernel (ais_kernels.hpp)
     bool isbox = true, gaussbox = true, allnormal = true;
     for (int k = 0; k < m->D; ++k) {

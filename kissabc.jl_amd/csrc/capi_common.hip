@@ -25,6 +25,9 @@ bool prepare_prior(const kabc_prior_t& pr, PriorDev& q) {
     const double a = pr.p[0], b = pr.p[1];
     q.rb = 1.0 / ((pr.kind == KABC_PRIOR_EXPONENTIAL) ? a : b);
     switch (pr.kind) {
+        case KABC_PRIOR_USER_INIT:  // no density, no parameters (drawn by the cost plugin)
+            q.rb = 0.0;
+            return true;
         case KABC_PRIOR_UNIFORM:
             if (!(b > a)) return false;
             q.c0 = -kabc_log(b - a);

@@ -358,6 +358,7 @@ extern "C" kabc_status_t kabc_compile_cost_plugin(const char* src, const int32_t
     }
     CostPlugin p = {};
     p.rtc = R;
+    p.has_sample_init = R->src.find("KABC_USER_SAMPLE_INIT") != std::string::npos ? 1 : 0;
     std::lock_guard<std::mutex> lk(g_mu);
     p.id = KABC_COST_USER + (int32_t)g_plugins.size();
     g_plugins.push_back(p);
@@ -407,6 +408,7 @@ extern "C" kabc_status_t kabc_register_cost_plugin(const char* path, int32_t* ou
     p.smc_loop = (void* (*)(int32_t, int32_t))dlsym(dl, "kabc_plugin_smc_loop");
     p.ais_dyn = (void* (*)(void))dlsym(dl, "kabc_plugin_ais_dyn");
     p.smc_dyn = (void* (*)(void))dlsym(dl, "kabc_plugin_smc_dyn");
+    if (auto hi = (int32_t(*)(void))dlsym(dl, "kabc_plugin_has_sample_init")) p.has_sample_init = hi();
     if (!abi || !p.dim_ok || !p.ais || !p.smc || !p.ais_init || !p.smc_init) {
         dlclose(dl);
         set_error("%s is not a kabc cost plugin (missing entry points)", path);

@@ -10,6 +10,7 @@ struct CostPlugin {
     void* dl;        // plugin .so built by hipcc (kabc_register_cost_plugin), else NULL
     RtcPlugin* rtc;  // hipRTC plugin (kabc_compile_cost_plugin), else NULL
     int32_t id;
+    int32_t has_sample_init;  // the snippet defines kabc_user_sample_init (KABC_PRIOR_USER_INIT)
     int32_t (*dim_ok)(int32_t D);
     void* (*ais)(int32_t D, int32_t prior_class);   // -> AisLaunchFn
     void* (*smc)(int32_t D, int32_t simple_prior);  // -> SmcLaunchFn

@@ -134,6 +134,21 @@ class LogNormal(UnivariateDistribution):
         return (self.mu, self.sigma)
 
 
+class UserInit(UnivariateDistribution):
+    """One coordinate of a CommonLogDensity's own `sample_init` (src/types.jl:105-113: any
+    `rng -> sample` in the reference): drawn on the device by the log-density's C snippet
+    (`#define KABC_USER_SAMPLE_INIT 1` + `kabc_user_sample_init`, include/kabc_costs.h).  It has
+    no density of its own.  `InitFromSnippet(n)` builds the n-coordinate product."""
+    kind = cd.PRIOR_USER_INIT
+
+    def params(self):
+        return ()
+
+
+def InitFromSnippet(nparameters):
+    return Factored(*[UserInit() for _ in range(int(nparameters))])
+
+
 class Factored:
     """Factored(d1, d2, ...) -- src/priors.jl:10-13: a product of univariate
     distributions with mixed continuous / discrete support."""

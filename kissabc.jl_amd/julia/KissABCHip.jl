@@ -230,9 +230,23 @@ struct InitFrom{D<:Distribution}
 end
 (s::InitFrom)(rng) = (x = rand(rng, s.d); x isa Tuple ? collect(Float64, x) : x)
 
+"""
+    InitFromSnippet(n, cpu)
+A `sample_init` drawn by the log-density's own C snippet on the device (`#define
+KABC_USER_SAMPLE_INIT 1` + `kabc_user_sample_init`, include/kabc_costs.h; prior kind
+KABC_PRIOR_USER_INIT = 10); `cpu` is the Julia closure `rng -> sample` with the same law, used
+when the model runs through KissABC's own path.
+"""
+struct InitFromSnippet{F}
+    n::Int
+    cpu::F
+end
+(s::InitFromSnippet)(rng) = s.cpu(rng)
+lower_prior(s::InitFromSnippet) = [KabcPrior(10, 0, (0.0, 0.0, 0.0, 0.0)) for _ in 1:s.n]
+
 const KernelizedDev = ApproxKernelizedPosterior{<:Distribution,<:DeviceCost}
 const ThresholdDev = ApproxPosterior{<:Distribution,<:DeviceCost}
-const CommonDev = CommonLogDensity{<:Any,<:InitFrom,<:DeviceCost}
+const CommonDev = CommonLogDensity{<:Any,<:Union{InitFrom,InitFromSnippet},<:DeviceCost}
 const DeviceModel = Union{KernelizedDev,ThresholdDev,CommonDev}
 
 posterior_kind(::ApproxKernelizedPosterior) = Int32(1)
@@ -241,7 +255,7 @@ posterior_kind(::CommonLogDensity) = Int32(3)
 eps_of(m::ApproxKernelizedPosterior) = Float64(m.scale)
 eps_of(m::ApproxPosterior) = Float64(m.maxcost)
 eps_of(::CommonLogDensity) = 1.0
-prior_of(m::CommonLogDensity) = m.sample_init.d
+prior_of(m::CommonLogDensity) = m.sample_init isa InitFromSnippet ? m.sample_init : m.sample_init.d
 prior_of(m) = m.prior
 cost_of(m::CommonLogDensity) = m.lπ
 cost_of(m) = m.cost
@@ -498,7 +512,7 @@ function KissABC.pfilter(prior::Distribution, cost::DeviceCost, N; rng = Random.
     (P = particles_of(prior, theta, 1:Neff), C = Particles(C))     # src/smc.jl:334-340
 end
 
-export DeviceCost, UserCost, InitFrom, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
+export DeviceCost, UserCost, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
        AbsDiff, NormShell, NoisyQuadDU, Mixture, NoisyBanana, WienerRms, sample_sharded, unique_id,
        comm_init_rank
 end # module

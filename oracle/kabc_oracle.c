@@ -133,6 +133,9 @@ static int prepare_prior(const kabc_prior_t* pr, prep_t* q) {
     const double a = pr->p[0], b = pr->p[1];
     q->rb = 1.0 / ((pr->kind == KABC_PRIOR_EXPONENTIAL) ? a : b);
     switch (pr->kind) {
+        case KABC_PRIOR_USER_INIT: /* no density: CommonLogDensity's own sample_init (src/types.jl:112) */
+            q->rb = 0.0;
+            return 1;
         case KABC_PRIOR_UNIFORM:
             if (!(b > a)) return 0;
             q->c0 = -kabc_log(b - a);
@@ -289,6 +292,15 @@ int32_t orc_factored_rand(const kabc_prior_t* prior, int32_t D, uint64_t seed, u
 typedef double (*orc_user_cost_fn)(const double*, int, const double*, const double*, int64_t,
                                    kabc_cost_rng_t*);
 static orc_user_cost_fn g_user_cost[64];
+/* the snippet's own sample_init (KABC_USER_SAMPLE_INIT, include/kabc_costs.h): CommonLogDensity's
+ * `sample_init(rng)` of src/types.jl:105-113 */
+typedef void (*orc_user_init_fn)(double*, int, const double*, const double*, int64_t, kabc_cost_rng_t*);
+static orc_user_init_fn g_user_init[64];
+int32_t orc_register_user_init(int32_t id, void* fn) {
+    if (id < KABC_COST_USER || id >= KABC_COST_USER + 64) return fail(KABC_ERR_INVALID_ARG, "bad user cost id");
+    g_user_init[id - KABC_COST_USER] = (orc_user_init_fn)fn;
+    return KABC_OK;
+}
 int32_t orc_register_user_cost(int32_t id, void* fn) {
     if (id < KABC_COST_USER || id >= KABC_COST_USER + 64) return fail(KABC_ERR_INVALID_ARG, "bad user cost id");
     g_user_cost[id - KABC_COST_USER] = (orc_user_cost_fn)fn;
@@ -434,20 +446,34 @@ void orc_ais_destroy(orc_ais_t* h) {
 }
 
 /* step(rng, model, spl::AIS; retry_sampling) -- src/KissABC.jl:35-64 */
+/* unconditional_sample(rng, density): Particle(rand(rng, prior)) (src/types.jl:34), or the
+ * CommonLogDensity's own sample_init(rng) (src/types.jl:112-113) when the snippet supplies it */
+static void model_sample(orc_ais_t* h, uint32_t walker, uint64_t attempt, double* out) {
+    if (h->prior[0].kind == KABC_PRIOR_USER_INIT) {
+        kabc_cost_rng_t rng = {h->seed, attempt, walker, KABC_DOM_AIS_INIT, 0u};
+        g_user_init[h->cost.id - KABC_COST_USER](out, h->D, h->cost.params, h->cost.data, h->cost.ndata, &rng);
+        return;
+    }
+    factored_rand(h->prior, h->D, h->seed, walker, attempt, KABC_DOM_AIS_INIT, out);
+}
+
 int32_t orc_ais_init(orc_ais_t* h, int32_t retry_sampling) {
     const int D = h->D;
+    if (h->prior[0].kind == KABC_PRIOR_USER_INIT &&
+        (h->posterior != KABC_POSTERIOR_COMMON || h->cost.id < KABC_COST_USER ||
+         !g_user_init[h->cost.id - KABC_COST_USER]))
+        return fail(KABC_ERR_INVALID_ARG, "KABC_PRIOR_USER_INIT needs a CommonLogDensity whose snippet defines kabc_user_sample_init");
     int64_t retrys = (int64_t)retry_sampling * h->N; /* :52 */
     double xp[ORC_MAX_DIM];
     for (int64_t i = 0; i < h->N; ++i) { /* :50-51, attempt 0 */
         uint64_t attempt = 0;
         int ev;
-        factored_rand(h->prior, D, h->seed, (uint32_t)i, attempt, KABC_DOM_AIS_INIT, h->x + i * D);
+        model_sample(h, (uint32_t)i, attempt, h->x + i * D);
         model_push_p(h, h->x + i * D, xp);
         ld_t v = loglike(h, xp, (uint32_t)i, attempt, KABC_DOM_AIS_INIT_COST, &ev);
         while (!is_valid(h, v)) { /* :54-60 */
             ++attempt;
-            factored_rand(h->prior, D, h->seed, (uint32_t)i, attempt, KABC_DOM_AIS_INIT,
-                          h->x + i * D);
+            model_sample(h, (uint32_t)i, attempt, h->x + i * D);
             model_push_p(h, h->x + i * D, xp);
             v = loglike(h, xp, (uint32_t)i, attempt, KABC_DOM_AIS_INIT_COST, &ev);
             retrys -= 1;

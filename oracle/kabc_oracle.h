@@ -66,6 +66,7 @@ double orc_cost_eval(const kabc_cost_t* cost, int32_t D, const double* x, uint64
 double orc_cdf_g_inv(double u, double a);
 /* register the gcc-compiled twin of a user DeviceCost plugin under its id */
 int32_t orc_register_user_cost(int32_t id, void* fn);
+int32_t orc_register_user_init(int32_t id, void* fn);
 
 /* AIS */
 int32_t orc_ais_create(const kabc_model_t* model, int64_t nparticles, uint64_t seed,

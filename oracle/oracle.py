@@ -59,6 +59,7 @@ def load():
                                            C.c_uint32, C.c_uint64, C.c_uint32]),
             "orc_cdf_g_inv": (C.c_double, [C.c_double, C.c_double]),
             "orc_register_user_cost": (C.c_int32, [C.c_int32, C.c_void_p]),
+            "orc_register_user_init": (C.c_int32, [C.c_int32, C.c_void_p]),
             "orc_ais_create": (C.c_int32, [C.POINTER(cd.Model), C.c_int64, C.c_uint64,
                                            C.POINTER(VP)]),
             "orc_ais_init": (C.c_int32, [VP, C.c_int32]),
@@ -189,7 +190,11 @@ def register_user_cost(cost):
     text = ('#include "kabc_philox.h"\n' + cost.source +
             "\ndouble orc_user_cost_entry(const double* x, int D, const double* params, "
             "const double* data, int64_t ndata, kabc_cost_rng_t* rng) {\n"
-            "    return kabc_user_cost(x, D, params, data, ndata, rng);\n}\n")
+            "    return kabc_user_cost(x, D, params, data, ndata, rng);\n}\n"
+            "#ifdef KABC_USER_SAMPLE_INIT\n"
+            "void orc_user_init_entry(double* x, int D, const double* params, const double* data, "
+            "int64_t ndata, kabc_cost_rng_t* rng) {\n"
+            "    kabc_user_sample_init(x, D, params, data, ndata, rng);\n}\n#endif\n")
     tag = hashlib.sha1(text.encode()).hexdigest()[:16]
     bdir = os.path.join(_HERE, "_build")
     os.makedirs(bdir, exist_ok=True)
@@ -205,6 +210,8 @@ def register_user_cost(cost):
     _user_libs[so] = lib
     fn = C.cast(lib.orc_user_cost_entry, C.c_void_p)
     _check(load().orc_register_user_cost(cost.id, fn))
+    if hasattr(lib, "orc_user_init_entry"):
+        _check(load().orc_register_user_init(cost.id, C.cast(lib.orc_user_init_entry, C.c_void_p)))
 
 
 def cdf_g_inv(u, a):

@@ -272,3 +272,71 @@ def test_hiprtc_and_hipcc_plugins_agree(k, orc, gpu_ctx, monkeypatch):
     assert ra.eps == rb.eps and np.array_equal(ra.info["theta_all"], rb.info["theta_all"])
     assert first_use < 10.0, first_use                          # two kernels through hipRTC + the run
     print(f"first AIS use of a hipRTC cost: {first_use:.2f} s")
+
+
+# a log-density that brings its own sample_init (src/types.jl:105-113: `rng -> sample`): a ring,
+# initial walkers drawn ON the ring (something no product of univariate priors can express)
+RING_SRC = """
+#define KABC_USER_SAMPLE_INIT 1
+KABC_HD void kabc_user_sample_init(double* x, int D, const double* params,
+                                   const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
+    double u0, u1, z0, z1;
+    kabc_cost_rng_uniform2(rng, &u0, &u1);
+    kabc_cost_rng_normal2(rng, &z0, &z1);
+    double s, c;
+    kabc_sincos2pi(u0, &s, &c);
+    const double r = params[0] + 0.05 * z0;
+    x[0] = r * c;
+    x[1] = r * s;
+}
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
+                              const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
+    const double r = kabc_sqrt(x[0] * x[0] + x[1] * x[1]);
+    const double d = (r - params[0]) / params[1];
+    return -0.5 * d * d;      /* lπ: a ring of radius params[0], width params[1] */
+}
+"""
+
+
+def test_user_sample_init_on_oracle(k, orc):
+    ring = k.costs.UserCost(RING_SRC, dims=[2], params=[2.0, 0.1], name="ring", posteriors=["common"])
+    orc.register_user_cost(ring)
+    model = k.CommonLogDensity(2, k.InitFromSnippet(2), ring)
+    o = orc.OracleAIS(model, 64, seed=3).init()
+    x0 = o.state()[0]
+    r0 = np.hypot(x0[:, 0], x0[:, 1])
+    assert np.all(np.abs(r0 - 2.0) < 0.4) and r0.std() > 0.01       # drawn on the ring by the snippet
+    x = o.steps_serial(64 * 50, 5)
+    assert abs(np.hypot(x[:, 0], x[:, 1]).mean() - 2.0) < 0.05
+    # a snippet without the hook cannot serve such a model
+    plain = k.costs.UserCost(BANANA_LPI + "// no init\\n", dims=[2], name="plain", posteriors=["common"])
+    orc.register_user_cost(plain)
+    with pytest.raises(orc.OracleError, match="kabc_user_sample_init"):
+        orc.OracleAIS(k.CommonLogDensity(2, k.InitFromSnippet(2), plain), 64, seed=3).init()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["hiprtc", "hipcc"])
+def test_user_sample_init_gpu_bit_exact(k, orc, gpu_ctx, monkeypatch, form):
+    """CommonLogDensity with an arbitrary sample_init: the snippet draws the initial walkers on
+    the device (ais_init_kernel calls kabc_user_sample_init), bit-identical to the oracle calling
+    the same function through gcc -- both forms of a user cost."""
+    if form == "hipcc":
+        monkeypatch.setenv("KABC_USER_PLUGIN", "hipcc")
+    ring = k.costs.UserCost(RING_SRC + f"// {form}\\n", dims=[2], params=[2.0, 0.1], name="ring",
+                            posteriors=["common"])
+    orc.register_user_cost(ring)
+    model = k.CommonLogDensity(2, k.InitFromSnippet(2), ring)
+    ens = k.AisEnsemble(model, 500, seed=8).init()
+    o = orc.OracleAIS(model, 500, seed=8).init()
+    for a, b in zip(ens.state()[:3], o.state()[:3]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ens.advance(3, 6, collect=True), o.generations_sync(3, 6))
+    res = k.sample(model, k.AIS(200), 4000, ntransitions=20, discard_initial=2000, seed=1, return_array=True)
+    assert abs(np.hypot(res[:, 0], res[:, 1]).mean() - 2.0) < 0.03
+    # the kind is refused where nothing can draw it
+    plain = k.costs.UserCost(BANANA_LPI + f"// no init {form}\\n", dims=[2], name="plain", posteriors=["common"])
+    with pytest.raises(k.KabcError, match="KABC_USER_SAMPLE_INIT"):
+        k.AisEnsemble(k.CommonLogDensity(2, k.InitFromSnippet(2), plain), 64, seed=1)
+    with pytest.raises(k.KabcError, match="KABC_USER_SAMPLE_INIT"):
+        k.AisEnsemble(k.ApproxKernelizedPosterior(k.InitFromSnippet(2), k.costs.Rosenbrock(), 1.0), 64, seed=1)
