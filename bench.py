@@ -457,6 +457,32 @@ def main():
 
         by_nt = {str(nt_r): summarise(nt_r, reg) for nt_r, reg in regions.items()}
         h = by_nt[str(nt_head)]
+        # What a smaller ntransitions could reach at best with this kernel: every half-generation
+        # must see the rows the previous one wrote, and the cheapest way to pay for that on this
+        # chip is the kernel boundary itself (profiles/r03_halfgen_floor.json: 3.6 us per half at
+        # 512 workgroups, against 18-31 us for a device-wide barrier inside one launch).
+        if str(100) in by_nt and by_nt["100"]["kernel_avg_us"] > 0:
+            try:
+                fl = json.load(open(os.path.join(ROOT, "profiles", "r03_halfgen_floor.json")))
+                launch_us = float(fl.get("launch_512", 3.6))
+            except Exception:
+                launch_us = 3.6
+            # steady-state time of one sub-step: the slope between the 16 and the 100 setting
+            if "16" in by_nt:
+                sub_us = (by_nt["100"]["kernel_avg_us"] - by_nt["16"]["kernel_avg_us"]) / 84.0
+            else:
+                sub_us = by_nt["100"]["kernel_avg_us"] / 100.0
+            for nt_s, v in by_nt.items():
+                nt_i = int(nt_s)
+                floor_us = nt_i * sub_us + launch_us
+                v["ceiling"] = {"substep_us": sub_us, "launch_boundary_us": launch_us,
+                                "overhead_us": v["kernel_avg_us"] - nt_i * sub_us,
+                                "kernel_floor_us": floor_us,
+                                "roofline_frac_ceiling": rows * nt_i * bytes_per_eval / (floor_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "formula": "ntransitions x steady-state sub-step + the launch boundary (measured "
+                                           "without arithmetic, profiles/r03_halfgen_floor.json); overhead_us = "
+                                           "what a launch adds to its sub-steps today (boundary + 3.3 us pipeline "
+                                           "fill + table staging / drain)"}
         # HBM bytes per launch from PMC counters are collected in separate rocprofv3
         # passes (FETCH_SIZE / WRITE_SIZE cannot share a pass); the committed summary
         # of that run is reported here when it was taken on this very workload.
