@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KABC_VERSION 200 /* 0.2.0 */
+#define KABC_VERSION 300 /* 0.3.0 */
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
 /* AIS and smc accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM run-time-dimension
  * kernels keep the walker / particle rows in memory (several times slower per evaluation, same
