@@ -380,10 +380,19 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t
         const double Z = tz * tz;
         R.zs[si][0][lane] = Z;
         R.zs[si][1][lane] = (double)(D - 1) * kabc_log_pn_tab(Z, logtab);
+        // partner rows b (DE, walk) and c (walk): drawn for every lane, kept by the 3/7 that use
+        // them -- 27 of 64 lanes is one pass either way, and the list indirection goes
+        const kabc_u128_t B2 = kabc_stream_block(seed, w, t, 2u, KABC_DOM_AIS_MOVE);
+        int64_t b = (int64_t)kabc_index32(kabc_lo64(B2), (uint32_t)nc - 1u);
+        b += (b >= (int64_t)a);
+        const int64_t lo = (int64_t)a < b ? (int64_t)a : b, hi = (int64_t)a < b ? b : (int64_t)a;
+        int64_t c = (int64_t)kabc_index32(kabc_hi64(B2), (uint32_t)nc - 2u);
+        c += (c >= lo);
+        c += (c >= hi);
+        R.bb[si][lane] = move >= 2 ? (uint32_t)b : a;  // (a: valid row for the consumer's unconditional prefetch)
+        R.cc[si][lane] = move >= 2 ? (uint32_t)c : a;
     }
     R.mva[si][lane] = ((uint32_t)move << 30) | a;
-    R.bb[si][lane] = a;  // valid row for the consumer's unconditional prefetch
-    R.cc[si][lane] = a;
     // -- compaction of the move-dependent extra work (wave ballot + mbcnt)
     const unsigned long long mDE = __ballot(move == 2), mWK = __ballot(move == 3);
     const unsigned long long mB = mDE | mWK;
@@ -395,23 +404,6 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t
     const int nN = NB * nDE + 2 * (nB - nDE);
     if (move == 2) listB[__popcll(mDE & below)] = (uint8_t)lane;
     if (move == 3) listB[nDE + __popcll(mWK & below)] = (uint8_t)lane;
-    wave_lds_fence();
-    // -- phase B2: partner rows b (and c) for DE / walk lanes, dense
-#pragma unroll 1
-    for (int e = lane; e < ((KABL & 32) ? 0 : nB); e += kWave) {
-        const int l = listB[e];
-        const uint32_t al = R.mva[si][l] & 0x3fffffffu;
-        const kabc_u128_t B2 =
-            kabc_stream_block(seed, w_base + (uint32_t)l, t, 2u, KABC_DOM_AIS_MOVE);
-        int64_t b = (int64_t)kabc_index32(kabc_lo64(B2), (uint32_t)nc - 1u);
-        b += (b >= (int64_t)al);
-        const int64_t lo = (int64_t)al < b ? (int64_t)al : b, hi = (int64_t)al < b ? b : (int64_t)al;
-        int64_t c = (int64_t)kabc_index32(kabc_hi64(B2), (uint32_t)nc - 2u);
-        c += (c >= lo);
-        c += (c >= hi);
-        R.bb[si][l] = (uint32_t)b;
-        R.cc[si][l] = (uint32_t)c;
-    }
     wave_lds_fence();
     // -- walk work, dense: the state-independent displacement W of a walk lane is D independent
     // coordinates, so it is spread over the wave as (walk lane, coordinate) items -- 64 / D walk
