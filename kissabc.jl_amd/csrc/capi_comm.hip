@@ -134,10 +134,11 @@ static bool p2p_host_barrier(P2PGroup* g) {
 static kabc_status_t exchange_setup(kabc_comm* c) {
     if (c->xstream) return KABC_OK;
     KABC_HIP_CHECK(hipSetDevice(c->ctx->device));
-    KABC_HIP_CHECK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    // the stream last: it is the "set up" flag, and a failure half way must not leave it set
     for (int k = 0; k < KABC_MAX_EXCHANGE_CHUNKS; ++k)
-        KABC_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
-    KABC_HIP_CHECK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+        if (!c->ev_chunk[k]) KABC_HIP_CHECK(hipEventCreateWithFlags(&c->ev_chunk[k], hipEventDisableTiming));
+    if (!c->ev_done) KABC_HIP_CHECK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    KABC_HIP_CHECK(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
     return KABC_OK;
 }
 
@@ -578,12 +579,11 @@ kabc_status_t kabc_comm_destroy(kabc_comm_t* c) {
         if (--g->refs == 0) delete g;
     }
     if (c->d_scratch) (void)hipFree(c->d_scratch);
-    if (c->xstream) {
-        (void)hipStreamSynchronize(c->xstream);
-        for (int k = 0; k < KABC_MAX_EXCHANGE_CHUNKS; ++k) (void)hipEventDestroy(c->ev_chunk[k]);
-        (void)hipEventDestroy(c->ev_done);
-        (void)hipStreamDestroy(c->xstream);
-    }
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    for (int k = 0; k < KABC_MAX_EXCHANGE_CHUNKS; ++k)
+        if (c->ev_chunk[k]) (void)hipEventDestroy(c->ev_chunk[k]);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->own_ctx) (void)kabc_ctx_destroy(c->ctx);
     delete c;
     return KABC_OK;
