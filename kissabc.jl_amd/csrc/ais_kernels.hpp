@@ -148,9 +148,6 @@ __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
 //   NORMAL  every component is a plain Normal: SIMPLE without the branch, the support tests and
 //           the push_p rounding (test/runtests.jl:241)
 //   GENERAL everything (Exponential, Beta, NegativeBinomial, Gamma, LogNormal ...)
-#ifndef KABC_GENERAL_UNFENCED_D
-#define KABC_GENERAL_UNFENCED_D 0
-#endif
 enum { kPriorBox = 0, kPriorSimple = 1, kPriorGeneral = 2, kPriorNormal = 3 };
 constexpr int kPriorClasses = 4;
 
@@ -305,7 +302,7 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         else sum = gaussbox_logpdf_push<D, false, true>(GB, y, yp, in);
         lp = in ? sum : -KABC_INF;
     } else {
-        lp = factored_logpdf_push<D, false, (D > KABC_GENERAL_UNFENCED_D)>(P, y, yp);
+        lp = factored_logpdf_push<D, false>(P, y, yp);
     }
     ev = kabc_isfinite(lp);
     if (posterior == KABC_POSTERIOR_KERNELIZED) {
