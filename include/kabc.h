@@ -68,7 +68,12 @@ typedef enum kabc_prior_kind {
      * plugin's own kabc_user_sample_init (include/kabc_costs.h).  Every component of the
      * "prior" carries this kind; it has no density (KABC_POSTERIOR_COMMON never asks for one). */
     KABC_PRIOR_USER_INIT = 10,
-    KABC_PRIOR__COUNT = 11
+    /* Component k of a full-covariance MvNormal(mu, Sigma) prior (the reference takes any
+     * `Distribution`: src/types.jl:30, :34-35, :52; src/smc.jl:92): p = (handle, k) with the
+     * handle of kabc_mvnormal_register below.  All D components of the prior carry this kind,
+     * the same handle and k = their index; D <= KABC_MAX_DIM.  include/kabc_mvnormal.h. */
+    KABC_PRIOR_MVNORMAL = 11,
+    KABC_PRIOR__COUNT = 12
 } kabc_prior_kind_t;
 
 /* one univariate component of Factored(...) */
@@ -148,6 +153,13 @@ kabc_status_t kabc_host_free(void* p);
  * push_p(d::Factored, x)                          -- src/types.jl:29-32
  * rand(rng, d::Factored) for walkers first..first+n of stream (seed, domain, attempt)
  *                                                 -- src/priors.jl:42-43 */
+/* MvNormal(mu, Sigma): mu[D], Sigma[D*D] row-major, symmetric positive definite, 1 <= D <=
+ * KABC_MAX_DIM.  The library keeps the Cholesky factor, its inverse and the constants
+ * (process lifetime); *handle goes into kabc_prior_t.p[0] of D components of kind
+ * KABC_PRIOR_MVNORMAL (p[1] = component index).  A diagonal Sigma needs none of this: it is
+ * Factored(Normal(mu_k, sqrt(Sigma_kk))...). */
+kabc_status_t kabc_mvnormal_register(const double* mu, const double* cov, int32_t D, int32_t* handle);
+
 kabc_status_t kabc_factored_logpdf(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,
                                    int64_t n, const double* x, double* out);
 kabc_status_t kabc_factored_push_p(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D,

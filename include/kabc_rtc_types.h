@@ -13,5 +13,6 @@ typedef unsigned int uint32_t;
 typedef long long int64_t;
 typedef unsigned long long uint64_t;
 typedef unsigned long size_t;
+typedef unsigned long uintptr_t;
 #endif
 #endif

@@ -19,6 +19,7 @@
 
 #include "kabc.h"
 #include "kabc_philox.h"
+#include "kabc_mvnormal.h"
 
 #define KABC_SLOTS_PER_DIM 128u
 
@@ -150,6 +151,24 @@ KABC_HD double kabc_sample_prior(const kabc_prior_t* pr, const kabc_slotwin_t* w
             double z0, z1;
             kabc_normal_pair(kabc_lo64(b), kabc_hi64(b), &z0, &z1);
             return kabc_exp(p0 + p1 * z0);
+        }
+        case KABC_PRIOR_MVNORMAL: {
+            /* x_k = mu_k + sum_{j<=k} L[k][j] z_j, z_j = the standard normal dimension j's own
+             * window yields (the draw a Normal component would make there).  `pr` is a RESOLVED
+             * component: p[1] = k, p[2] = the prepared block, p[3] = D (kabc_mvnormal.h). */
+            const int k = (int)p1, D = (int)pr->p[3];
+            const double* blk = kabc_mvn_ptr_from_double(pr->p[2]);
+            const double* L = kabc_mvn_L(blk, D) + k * D;
+            double acc = 0.0;
+            for (int j = 0; j <= k; ++j) {
+                kabc_slotwin_t wj = *w;
+                wj.base = w->base - (uint32_t)(k - j) * KABC_SLOTS_PER_DIM;
+                kabc_u128_t b = kabc_slot(&wj, 0);
+                double z0, z1;
+                kabc_normal_pair(kabc_lo64(b), kabc_hi64(b), &z0, &z1);
+                acc = acc + L[j] * z0;
+            }
+            return blk[k] + acc;
         }
         default: return KABC_NAN;
     }

@@ -21,6 +21,7 @@ KABC_OK, KABC_ERR_INVALID_ARG, KABC_ERR_RETRY_EXHAUSTED, KABC_ERR_INVALID_STATE,
 PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_BETA, PRIOR_DISCRETE_UNIFORM, \
     PRIOR_NEGBINOMIAL, PRIOR_EXPONENTIAL, PRIOR_GAMMA, PRIOR_LOGNORMAL = range(1, 10)
 PRIOR_USER_INIT = 10
+PRIOR_MVNORMAL = 11
 
 POSTERIOR_KERNELIZED, POSTERIOR_THRESHOLD, POSTERIOR_COMMON = 1, 2, 3
 
@@ -103,6 +104,7 @@ VP = C.c_void_p
 PROTOTYPES = {
     "kabc_version": (C.c_int32, []),
     "kabc_abi_sizeof": (C.c_int32, [C.c_int32]),
+    "kabc_mvnormal_register": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.POINTER(C.c_int32)]),
     "kabc_last_error": (C.c_char_p, []),
     "kabc_device_count": (C.c_int32, []),
     "kabc_ctx_create": (C.c_int, [C.c_int32, VP, C.POINTER(VP)]),

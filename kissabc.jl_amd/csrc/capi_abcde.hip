@@ -151,6 +151,9 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         set_error("nparticles must be >= 3 (and < 2^31)");
         return KABC_ERR_INVALID_ARG;
     }
+    std::vector<kabc_prior_t> resolved((size_t)D);  // MvNormal components: device block, D
+    if (kabc_status_t st = resolve_priors(ctx, prior, D, resolved.data())) return st;
+    prior = resolved.data();
     AbcdeArgs A;
     std::memset(&A, 0, sizeof A);
     std::vector<PriorDev> Pdyn((size_t)(dyn ? D : 0));

@@ -229,6 +229,13 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
                   KABC_MAX_DIM_DYN);
         return KABC_ERR_UNSUPPORTED;
     }
+    // the library-side fields of MvNormal components (device block, D): everything below works
+    // on the resolved copy
+    std::vector<kabc_prior_t> resolved((size_t)m->D);
+    if (kabc_status_t st = resolve_priors(ctx, m->prior, m->D, resolved.data())) return st;
+    kabc_model_t mres = *m;
+    mres.prior = resolved.data();
+    m = &mres;
     const bool dyn = m->D > KABC_MAX_DIM;
     AisDynLaunchFn dyn_fn = nullptr;
     if (dyn) {

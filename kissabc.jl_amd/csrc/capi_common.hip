@@ -1,5 +1,9 @@
 // capi_common.hip -- context, error plumbing, prior preparation and the small
 // Factored utility kernels (logpdf / rand) of the C ABI (include/kabc.h).
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "ais_kernels.hpp"
 #include "host_common.hpp"
 
@@ -17,6 +21,63 @@ const char* get_error() { return g_err; }
 
 static double std_normal_cdf(double z) { return 0.5 * std::erfc(-z * M_SQRT1_2); }
 
+// ---- MvNormal(mu, Sigma) priors (include/kabc_mvnormal.h) ---------------------------
+// Registered once per process; the prepared block is copied to a device at first use there.
+struct MvnEntry {
+    int D = 0;
+    std::vector<double> host;
+    std::map<int, double*> dev;  // device id -> block
+};
+static std::mutex g_mvn_mu;
+static std::vector<MvnEntry*> g_mvn;
+
+kabc_status_t resolve_priors(kabc_ctx_t* ctx, const kabc_prior_t* prior, int D, kabc_prior_t* out) {
+    if (!ctx || !prior || D < 1 || D > KABC_MAX_DIM_DYN) {
+        set_error("invalid prior: NULL or D outside 1..%d", KABC_MAX_DIM_DYN);
+        return KABC_ERR_INVALID_ARG;
+    }
+    int nmv = 0;
+    for (int k = 0; k < D; ++k) {
+        out[k] = prior[k];
+        nmv += prior[k].kind == KABC_PRIOR_MVNORMAL;
+    }
+    if (nmv == 0) return KABC_OK;
+    if (nmv != D || D > KABC_MAX_DIM) {
+        set_error("an MvNormal prior is all D components of the prior (kind KABC_PRIOR_MVNORMAL, one handle, "
+                  "p[1] = index), D <= %d; it does not mix with univariate components (the reference's "
+                  "Factored takes univariate distributions only, src/priors.jl:10-13)", KABC_MAX_DIM);
+        return nmv != D ? KABC_ERR_INVALID_ARG : KABC_ERR_UNSUPPORTED;
+    }
+    const int h = (int)prior[0].p[0];
+    std::lock_guard<std::mutex> lk(g_mvn_mu);
+    if (h < 1 || h > (int)g_mvn.size() || g_mvn[h - 1]->D != D) {
+        set_error("MvNormal prior: handle %d is not a registered %d-dimensional MvNormal "
+                  "(kabc_mvnormal_register)", h, D);
+        return KABC_ERR_INVALID_ARG;
+    }
+    MvnEntry* e = g_mvn[h - 1];
+    for (int k = 0; k < D; ++k)
+        if ((int)prior[k].p[0] != h || prior[k].p[1] != (double)k) {
+            set_error("MvNormal prior: component %d must carry p = (handle %d, %d)", k + 1, h, k);
+            return KABC_ERR_INVALID_ARG;
+        }
+    double* d = nullptr;
+    auto it = e->dev.find(ctx->device);
+    if (it != e->dev.end()) {
+        d = it->second;
+    } else {
+        KABC_HIP_CHECK(hipSetDevice(ctx->device));
+        KABC_HIP_CHECK(hipMalloc(&d, sizeof(double) * e->host.size()));
+        KABC_HIP_CHECK(hipMemcpy(d, e->host.data(), sizeof(double) * e->host.size(), hipMemcpyHostToDevice));
+        e->dev[ctx->device] = d;
+    }
+    for (int k = 0; k < D; ++k) {
+        out[k].p[2] = kabc_mvn_ptr_to_double(d);
+        out[k].p[3] = (double)D;
+    }
+    return KABC_OK;
+}
+
 bool prepare_prior(const kabc_prior_t& pr, PriorDev& q) {
     q.kind = pr.kind;
     q.discrete = kabc_prior_is_discrete(pr.kind);
@@ -25,6 +86,9 @@ bool prepare_prior(const kabc_prior_t& pr, PriorDev& q) {
     const double a = pr.p[0], b = pr.p[1];
     q.rb = 1.0 / ((pr.kind == KABC_PRIOR_EXPONENTIAL) ? a : b);
     switch (pr.kind) {
+        case KABC_PRIOR_MVNORMAL:  // a RESOLVED component (resolve_priors): p[2] = the device block
+            q.rb = 0.0;
+            return kabc_bits(pr.p[2]) != 0 && pr.p[3] >= 1.0;
         case KABC_PRIOR_USER_INIT:  // no density, no parameters (drawn by the cost plugin)
             q.rb = 0.0;
             return true;
@@ -106,7 +170,10 @@ __global__ void __launch_bounds__(256) prior_logpdf_kernel(const PriorUtilArgs A
             A.out[i * A.D + k] = v;
         } else {
             // logpdf(Factored, x) is evaluated on x as given (src/priors.jl:30-36)
-            const double l = comp_logpdf(q.kind, q, xv);
+            // (an MvNormal component reads coordinates 0..k of the row: continuous, x as given)
+            const double l = q.kind == KABC_PRIOR_MVNORMAL
+                                 ? kabc_mvn_logpdf_comp(kabc_mvn_ptr_from_double(q.p[2]), A.D, k, A.x + i * A.D)
+                                 : comp_logpdf(q.kind, q, xv);
             s = (k == 0) ? l : s + l;
         }
     }
@@ -265,6 +332,9 @@ static kabc_status_t prior_util(kabc_ctx_t* ctx, const kabc_prior_t* prior, int3
         set_error("invalid prior: D outside 1..%d", KABC_MAX_DIM_DYN);
         return KABC_ERR_INVALID_ARG;
     }
+    std::vector<kabc_prior_t> rp((size_t)D);
+    if (kabc_status_t st = resolve_priors(ctx, prior, D, rp.data())) return st;
+    prior = rp.data();
     std::vector<PriorDev> prep((size_t)D);
     for (int k = 0; k < D; ++k)
         if (!prepare_prior(prior[k], prep[k])) {
@@ -310,6 +380,31 @@ static kabc_status_t prior_util(kabc_ctx_t* ctx, const kabc_prior_t* prior, int3
     (void)hipFree(dout);
     (void)hipFree(d_prep);
     (void)hipFree(d_raw);
+    return KABC_OK;
+}
+
+kabc_status_t kabc_mvnormal_register(const double* mu, const double* cov, int32_t D, int32_t* handle) {
+    if (!mu || !cov || !handle || D < 1 || D > KABC_MAX_DIM) {
+        set_error("kabc_mvnormal_register: NULL argument or D outside 1..%d", KABC_MAX_DIM);
+        return KABC_ERR_INVALID_ARG;
+    }
+    for (int i = 0; i < D; ++i)
+        if (!kabc_isfinite(mu[i])) {
+            set_error("kabc_mvnormal_register: mu[%d] is not finite", i);
+            return KABC_ERR_INVALID_ARG;
+        }
+    MvnEntry* e = new MvnEntry();
+    e->D = D;
+    e->host.resize((size_t)kabc_mvn_block_words(D));
+    const int rc = kabc_mvn_prepare(D, mu, cov, e->host.data());
+    if (rc) {
+        delete e;
+        set_error("kabc_mvnormal_register: Sigma is not %s", rc == 1 ? "symmetric" : "positive definite");
+        return KABC_ERR_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lk(g_mvn_mu);
+    g_mvn.push_back(e);
+    *handle = (int32_t)g_mvn.size();
     return KABC_OK;
 }
 

@@ -259,6 +259,9 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     }
     // beyond KABC_MAX_DIM: run-time-dimension kernels (smc_dyn_kernels.hpp) on the
     // kernel-per-phase path; the selection / control kernels do not depend on D
+    std::vector<kabc_prior_t> resolved((size_t)D);  // MvNormal components: device block, D
+    if (kabc_status_t st = resolve_priors(ctx, prior, D, resolved.data())) return st;
+    prior = resolved.data();
     const bool dyn = D > KABC_MAX_DIM;
     PriorSet P;
     std::memset(&P, 0, sizeof P);
@@ -845,6 +848,9 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     }
     // length(prior) > KABC_MAX_DIM: the run-time-dimension instantiation (D = 0) of the kernels,
     // prior components as device arrays
+    std::vector<kabc_prior_t> resolved((size_t)D);  // MvNormal components: device block, D
+    if (kabc_status_t st = resolve_priors(ctx, prior, D, resolved.data())) return st;
+    prior = resolved.data();
     const bool dyn = D > KABC_MAX_DIM;
     PriorSet P;
     std::memset(&P, 0, sizeof P);

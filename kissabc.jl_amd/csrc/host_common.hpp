@@ -31,6 +31,9 @@ const char* get_error();
 // derived constants of one Factored component.  Host libm supplies the one-off
 // normalisers (lgamma, erfc); everything evaluated per walker goes through the
 // math contract.  Returns false for invalid parameters.
+// copy of the caller's components with the library-side fields of MvNormal components filled in
+// (device block pointer, D); every entry point resolves before it prepares or copies the prior
+kabc_status_t resolve_priors(kabc_ctx_t* ctx, const kabc_prior_t* prior, int D, kabc_prior_t* out);
 bool prepare_prior(const kabc_prior_t& pr, PriorDev& q);
 bool prepare_priors(const kabc_prior_t* prior, int D, PriorSet& out);
 

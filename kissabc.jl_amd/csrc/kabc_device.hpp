@@ -126,6 +126,32 @@ __device__ __forceinline__ double comp_logpdf(int kind, const PriorDev& q, doubl
         return comp_logpdf_general(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
 }
 
+// the prepared block of an MvNormal prior (kabc_mvnormal.h) as a wave-uniform pointer
+__device__ __forceinline__ const double* mvn_block(const PriorDev& q) {
+    const uint64_t b = kabc_bits(q.p[2]);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)b);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));
+    return (const double*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+// The whole MvNormal log-density.  (Inline: as an out-of-line function it was the first call in
+// the smc kernels' propose/accept pass, and smc_loop_kernel -- 256 VGPRs + AGPR spill space -- then
+// produced different trajectories for OTHER priors; `tests/test_gpu_random_sweep.py`.)
+template <int D>
+struct MvnRow {
+    double v[D];
+};
+template <int D>
+__device__ __forceinline__ double mvn_logpdf_total(const double* blk, MvnRow<D> x) {
+    double sm = 0.0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const double l = kabc_mvn_logpdf_comp(blk, D, k, x.v);
+        sm = (k == 0) ? l : sm + l;
+    }
+    return sm;
+}
+
 // host-side classification used to pick the kernel variant
 inline bool prior_is_simple(int kind) {
     return kind == KABC_PRIOR_UNIFORM || kind == KABC_PRIOR_NORMAL ||
@@ -143,6 +169,7 @@ template <int D, bool SIMPLE = false, bool FENCED = true>
 __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restrict__ P,
                                                        const double* x, double* xp) {
     double s = 0.0;
+    [[maybe_unused]] int kind0 = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         if constexpr (FENCED) __builtin_amdgcn_sched_barrier(0);
@@ -150,12 +177,29 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restric
         // the prior is the same for every lane: kind / discrete as SCALARS make the family
         // dispatch a uniform branch instead of an exec-masked walk through every case
         const int kind = __builtin_amdgcn_readfirstlane(q.kind);
+        if (k == 0) kind0 = kind;
         const bool disc = __builtin_amdgcn_readfirstlane(q.discrete) != 0;
         const double v = disc ? kabc_rint(x[k]) : x[k];
         xp[k] = v;
         const double l = SIMPLE ? comp_logpdf_simple(kind, q, v) : comp_logpdf<D>(kind, q, v);
         s = (k == 0) ? l : s + l;
     }
+#ifndef KABC_NO_MVN_DEVICE  // (A/B builds: the case compiled out)
+    if constexpr (!SIMPLE) {
+        // A full-covariance MvNormal (kabc_mvnormal.h) is all D components or none.  Its
+        // components went through the loop above like any other (continuous: xp = x; the family
+        // switch returned NaN for each), so that the two paths meet on ONE value, the sum -- a
+        // branch in front of the loop made them meet on all of xp as well, which cost every other
+        // GENERAL prior 3-5 % of an AIS launch in register copies.  The block pointer is
+        // wave-uniform.
+        if (kind0 == KABC_PRIOR_MVNORMAL) {  // (component 0's family: the scalar the loop read)
+            MvnRow<D> r;
+#pragma unroll
+            for (int j = 0; j < D; ++j) r.v[j] = xp[j];
+            s = mvn_logpdf_total<D>(mvn_block(P[0]), r);
+        }
+    }
+#endif
     return s;
 }
 template <int D, bool SIMPLE = false>

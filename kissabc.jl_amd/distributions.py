@@ -238,11 +238,30 @@ class Product(Factored):
         return "Product([" + ", ".join(map(repr, self.p)) + "])"
 
 
+class _MvNormalComponent(UnivariateDistribution):
+    """Component k of a full-covariance MvNormal: (handle, k) of kabc_mvnormal_register."""
+    kind = cd.PRIOR_MVNORMAL
+
+    def __init__(self, owner, k):
+        self.owner, self.k = owner, int(k)
+
+    def params(self):
+        return (self.owner.handle(), self.k)
+
+    def __repr__(self):
+        return f"MvNormal[{self.k}]"
+
+
 class MvNormal(Product):
-    """MultivariateNormal with a DIAGONAL covariance: MvNormal(d, σ) (zero mean, isotropic --
-    the form test/runtests.jl:186 uses), MvNormal(μ, σ) with σ a scalar or a vector of
-    standard deviations.  It is a product of Normals, so it runs on the Factored kernels; a
-    full covariance matrix would need a triangular solve per walker and is not on this path."""
+    """MultivariateNormal of Distributions.jl as a prior (the reference takes any Distribution:
+    src/types.jl:30, :34-35, :52; src/smc.jl:92).
+
+    MvNormal(d, σ) (zero mean, isotropic -- the form test/runtests.jl:186 uses) and MvNormal(μ, σ)
+    with σ a scalar or a vector of standard deviations are products of Normals and run on the
+    Factored kernels as such.  MvNormal(μ, Σ) with a covariance MATRIX is registered with the
+    library (kabc_mvnormal_register: Cholesky factor, its inverse, constants) and travels as D
+    components of kind KABC_PRIOR_MVNORMAL (include/kabc_mvnormal.h); a diagonal Σ is lowered to
+    Normal(μ_k, sqrt(Σ_kk)) components."""
 
     def __init__(self, mu_or_dim, sigma=1.0):
         if np.isscalar(mu_or_dim):
@@ -250,14 +269,34 @@ class MvNormal(Product):
         else:
             mu = np.asarray(mu_or_dim, dtype=float).ravel()
         sig = np.asarray(sigma, dtype=float)
+        self.mu, self.cov, self._h = mu, None, {}
         if sig.ndim == 2:
-            raise TypeError("MvNormal with a full covariance matrix is not supported on the device "
-                            "path (diagonal / isotropic only)")
+            if sig.shape != (mu.size, mu.size):
+                raise ValueError(f"MvNormal: Σ must be {mu.size} x {mu.size}")
+            if np.count_nonzero(sig - np.diag(np.diagonal(sig))) == 0:
+                sig = np.sqrt(np.diagonal(sig))          # diagonal Σ: a product of Normals
+            else:
+                if mu.size > cd.KABC_MAX_DIM:
+                    raise ValueError(f"a full-covariance MvNormal prior supports length(prior) <= {cd.KABC_MAX_DIM}")
+                self.cov = np.ascontiguousarray(sig)
+                super().__init__([_MvNormalComponent(self, k) for k in range(mu.size)])
+                self.handle()                            # validates Σ now (symmetric, positive definite)
+                return
         sig = np.broadcast_to(sig, mu.shape)
         super().__init__([Normal(m, s) for m, s in zip(mu, sig)])
 
+    def handle(self):
+        """the library's handle of the prepared block (kabc_mvnormal_register), taken once"""
+        if "lib" not in self._h:
+            h = C.c_int32()
+            _lib.check(_lib.load().kabc_mvnormal_register(
+                self.mu.ctypes.data_as(cd.c_double_p), self.cov.ctypes.data_as(cd.c_double_p),
+                self.mu.size, C.byref(h)))
+            self._h["lib"] = int(h.value)
+        return self._h["lib"]
+
     def __repr__(self):
-        return f"MvNormal(dim={len(self)})"
+        return f"MvNormal(dim={len(self)}{', full covariance' if self.cov is not None else ''})"
 
 
 MultivariateNormal = MvNormal

@@ -14,7 +14,7 @@
 # Dispatch: `AbstractMCMC.step(rng, model::DeviceModel, spl::AIS; ...)` is more specific than
 # the reference's `step(rng, model::AbstractDensity, spl::AIS; ...)` (src/KissABC.jl:35-41,66-72).
 #
-# It contains no numerics: it lowers `Factored` / `Product` / diagonal `MvNormal` /
+# It contains no numerics: it lowers `Factored` / `Product` / `MvNormal` (diagonal or full) /
 # univariate Distributions to `kabc_prior_t`, a DeviceCost to `kabc_cost_t`, calls the library
 # and wraps the result in `Particles` exactly as src/KissABC.jl:82-104 and src/smc.jl:200-205,
 # :334-340, :425-430 do.  It mirrors kissabc.jl_amd/api.py call for call.
@@ -216,11 +216,22 @@ lower_prior(d::Factored) = KabcPrior[lower(c) for c in d.p]
 # vector-valued walkers (test/runtests.jl:30,186): products of univariate components run on the
 # Factored kernels; only the shape of the emitted sample differs (Vector instead of Tuple)
 lower_prior(d::Product) = KabcPrior[lower(c) for c in d.v]
+# a diagonal Σ is a product of Normals; a full Σ is registered with the library (Cholesky factor,
+# its inverse and the constants are kept there: include/kabc_mvnormal.h) and travels as D
+# components of kind KABC_PRIOR_MVNORMAL carrying (handle, index)
+const mvnormal_handles = IdDict{Any,Int32}()
 function lower_prior(d::AbstractMvNormal)
-    Σ = cov(d)
-    isdiag(Σ) || error("MvNormal with a full covariance matrix is not supported on the device path " *
-                       "(diagonal / isotropic only)")
-    KabcPrior[KabcPrior(2, 0, (m, sqrt(v), 0.0, 0.0)) for (m, v) in zip(mean(d), diag(Σ))]
+    Σ = Matrix{Float64}(cov(d))
+    μ = Vector{Float64}(mean(d))
+    isdiag(Σ) && return KabcPrior[KabcPrior(2, 0, (m, sqrt(v), 0.0, 0.0)) for (m, v) in zip(μ, diag(Σ))]
+    h = get!(mvnormal_handles, d) do
+        r = Ref{Int32}(0)
+        # row-major D x D: Σ is symmetric, so Julia's column-major storage is the same matrix
+        check(ccall((:kabc_mvnormal_register, libkabc), Cint, (Ptr{Float64}, Ptr{Float64}, Int32, Ref{Int32}),
+                    μ, Σ, Int32(length(μ)), r))
+        r[]
+    end
+    KabcPrior[KabcPrior(11, 0, (Float64(h), Float64(k - 1), 0.0, 0.0)) for k in 1:length(μ)]
 end
 vector_valued(d) = d isa MultivariateDistribution && !(d isa Factored)
 

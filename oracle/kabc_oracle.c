@@ -136,6 +136,9 @@ static int prepare_prior(const kabc_prior_t* pr, prep_t* q) {
         case KABC_PRIOR_USER_INIT: /* no density: CommonLogDensity's own sample_init (src/types.jl:112) */
             q->rb = 0.0;
             return 1;
+        case KABC_PRIOR_MVNORMAL: /* resolved by oracle.py: p[1] = k, p[2] = the block, p[3] = D */
+            q->rb = 0.0;
+            return kabc_bits(pr->p[2]) != 0 && pr->p[3] >= 1.0;
         case KABC_PRIOR_UNIFORM:
             if (!(b > a)) return 0;
             q->c0 = -kabc_log(b - a);
@@ -229,10 +232,40 @@ static void push_p(const prep_t* q, int D, const double* x, double* out) {
 }
 
 /* logpdf(d::Factored, x): s = logpdf(p[1],x[1]); for i=2:N s += ... (src/priors.jl:30-36) */
+/* component k; an MvNormal component (include/kabc_mvnormal.h: Distributions.jl's
+ * logpdf(MvNormal, x) split into D Normal-shaped terms) reads coordinates 0..k */
+static double comp_logpdf_k(const prep_t* q, int D, int k, const double* x) {
+    if (q[k].kind == KABC_PRIOR_MVNORMAL)
+        return kabc_mvn_logpdf_comp(kabc_mvn_ptr_from_double(q[k].p[2]), D, k, x);
+    return comp_logpdf(&q[k], x[k]);
+}
 static double factored_logpdf(const prep_t* q, int D, const double* x) {
-    double s = comp_logpdf(&q[0], x[0]);
-    for (int k = 1; k < D; ++k) s += comp_logpdf(&q[k], x[k]);
+    double s = comp_logpdf_k(q, D, 0, x);
+    for (int k = 1; k < D; ++k) s += comp_logpdf_k(q, D, k, x);
     return s;
+}
+
+/* MvNormal(mu, Sigma) priors: the oracle's own registry of prepared blocks (oracle.py resolves
+ * the components it hands over: p[2] = orc_mvnormal_block(handle) as a double's bits, p[3] = D) */
+static double* g_mvn_blk[256];
+static int g_mvn_dim[256];
+static int g_mvn_n;
+int32_t orc_mvnormal_register(const double* mu, const double* cov, int32_t D, int32_t* handle) {
+    if (!mu || !cov || !handle || D < 1 || D > KABC_MAX_DIM) return fail(KABC_ERR_INVALID_ARG, "bad MvNormal");
+    if (g_mvn_n >= 256) return fail(KABC_ERR_UNSUPPORTED, "too many MvNormal priors");
+    double* blk = (double*)malloc(sizeof(double) * (size_t)kabc_mvn_block_words(D));
+    const int rc = kabc_mvn_prepare(D, mu, cov, blk);
+    if (rc) {
+        free(blk);
+        return fail(KABC_ERR_INVALID_ARG, rc == 1 ? "Sigma is not symmetric" : "Sigma is not positive definite");
+    }
+    g_mvn_blk[g_mvn_n] = blk;
+    g_mvn_dim[g_mvn_n] = D;
+    *handle = ++g_mvn_n;
+    return KABC_OK;
+}
+uint64_t orc_mvnormal_block(int32_t handle) {
+    return (handle >= 1 && handle <= g_mvn_n) ? (uint64_t)(uintptr_t)g_mvn_blk[handle - 1] : 0;
 }
 
 static int prep_all(const kabc_prior_t* prior, int32_t D, prep_t* q) {
@@ -256,8 +289,8 @@ int32_t orc_factored_pdf(const kabc_prior_t* prior, int32_t D, int64_t n, const 
     prep_t q[ORC_MAX_DIM];
     if (!prep_all(prior, D, q)) return fail(KABC_ERR_INVALID_ARG, "invalid prior");
     for (int64_t i = 0; i < n; ++i) {
-        double s = exp(comp_logpdf(&q[0], x[i * D]));
-        for (int k = 1; k < D; ++k) s *= exp(comp_logpdf(&q[k], x[i * D + k]));
+        double s = exp(comp_logpdf_k(q, D, 0, x + i * D));
+        for (int k = 1; k < D; ++k) s *= exp(comp_logpdf_k(q, D, k, x + i * D));
         out[i] = s;
     }
     return KABC_OK;

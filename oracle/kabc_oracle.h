@@ -67,6 +67,10 @@ double orc_cdf_g_inv(double u, double a);
 /* register the gcc-compiled twin of a user DeviceCost plugin under its id */
 int32_t orc_register_user_cost(int32_t id, void* fn);
 int32_t orc_register_user_init(int32_t id, void* fn);
+/* MvNormal(mu, Sigma) priors (include/kabc_mvnormal.h): the oracle's registry; the components it is
+ * handed are resolved by the caller: p[1] = k, p[2] = bits of orc_mvnormal_block(handle), p[3] = D */
+int32_t orc_mvnormal_register(const double* mu, const double* cov, int32_t D, int32_t* handle);
+uint64_t orc_mvnormal_block(int32_t handle);
 
 /* AIS */
 int32_t orc_ais_create(const kabc_model_t* model, int64_t nparticles, uint64_t seed,

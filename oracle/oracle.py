@@ -60,6 +60,8 @@ def load():
             "orc_cdf_g_inv": (C.c_double, [C.c_double, C.c_double]),
             "orc_register_user_cost": (C.c_int32, [C.c_int32, C.c_void_p]),
             "orc_register_user_init": (C.c_int32, [C.c_int32, C.c_void_p]),
+            "orc_mvnormal_register": (C.c_int32, [dp, dp, C.c_int32, C.POINTER(C.c_int32)]),
+            "orc_mvnormal_block": (C.c_uint64, [C.c_int32]),
             "orc_ais_create": (C.c_int32, [C.POINTER(cd.Model), C.c_int64, C.c_uint64,
                                            C.POINTER(VP)]),
             "orc_ais_init": (C.c_int32, [VP, C.c_int32]),
@@ -96,6 +98,33 @@ def _check(st):
 
 def _dp(a):
     return a.ctypes.data_as(cd.c_double_p)
+
+
+def _prior_c(fac):
+    """kabc_prior_t[D] for the ORACLE: a full-covariance MvNormal is registered with the oracle's
+    own registry and handed over resolved (p[1] = k, p[2] = the block's address as a double's
+    bits, p[3] = D; include/kabc_mvnormal.h) -- the library resolves its own handles itself."""
+    if getattr(fac, "cov", None) is None:
+        return fac.to_c()
+    L = load()
+    h = getattr(fac, "_oracle_handle", None)
+    if h is None:
+        hh = C.c_int32()
+        _check(L.orc_mvnormal_register(_dp(fac.mu), _dp(fac.cov), len(fac), C.byref(hh)))
+        h = fac._oracle_handle = int(hh.value)
+    blk = np.array([L.orc_mvnormal_block(h)], dtype=np.uint64).view(np.float64)[0]
+    arr = (cd.Prior * len(fac))()
+    for k in range(len(fac)):
+        arr[k] = cd.Prior(cd.PRIOR_MVNORMAL, 0, (C.c_double * 4)(float(h), float(k), blk, float(len(fac))))
+    return arr
+
+
+def _model_c(model):
+    m = model.to_c()
+    if getattr(model.prior, "cov", None) is not None:
+        model._prior_c_oracle = _prior_c(model.prior)
+        m.prior = C.cast(model._prior_c_oracle, C.POINTER(cd.Prior))
+    return m
 
 
 MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6,
@@ -148,28 +177,28 @@ def _rows(prior, x):
 def factored_logpdf(prior, x):
     fac, a = _rows(prior, x)
     out = np.empty(a.shape[0])
-    _check(load().orc_factored_logpdf(fac.to_c(), len(fac), a.shape[0], _dp(a), _dp(out)))
+    _check(load().orc_factored_logpdf(_prior_c(fac), len(fac), a.shape[0], _dp(a), _dp(out)))
     return out
 
 
 def factored_pdf(prior, x):
     fac, a = _rows(prior, x)
     out = np.empty(a.shape[0])
-    _check(load().orc_factored_pdf(fac.to_c(), len(fac), a.shape[0], _dp(a), _dp(out)))
+    _check(load().orc_factored_pdf(_prior_c(fac), len(fac), a.shape[0], _dp(a), _dp(out)))
     return out
 
 
 def push_p(prior, x):
     fac, a = _rows(prior, x)
     out = np.empty_like(a)
-    _check(load().orc_push_p(fac.to_c(), len(fac), a.shape[0], _dp(a), _dp(out)))
+    _check(load().orc_push_p(_prior_c(fac), len(fac), a.shape[0], _dp(a), _dp(out)))
     return out
 
 
 def factored_rand(prior, n, seed=0, domain=cd.DOM_AIS_INIT, first_walker=0, attempt=0):
     fac = as_factored(prior)
     out = np.empty((n, len(fac)))
-    _check(load().orc_factored_rand(fac.to_c(), len(fac), seed, domain, first_walker, n, attempt,
+    _check(load().orc_factored_rand(_prior_c(fac), len(fac), seed, domain, first_walker, n, attempt,
                                     _dp(out)))
     return out
 
@@ -230,7 +259,7 @@ class OracleAIS:
 
     def __init__(self, model, nparticles, seed=0):
         self.model, self.N, self.D = model, int(nparticles), len(model)
-        self._cm = model.to_c()
+        self._cm = _model_c(model)
         self._h = C.c_void_p()
         _check(load().orc_ais_create(C.byref(self._cm), self.N, seed, C.byref(self._h)))
 
@@ -311,7 +340,7 @@ def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.01
     r.alive = alive.ctypes.data_as(C.POINTER(C.c_uint8))
     r.iter_log, r.iter_log_cap = log, 4096
     cc = cost.to_c()
-    _check(load().orc_smc_run(fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    _check(load().orc_smc_run(_prior_c(fac), D, C.byref(cc), C.byref(o), C.byref(r)))
     nit = min(r.iterations, 4096)
     return {
         "theta_all": theta, "C": Cst, "alive": alive.astype(bool), "eps": r.eps,
@@ -336,7 +365,7 @@ def abcde(prior, cost, eps_target, *, nparticles=50, generations=20, alpha=0.0, 
     r = cd.AbcdeResult()
     r.theta, r.cost = _dp(theta), _dp(Cst)
     cc = cost.to_c()
-    _check(load().orc_abcde_run(fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    _check(load().orc_abcde_run(_prior_c(fac), D, C.byref(cc), C.byref(o), C.byref(r)))
     return {"P": theta, "C": Cst, "reached_eps": bool(r.reached_eps),
             "generations_run": r.generations_run, "nsims": r.nsims}
 
@@ -356,6 +385,6 @@ def pfilter(prior, cost, N, *, q=0.7, eff_tol=0.1, epstol=-math.inf, max_iters=m
     r = cd.PfilterResult()
     r.theta, r.cost = _dp(theta), _dp(Cst)
     cc = cost.to_c()
-    _check(load().orc_pfilter_run(fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
+    _check(load().orc_pfilter_run(_prior_c(fac), D, C.byref(cc), C.byref(o), C.byref(r)))
     return {"P": theta, "C": Cst, "eps": r.eps, "eff": r.eff, "iterations": r.iterations,
             "nreps": r.nreps, "cost_evals": r.cost_evals}

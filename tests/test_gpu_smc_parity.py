@@ -172,3 +172,23 @@ def test_loop_kernel_giving_up_repeats_the_run_on_the_kernel_path(k, orc, gpu_ct
     r = k.smc(prior, cost, return_array=True, **kw)
     assert r.eps == ref["eps"] and np.array_equal(r.info["theta_all"], ref["theta_all"])
     assert r.info["iterations"] == ref["iterations"]
+
+
+@pytest.mark.parametrize("path", ["loop", "kernels"])
+@pytest.mark.parametrize("D", [9, 12, 16])
+def test_general_priors_beyond_eight_parameters(k, orc, gpu_ctx, monkeypatch, path, D):
+    """GENERAL prior class with more than 8 components: the per-component log-density is an
+    out-of-line function there (csrc/kabc_device.hpp kGeneralInlineD) -- the only call inside the
+    propose/accept pass of the smc kernels.  Both drivers, all nine families in the prior."""
+    monkeypatch.setenv("KABC_SMC_LOOP", "1" if path == "loop" else "0")
+    fam = [k.Gamma(2.5, 0.7), k.LogNormal(0.3, 0.6), k.Beta(2, 3), k.Normal(0, 1), k.Uniform(-2, 3),
+           k.Exponential(1.5), k.TruncatedNormal(0, 1, -1, 2), k.DiscreteUniform(0, 6),
+           k.NegativeBinomial(4.0, 0.4)]
+    prior = k.Factored(*[fam[i % 9] for i in range(D)])
+    cost = k.costs.GaussDist(np.linspace(0.2, 1.5, D))
+    kw = dict(nparticles=2000, alpha=0.9, epstol=2.0, mcmc_retrys=1, seed=11)
+    got = k.smc(prior, cost, return_array=True, **kw)
+    ref = orc.smc(prior, cost, **kw)
+    assert got.info["log"] == ref["log"] and got.eps == ref["eps"]
+    assert np.array_equal(got.info["theta_all"], ref["theta_all"])
+    assert np.array_equal(got.info["alive"], ref["alive"]) and np.array_equal(got.C, ref["C"])

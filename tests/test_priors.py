@@ -105,5 +105,47 @@ def test_vector_valued_priors_are_products_of_their_components(orc, k):
     xs = orc.push_p(pr, orc.factored_rand(pr, 100, seed=2))
     assert np.all((xs[:, 0] >= 0) & (xs[:, 0] <= 2)) and np.array_equal(xs[:, 1], np.rint(xs[:, 1]))
     assert k.MultivariateNormal is k.MvNormal
-    with pytest.raises(TypeError, match="full covariance"):
-        k.MvNormal(np.zeros(2), np.array([[1.0, 0.3], [0.3, 1.0]]))
+
+
+def _mv_cases():
+    rng = np.random.default_rng(11)
+    out = []
+    for D in (1, 2, 3, 8, 16):
+        A = rng.normal(size=(D, D))
+        out.append((rng.normal(size=D) * 2, A @ A.T + 0.3 * np.eye(D)))
+    out.append((np.array([1.0, -1.0]), np.array([[1.0, 0.999], [0.999, 1.0]])))   # nearly singular
+    return out
+
+
+@pytest.mark.parametrize("mu,cov", _mv_cases(), ids=lambda v: f"D{np.asarray(v).shape[0]}")
+def test_full_covariance_mvnormal_against_scipy(orc, k, mu, cov):
+    """MvNormal(μ, Σ) with a covariance matrix (the reference takes any Distribution as a prior:
+    src/types.jl:30,34-35,52): log-density against scipy.stats.multivariate_normal, draws by their
+    first two moments, push_p = identity, pdf = exp(logpdf)."""
+    from scipy import stats
+    d = k.MvNormal(mu, cov)
+    D = len(mu)
+    assert len(d) == D and d.vector_valued
+    x = np.random.default_rng(1).normal(size=(300, D)) * 2 + mu
+    ref = stats.multivariate_normal(mu, cov).logpdf(x).reshape(-1)
+    got = orc.factored_logpdf(d, x)
+    assert np.allclose(got, ref, rtol=1e-11, atol=1e-11)
+    assert np.allclose(orc.factored_pdf(d, x), np.exp(ref), rtol=1e-10, atol=1e-300)
+    assert np.array_equal(orc.push_p(d, x), x)
+    n = 200000
+    s = orc.factored_rand(d, n, seed=5)
+    se = np.sqrt(np.diagonal(cov) / n)
+    assert np.all(np.abs(s.mean(0) - mu) < 5 * se)
+    C = np.cov(s.T).reshape(D, D)
+    assert np.all(np.abs(C - cov) < 6 * np.sqrt((cov ** 2 + np.outer(np.diagonal(cov), np.diagonal(cov))) / n))
+
+
+def test_mvnormal_argument_checks(k):
+    assert "full covariance" not in repr(k.MvNormal([0.0, 1.0], [[4.0, 0.0], [0.0, 9.0]]))   # diagonal Σ: Normals
+    assert [c.sigma for c in k.MvNormal([0.0, 1.0], [[4.0, 0.0], [0.0, 9.0]]).p] == [2.0, 3.0]
+    with pytest.raises(k.KabcError, match="positive definite"):
+        k.MvNormal(np.zeros(2), np.array([[1.0, 2.0], [2.0, 1.0]]))
+    with pytest.raises(k.KabcError, match="symmetric"):
+        k.MvNormal(np.zeros(2), np.array([[1.0, 0.5], [0.4, 1.0]]))
+    with pytest.raises(ValueError, match="length"):
+        k.MvNormal(np.zeros(17), np.eye(17) + 0.1)
