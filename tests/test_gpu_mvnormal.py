@@ -129,3 +129,29 @@ def test_random_cases_bit_exact(k, orc, gpu_ctx, case):
     assert np.array_equal(ens.advance(gens, nt, collect=True), o.generations_sync(gens, nt))
     assert all(np.array_equal(a, b) for a, b in zip(ens.state()[:3], o.state()[:3]))
     assert ens.stats() == o.stats()
+
+
+# (the hipcc-built plugin form passes too -- KABC_TEST_HIPCC_PLUGIN=1 adds it: ~90 s of compilation)
+@pytest.mark.parametrize("form", ["hiprtc"] + (["hipcc"] if __import__("os").environ.get("KABC_TEST_HIPCC_PLUGIN") else []))
+def test_user_cost_with_an_mvnormal_prior(k, orc, gpu_ctx, monkeypatch, form):
+    """a user DeviceCost (run-time compiled kernels: hipRTC, or the hipcc-built plugin) under an
+    MvNormal prior: the plugin's kernels are instantiated from the same headers"""
+    monkeypatch.setenv("KABC_USER_PLUGIN", form)
+    src = """
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
+                              const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
+    double s = 0.0;
+    for (int k = 0; k < D; ++k) s += (x[k] - params[k]) * (x[k] - params[k]);
+    return kabc_sqrt(s) + 0.25 * kabc_fabs(x[0] * x[1]);
+}
+"""
+    user = k.costs.UserCost(src, dims=[3], params=[0.3, -0.2, 0.1], name=f"mvn_user_{form}", posteriors=["kernelized"])
+    orc.register_user_cost(user)
+    prior = _mv(k, 3)
+    model = k.ApproxKernelizedPosterior(prior, user, 1.0)
+    ens = k.AisEnsemble(model, 400, seed=6).init()
+    o = orc.OracleAIS(model, 400, seed=6).init()
+    assert np.array_equal(ens.advance(3, 5, collect=True), o.generations_sync(3, 5))
+    kw = dict(nparticles=700, alpha=0.9, epstol=0.5, seed=2)
+    r, ro = k.smc(prior, user, return_array=True, **kw), orc.smc(prior, user, **kw)
+    assert np.array_equal(r.info["theta_all"], ro["theta_all"]) and r.eps == ro["eps"]
