@@ -223,7 +223,7 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
                                         int posterior, double eps, double reps, const double* y,
                                         const double* cost_params, const double* cost_data,
                                         int64_t ndata, kabc_cost_rng_t* rng, double& lp,
-                                        double& ll, bool& ev) {
+                                        double& ll, bool& ev, const double* logtab = kabc_log_tab) {
     double yp[D];
     // A cheap deterministic cost is evaluated for every lane and selected afterwards: the
     // divergent region around it (exec save / branch / restore) costs the consumer wave more
@@ -302,7 +302,7 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         else sum = gaussbox_logpdf_push<D, false, true>(GB, y, yp, in);
         lp = in ? sum : -KABC_INF;
     } else {
-        lp = factored_logpdf_push<D, false>(P, y, yp);
+        lp = factored_logpdf_push<D, false>(P, y, yp, logtab);
     }
     ev = kabc_isfinite(lp);
     if (posterior == KABC_POSTERIOR_KERNELIZED) {
@@ -758,7 +758,7 @@ ais_half_kernel(const AisArgs A0) {
                     double nlp, nll;
                     bool ev;
                     loglike<D, COST, PC>(sprior, box, gbox, PK, A.eps, A.reps, y, A.cost_params,
-                                         A.cost_data, A.cost_ndata, &rng, nlp, nll, ev);
+                                         A.cost_data, A.cost_ndata, &rng, nlp, nll, ev, slogtab);
                     __builtin_amdgcn_sched_barrier(0);
                     n_eval += ev ? 1u : 0u;
                     // accept(...)  src/types.jl:62-75, :96-104

@@ -66,9 +66,11 @@ __device__ __forceinline__ double comp_logpdf_simple(int kind, const PriorDev& q
     }
 }
 
+// tab: kabc_log_tab or the kernel's LDS copy of it (same values; the global table is a dependent
+// L2 round trip per log on the consumer's chain)
 __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, double b, double p2,
                                                            double p3, double c0, double c1, double rb,
-                                                           double x) {
+                                                           double x, const double* tab = kabc_log_tab) {
     switch (kind) {
         case KABC_PRIOR_UNIFORM: return (x >= a && x <= b) ? c0 : -KABC_INF;
         case KABC_PRIOR_NORMAL: {
@@ -82,25 +84,25 @@ __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, d
         }
         case KABC_PRIOR_BETA: {
             if (!(x >= 0.0 && x <= 1.0)) return -KABC_INF;
-            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log(x);
-            const double t2 = (b == 1.0) ? 0.0 : (b - 1.0) * kabc_log1p(-x);
+            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log_t(x, tab);
+            const double t2 = (b == 1.0) ? 0.0 : (b - 1.0) * kabc_log1p_t(-x, tab);
             return t1 + t2 - c0;
         }
         case KABC_PRIOR_DISCRETE_UNIFORM:
             return (x >= a && x <= b && x == kabc_rint(x)) ? c0 : -KABC_INF;
         case KABC_PRIOR_NEGBINOMIAL: {
             if (!(x >= 0.0) || x != kabc_rint(x)) return -KABC_INF;
-            return c0 + x * c1 + kabc_lgamma(x + a) - kabc_lgamma(x + 1.0);
+            return c0 + x * c1 + kabc_lgamma_t(x + a, tab) - kabc_lgamma_t(x + 1.0, tab);
         }
         case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -c0 - kabc_div_rc(x, a, rb) : -KABC_INF;
         case KABC_PRIOR_GAMMA: {
             if (!(x >= 0.0)) return -KABC_INF;
-            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log(x);
+            const double t1 = (a == 1.0) ? 0.0 : (a - 1.0) * kabc_log_t(x, tab);
             return t1 - kabc_div_rc(x, b, rb) - c0;
         }
         case KABC_PRIOR_LOGNORMAL: {
             if (!(x > 0.0)) return -KABC_INF;
-            const double lx = kabc_log(x);
+            const double lx = kabc_log_t(x, tab);
             const double z = kabc_div_rc(lx - a, b, rb);
             return -(z * z + KABC_LOG_2PI) / 2.0 - c0 - lx;
         }
@@ -110,8 +112,8 @@ __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, d
 
 static __device__ __noinline__ double comp_logpdf_general(int kind, double a, double b, double p2,
                                                           double p3, double c0, double c1, double rb,
-                                                          double x) {
-    return comp_logpdf_general_body(kind, a, b, p2, p3, c0, c1, rb, x);
+                                                          double x, const double* tab) {
+    return comp_logpdf_general_body(kind, a, b, p2, p3, c0, c1, rb, x, tab);
 }
 
 // Inlined up to kGeneralInlineD components: a call costs the caller its live registers
@@ -119,11 +121,12 @@ static __device__ __noinline__ double comp_logpdf_general(int kind, double a, do
 // would bloat the kernel (and the build) for little.
 constexpr int kGeneralInlineD = 8;
 template <int D = KABC_MAX_DIM>
-__device__ __forceinline__ double comp_logpdf(int kind, const PriorDev& q, double x) {
+__device__ __forceinline__ double comp_logpdf(int kind, const PriorDev& q, double x,
+                                              const double* tab = kabc_log_tab) {
     if constexpr (D <= kGeneralInlineD)
-        return comp_logpdf_general_body(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
+        return comp_logpdf_general_body(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x, tab);
     else
-        return comp_logpdf_general(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x);
+        return comp_logpdf_general(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x, tab);
 }
 
 // the prepared block of an MvNormal prior (kabc_mvnormal.h) as a wave-uniform pointer
@@ -167,7 +170,8 @@ inline bool prior_is_simple(int kind) {
 // latencies overlap (smc_loop_kernel: 2.3 -> ... us for 16 components read from LDS)
 template <int D, bool SIMPLE = false, bool FENCED = true>
 __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restrict__ P,
-                                                       const double* x, double* xp) {
+                                                       const double* x, double* xp,
+                                                       const double* tab = kabc_log_tab) {
     double s = 0.0;
     [[maybe_unused]] int kind0 = 0;
 #pragma unroll
@@ -181,7 +185,7 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restric
         const bool disc = __builtin_amdgcn_readfirstlane(q.discrete) != 0;
         const double v = disc ? kabc_rint(x[k]) : x[k];
         xp[k] = v;
-        const double l = SIMPLE ? comp_logpdf_simple(kind, q, v) : comp_logpdf<D>(kind, q, v);
+        const double l = SIMPLE ? comp_logpdf_simple(kind, q, v) : comp_logpdf<D>(kind, q, v, tab);
         s = (k == 0) ? l : s + l;
     }
 #ifndef KABC_NO_MVN_DEVICE  // (A/B builds: the case compiled out)
