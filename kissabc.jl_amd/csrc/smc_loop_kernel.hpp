@@ -412,6 +412,10 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
     // prepared prior components, read with wave-uniform LDS addresses (by-value kernel
     // arguments pin ~250 SGPRs and spill them to VGPR lanes, as in ais_half_kernel)
     __shared__ PriorDev s_prior[D];
+    // the log / sin-cos table (include/kabc_math.h): every table-driven function of the pass (the
+    // draws' Box-Muller pairs, log(rand), a GENERAL prior's logs, the cost's own draws) looks it up
+    // here -- in global memory each look-up is a dependent L2 round trip
+    __shared__ __attribute__((aligned(16))) double s_logtab[KABC_MATH_TAB_WORDS];
     __shared__ unsigned int s_scan[kLoopWaves];
     __shared__ unsigned long long s_ka, s_kb;
     __shared__ long long s_bin[4];  // b*, count, before, found
@@ -454,6 +458,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
     }
     if (tid < D * (int)(sizeof(PriorDev) / 8))
         reinterpret_cast<double*>(s_prior)[tid] = reinterpret_cast<const double*>(A.prior)[tid];
+    for (int j = tid; j < KABC_MATH_TAB_WORDS; j += kLoopBlock) s_logtab[j] = kabc_log_tab[j];
     __syncthreads();
     // the XCD populations of the XCD-aware barrier: counted here, published by one plain barrier
     LoopXcd X;
@@ -492,7 +497,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                     const kabc_u128_t Bn =
                         kabc_stream_block(seed_v, (uint32_t)i, nps, (uint32_t)j, KABC_DOM_SMC_COST);
                     kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
-                                         kabc_log_tab);
+                                         s_logtab);
                 }
             }
         }
@@ -584,16 +589,16 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             nx_a = (unsigned)a;
             nx_b = (unsigned)b;
             double z0, z1;
-            kabc_normal_pair(kabc_lo64(B1), kabc_hi64(B1), &z0, &z1);
+            kabc_normal_pair_tab(kabc_lo64(B1), kabc_hi64(B1), &z0, &z1, s_logtab);
             nx_s = A.max_stretch * z0 / kabc_sqrt((double)D);
-            nx_lprob = kabc_log(kabc_u01(kabc_lo64(B2)));
+            nx_lprob = kabc_log_pn_tab(kabc_u01(kabc_lo64(B2)), s_logtab);  // u01 is a positive normal
             // the cost's normal pairs: the first half here, the rest in the shadow of B2
             if constexpr (kPre > 0) {
 #pragma unroll
                 for (int j = 0; j < kPreA; ++j) {
                     const kabc_u128_t Bn = kabc_stream_block(seed_v, w, nps, (uint32_t)j, KABC_DOM_SMC_COST);
                     kabc_normal_pair_tab(kabc_lo64(Bn), kabc_hi64(Bn), &nx_pre[2 * j], &nx_pre[2 * j + 1],
-                                         kabc_log_tab);
+                                         s_logtab);
                 }
             }
         }
@@ -1019,7 +1024,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                 load_row<D>(theta_src + sb * D, tb);
                 if (alive_i) {
                     const double s = nx_s, lprob = nx_lprob;
-                    kabc_cost_rng_t rng = {seed_v, ps, w, KABC_DOM_SMC_COST, 0u};
+                    kabc_cost_rng_t rng = {seed_v, ps, w, KABC_DOM_SMC_COST, 0u, 0u, nullptr, s_logtab};
                     if constexpr (kPre > 0) {
                         rng.pre = nx_pre;
                         rng.pre_n = (uint32_t)kPre;
@@ -1037,7 +1042,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         KABC_LSTAMP(18)
                     }
-                    const double lpp = factored_logpdf_push<D, SIMPLE, false>(s_prior, prop, xp);
+                    const double lpp = factored_logpdf_push<D, SIMPLE, false>(s_prior, prop, xp, s_logtab);
                     if (A.stamps) {
                         asm volatile("" :: "v"(lpp));
                         KABC_LSTAMP(19)
