@@ -35,7 +35,8 @@ enum {
      * (kabc_register_cost_plugin, include/kabc.h).  The snippet defines
      *   KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
      *                                 const double* data, int64_t ndata, kabc_cost_rng_t* rng);
-     * and may use everything in kabc_math.h / kabc_philox.h.
+     * and may use everything in kabc_math.h / kabc_philox.h (logs inside a cost: prefer
+     * kabc_log_t(x, kabc_cost_tab(rng)) to kabc_log(x) -- the kernel's LDS copy of the table).
      * Optional, for CommonLogDensity with an arbitrary `sample_init` (src/types.jl:105-113): the
      * snippet also defines
      *   #define KABC_USER_SAMPLE_INIT 1

@@ -127,6 +127,14 @@ typedef struct kabc_cost_rng {
 #endif
 } kabc_cost_rng_t;
 
+/* the table a cost should hand to the table-driven functions of kabc_math.h (kabc_log_t,
+ * kabc_log1p_t, kabc_lgamma_t, kabc_sincos2pi_tab, kabc_normal_pair_tab): the calling kernel's
+ * LDS copy when there is one.  kabc_log(x) & co. read the table in global memory -- a dependent
+ * L2 round trip per call on the AIS consumer wave; same values either way. */
+KABC_HD const double* kabc_cost_tab(const kabc_cost_rng_t* g) {
+    return (g && g->logtab) ? g->logtab : kabc_log_tab;
+}
+
 KABC_HD kabc_u128_t kabc_cost_rng_next(kabc_cost_rng_t* g) {
     return kabc_stream_block(g->seed, g->walker, g->t, g->slot++, g->domain);
 }
