@@ -193,7 +193,7 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     hipStream_t s = ctx->stream;
     std::vector<void*> bufs;
     auto alloc = [&](void** p, size_t bytes) {
-        hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+        hipError_t e = dev_malloc(p, bytes ? bytes : 8);
         if (e == hipSuccess) bufs.push_back(*p);
         return e;
     };

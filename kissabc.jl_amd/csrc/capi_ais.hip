@@ -167,12 +167,12 @@ static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0,
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     if (m->cost.nparams > 0) {
-        KABC_HIP_CHECK(hipMalloc(&h->d_cost_params, sizeof(double) * m->cost.nparams));
+        KABC_HIP_CHECK(dev_malloc(&h->d_cost_params, sizeof(double) * m->cost.nparams));
         KABC_HIP_CHECK(hipMemcpyAsync(h->d_cost_params, m->cost.params,
                                       sizeof(double) * m->cost.nparams, hipMemcpyHostToDevice, s));
     }
     if (m->cost.ndata > 0) {
-        KABC_HIP_CHECK(hipMalloc(&h->d_cost_data, sizeof(double) * m->cost.ndata));
+        KABC_HIP_CHECK(dev_malloc(&h->d_cost_data, sizeof(double) * m->cost.ndata));
         KABC_HIP_CHECK(hipMemcpyAsync(h->d_cost_data, m->cost.data, sizeof(double) * m->cost.ndata,
                                       hipMemcpyHostToDevice, s));
     }
@@ -180,37 +180,37 @@ static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0,
         if (h->own_halves) {
             // padded to world equal segments so that the in-place all-gather has one count
             const size_t nb = sizeof(double) * (size_t)(h->cper[hf] * h->xk * world) * h->D * nch;
-            KABC_HIP_CHECK(hipMalloc(&h->d_half[hf], nb));
+            KABC_HIP_CHECK(dev_malloc(&h->d_half[hf], nb));
             KABC_HIP_CHECK(hipMemsetAsync(h->d_half[hf], 0, nb, s));
         } else {
             h->d_half[hf] = (double*)(hf == 0 ? ext0 : ext1);
         }
         const size_t nb = sizeof(double) * (size_t)(h->rows_owned[hf] > 0 ? h->rows_owned[hf] : 1) * nch;
-        KABC_HIP_CHECK(hipMalloc(&h->d_lp[hf], nb));
-        KABC_HIP_CHECK(hipMalloc(&h->d_ll[hf], nb));
+        KABC_HIP_CHECK(dev_malloc(&h->d_lp[hf], nb));
+        KABC_HIP_CHECK(dev_malloc(&h->d_ll[hf], nb));
     }
     if (seeds) {
-        KABC_HIP_CHECK(hipMalloc(&h->d_seeds, sizeof(uint64_t) * nch));
+        KABC_HIP_CHECK(dev_malloc(&h->d_seeds, sizeof(uint64_t) * nch));
         KABC_HIP_CHECK(hipMemcpyAsync(h->d_seeds, seeds, sizeof(uint64_t) * nch, hipMemcpyHostToDevice, s));
-        KABC_HIP_CHECK(hipMalloc(&h->d_chain_retries, sizeof(unsigned long long) * nch));
+        KABC_HIP_CHECK(dev_malloc(&h->d_chain_retries, sizeof(unsigned long long) * nch));
     }
-    KABC_HIP_CHECK(hipMalloc(&h->d_counters, sizeof(DevCounters)));
+    KABC_HIP_CHECK(dev_malloc(&h->d_counters, sizeof(DevCounters)));
     KABC_HIP_CHECK(hipMemsetAsync(h->d_counters, 0, sizeof(DevCounters), s));
     if (h->dyn) {
         const size_t D = (size_t)h->D;
         const size_t rmax = (size_t)(h->rows_owned[0] > h->rows_owned[1] ? h->rows_owned[0] : h->rows_owned[1]);
-        KABC_HIP_CHECK(hipMalloc(&h->d_prior, sizeof(PriorDev) * D));
+        KABC_HIP_CHECK(dev_malloc(&h->d_prior, sizeof(PriorDev) * D));
         KABC_HIP_CHECK(hipMemcpyAsync(h->d_prior, h->prior_dyn.data(), sizeof(PriorDev) * D,
                                       hipMemcpyHostToDevice, s));
-        KABC_HIP_CHECK(hipMalloc(&h->d_raw, sizeof(kabc_prior_t) * D));
+        KABC_HIP_CHECK(dev_malloc(&h->d_raw, sizeof(kabc_prior_t) * D));
         KABC_HIP_CHECK(hipMemcpyAsync(h->d_raw, h->raw_dyn.data(), sizeof(kabc_prior_t) * D,
                                       hipMemcpyHostToDevice, s));
-        KABC_HIP_CHECK(hipMalloc(&h->d_scratch, sizeof(double) * (rmax ? rmax : 1) * 2 * D));
+        KABC_HIP_CHECK(dev_malloc(&h->d_scratch, sizeof(double) * (rmax ? rmax : 1) * 2 * D));
     } else {
-        KABC_HIP_CHECK(hipMalloc(&h->d_prior, sizeof(PriorSet)));
+        KABC_HIP_CHECK(dev_malloc(&h->d_prior, sizeof(PriorSet)));
         KABC_HIP_CHECK(hipMemcpyAsync(h->d_prior, &h->prior, sizeof(PriorSet), hipMemcpyHostToDevice, s));
     }
-    KABC_HIP_CHECK(hipMalloc(&h->d_slots, sizeof(unsigned long long) * kCounterSlots * 8));
+    KABC_HIP_CHECK(dev_malloc(&h->d_slots, sizeof(unsigned long long) * kCounterSlots * 8));
     KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
     KABC_HIP_CHECK(hipStreamSynchronize(s));
     return KABC_OK;
@@ -786,7 +786,7 @@ static kabc_status_t launch_half_seg(kabc_ais_t* h, int32_t half, const kabc_ais
                     h->d_aux = nullptr;
                     h->aux_cap = 0;
                 }
-                KABC_HIP_CHECK(hipMalloc(&h->d_aux, per_step * (size_t)blk));
+                KABC_HIP_CHECK(dev_malloc(&h->d_aux, per_step * (size_t)blk));
                 h->aux_cap = per_step * (size_t)blk;
             }
         }
@@ -950,7 +950,7 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
             for (int b = 0; b < kTraceBufs; ++b) {
                 if (h->d_trace[b]) KABC_HIP_CHECK(hipFree(h->d_trace[b]));
                 h->d_trace[b] = nullptr;
-                KABC_HIP_CHECK(hipMalloc(&h->d_trace[b], gen_bytes * chunk));
+                KABC_HIP_CHECK(dev_malloc(&h->d_trace[b], gen_bytes * chunk));
             }
             h->trace_cap_gens = chunk;
         }
@@ -1273,7 +1273,7 @@ kabc_status_t kabc_ais_set_debug(kabc_ais_t* h, int32_t ntransitions) {
     h->dbg_cap = 0;
     if (ntransitions > 0) {
         h->dbg_cap = (h->rows_owned[0] + h->rows_owned[1]) * (int64_t)ntransitions * 6;
-        KABC_HIP_CHECK(hipMalloc(&h->d_dbg, sizeof(int32_t) * h->dbg_cap));
+        KABC_HIP_CHECK(dev_malloc(&h->d_dbg, sizeof(int32_t) * h->dbg_cap));
         KABC_HIP_CHECK(hipMemset(h->d_dbg, 0xff, sizeof(int32_t) * h->dbg_cap));
     }
     return KABC_OK;

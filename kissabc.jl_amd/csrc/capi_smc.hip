@@ -133,10 +133,11 @@ struct DevBufs {
                 *p = (T*)ctx->pool[best].second;
                 ctx->pool_bytes -= ctx->pool[best].first;
                 ctx->pool.erase(ctx->pool.begin() + best);
-                return hipSuccess;
+                // (a recycled buffer carries the last run's bytes: the same poison as a fresh one)
+                return poison_alloc() ? poison_fill((void*)*p, held.back().first) : hipSuccess;
             }
         }
-        hipError_t e = hipMalloc(p, bytes);
+        hipError_t e = dev_malloc(p, bytes);
         if (e == hipSuccess) held.push_back({bytes, (void*)*p});
         return e;
     }

@@ -1,5 +1,6 @@
 // host_common.hpp -- host-side helpers of the C-ABI library (not part of the ABI)
 #pragma once
+#include <cstdlib>
 
 #include <hip/hip_runtime.h>
 
@@ -31,6 +32,30 @@ const char* get_error();
 // derived constants of one Factored component.  Host libm supplies the one-off
 // normalisers (lgamma, erfc); everything evaluated per walker goes through the
 // math contract.  Returns false for invalid parameters.
+// hipMalloc for the library's working buffers.  KABC_POISON_ALLOC=1 (tests) fills every buffer --
+// fresh or recycled from a context's pool -- with 0xA5 bytes first: fresh device memory usually
+// reads as zero, so a kernel that relies on that passes every test until the driver hands out a
+// recycled page (several processes starting on one GPU).
+inline bool poison_alloc() {
+    static const bool on = [] {
+        const char* e = std::getenv("KABC_POISON_ALLOC");
+        return e && *e && *e != '0';
+    }();
+    return on;
+}
+// (hipMemset on the null stream is not ordered against the contexts' non-blocking streams and may
+// return before it has run: wait for it, or it lands on top of the run's own initialisation)
+inline hipError_t poison_fill(void* p, size_t bytes) {
+    hipError_t e = hipMemset(p, 0xA5, bytes);
+    return e == hipSuccess ? hipDeviceSynchronize() : e;
+}
+template <class T>
+inline hipError_t dev_malloc(T** p, size_t bytes) {
+    hipError_t e = hipMalloc((void**)p, bytes);
+    if (e == hipSuccess && poison_alloc()) e = poison_fill((void*)*p, bytes);
+    return e;
+}
+
 // copy of the caller's components with the library-side fields of MvNormal components filled in
 // (device block pointer, D); every entry point resolves before it prepares or copies the prior
 kabc_status_t resolve_priors(kabc_ctx_t* ctx, const kabc_prior_t* prior, int D, kabc_prior_t* out);

@@ -274,6 +274,9 @@ __device__ __forceinline__ void for_each_alive(const uint8_t* __restrict__ alive
 // the kernel, and kabc_smc_run / kabc_pfilter_run return KABC_ERR_DEVICE instead of hanging.
 __device__ __forceinline__ bool sel_grid_barrier(SmcSelScratch* g, unsigned G) {
     __shared__ int s_ok;
+    // every wavefront's own stores are in the L2 before thread 0 releases for the workgroup
+    // (__syncthreads() waits for LDS / scalar traffic only; smc_loop_kernel.hpp loop_sync_stores_done)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (G > 1u) {
         if (threadIdx.x == 0) {

@@ -150,8 +150,17 @@ __device__ __forceinline__ unsigned long long wave_sum_all(unsigned long long v)
 // workgroups, 2.4 us without them): a release writes the XCD's whole L2 back, an acquire
 // invalidates it, and every one of the 16 workgroups of an XCD does both.  Used ONCE, in the
 // prologue (it publishes the XCD populations the barrier below needs).
-__device__ __forceinline__ bool loop_plain_barrier(SmcLoopScratch* g, unsigned G, unsigned nb, int* s_ok) {
+// Every wavefront's global stores must have been acknowledged by the L2 BEFORE its workgroup is
+// counted as arrived: the release (buffer_wbl2) is issued by ONE wavefront -- of this workgroup or,
+// with the XCD-aware barrier, of another one -- and only writes back what is in the L2 by then.
+// __syncthreads() does not do that: outside threadgroup-split mode its workgroup-scope release
+// waits for LDS / scalar traffic only (`s_waitcnt lgkmcnt(0); s_barrier` in the ISA).
+__device__ __forceinline__ void loop_sync_stores_done() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
+__device__ __forceinline__ bool loop_plain_barrier(SmcLoopScratch* g, unsigned G, unsigned nb, int* s_ok) {
+    loop_sync_stores_done();
     if (threadIdx.x == 0) {
         int ok = 1;
         __threadfence();
@@ -231,7 +240,10 @@ __device__ __forceinline__ void loop_barrier_arrive_t0(SmcLoopScratch* g, const 
     }
     return;
 #endif
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // this thread's own stores (its workgroup's record, written after the workgroup-wide wait
+    // above) must be in the L2 before the arrival is counted: a workgroup-scope fence does not wait
+    // for them, and the atomic below is relaxed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #ifdef KABC_XBAR_EARLYWB
     // start writing back what is dirty NOW (not waited for): the last arrival's write-back then
     // finds little left, as with the plain barrier, where early arrivals flush while they wait
@@ -245,7 +257,7 @@ __device__ __forceinline__ void loop_barrier_arrive_t0(SmcLoopScratch* g, const 
     }
 }
 __device__ __forceinline__ void loop_barrier_arrive(SmcLoopScratch* g, const LoopXcd& X, unsigned nb) {
-    __syncthreads();
+    loop_sync_stores_done();
     if (threadIdx.x == 0) loop_barrier_arrive_t0(g, X, nb);
 }
 __device__ __forceinline__ bool loop_barrier_wait(SmcLoopScratch* g, const LoopXcd& X, unsigned nb, int* s_ok) {
@@ -550,7 +562,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             }
         }
         KABC_LSTAMP(21)
-        __syncthreads();  // s_acc complete; every wavefront's global writes have completed
+        loop_sync_stores_done();  // s_acc complete; every wavefront's global writes have reached the L2
         if (tid == 0) {
             const unsigned slot = q & (kLoopSlots - 1);
             const unsigned long long a = s_acc[0], b = s_acc[1];

@@ -72,7 +72,11 @@ __device__ __forceinline__ void plain_barrier(Bar* b, unsigned G, unsigned nb) {
 
 // barrier number nb (0-based); xcd / members: this workgroup's XCD and its population
 __device__ __forceinline__ void xcd_barrier(Bar* b, unsigned nb, unsigned xcd, unsigned members, unsigned nxcd) {
-    __syncthreads();  // every wavefront's stores have completed: they are in this XCD's L2
+    // every wavefront's stores must be in this XCD's L2 before the workgroup is counted: an explicit
+    // vmcnt wait -- __syncthreads() alone waits for LDS / scalar traffic only (the hole the
+    // contention soak found in smc_loop_kernel: tools/contention_stress.py)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         if (atomicAdd(&b->xcount[xcd].v, 1ull) + 1ull == (unsigned long long)(nb + 1u) * members) {
             // last workgroup of this XCD: one write-back for all of them
@@ -108,6 +112,7 @@ __device__ __forceinline__ unsigned mix(unsigned a, unsigned b) {
 // rows (value = f(iteration, row)), barrier, every thread reads a random row of another
 // workgroup and checks it.
 __device__ __forceinline__ void xcd_barrier_inv1(Bar* b, unsigned nb, unsigned xcd, unsigned members, unsigned nxcd) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         if (atomicAdd(&b->xcount[xcd].v, 1ull) + 1ull == (unsigned long long)(nb + 1u) * members) {
