@@ -3,7 +3,8 @@ and over for `seconds` while background processes of another kind keep the GPU b
 process compares each result with its first one and, at the end, the odd ones with the CPU oracle.
   python tools/contention_stress.py <kind> [nproc=3] [background=ais] [seconds=20]
 kinds: smc_loop (persistent loop kernel), smc_kernels (kernel-per-phase path), ais (C3-shaped
-ensemble, 40 generations x 16 transitions from the same start)."""
+ensemble, 40 generations x 16 transitions from the same start), sharded (four emulated ranks,
+pipelined exchange), trace (streamed sample trace)."""
 import os
 import subprocess
 import sys
@@ -30,6 +31,23 @@ if kind.startswith('smc'):
     def run():
         r = k.smc(prior, cost, return_array=True, **kw)
         return (r.eps, r.info['theta_all'])
+elif kind == 'sharded':   # four emulated ranks on this GPU, pipelined exchange chunks (second stream + events)
+    os.environ['KABC_EXCHANGE_CHUNKS'] = '3'
+    model = bench.build_model(k)
+    def run():
+        g = k.EnsembleGroup(model, 1 << 16, seed=1, devices=[0] * 4, backend='p2p').init()
+        g.advance(12, 8)
+        x = g.ensemble(3).copy()
+        st = g.stats()
+        g.close()
+        return (float(st['accepted']), x)
+elif kind == 'trace':     # streamed sample trace: device chunks in rotation, drain thread, copy stream
+    model = bench.build_model(k)
+    def run():
+        e = k.AisEnsemble(model, 1 << 14, seed=1).init()
+        tr = e.advance(48, 4, collect=True)
+        e.close()
+        return (float(tr[-1].sum()), np.ascontiguousarray(tr).reshape(-1, tr.shape[-1]))
 else:
     model = bench.build_model(k)
     def run():
