@@ -1274,7 +1274,8 @@ kabc_status_t kabc_ais_set_debug(kabc_ais_t* h, int32_t ntransitions) {
     if (ntransitions > 0) {
         h->dbg_cap = (h->rows_owned[0] + h->rows_owned[1]) * (int64_t)ntransitions * 6;
         KABC_HIP_CHECK(dev_malloc(&h->d_dbg, sizeof(int32_t) * h->dbg_cap));
-        KABC_HIP_CHECK(hipMemset(h->d_dbg, 0xff, sizeof(int32_t) * h->dbg_cap));
+        // (on the handle's stream: the null stream is not ordered against a non-blocking one)
+        KABC_HIP_CHECK(hipMemsetAsync(h->d_dbg, 0xff, sizeof(int32_t) * h->dbg_cap, h->ctx->stream));
     }
     return KABC_OK;
 }

@@ -69,6 +69,7 @@ kabc_status_t resolve_priors(kabc_ctx_t* ctx, const kabc_prior_t* prior, int D, 
         KABC_HIP_CHECK(hipSetDevice(ctx->device));
         KABC_HIP_CHECK(hipMalloc(&d, sizeof(double) * e->host.size()));
         KABC_HIP_CHECK(hipMemcpy(d, e->host.data(), sizeof(double) * e->host.size(), hipMemcpyHostToDevice));
+        KABC_HIP_CHECK(hipDeviceSynchronize());  // (once per handle and device: the contexts' streams are non-blocking)
         e->dev[ctx->device] = d;
     }
     for (int k = 0; k < D; ++k) {
