@@ -667,6 +667,19 @@ ais_half_kernel(const AisArgs A0) {
             KABC_TIMED_BARRIER();
         }
     } else {
+#ifndef KABC_NO_REG_PARAMS
+        // the cost's leading parameters in registers for the whole launch (cost_reg_params)
+        constexpr int kRP = cost_reg_params(COST, D);
+        double cpar[kRP > 0 ? kRP : 1];
+#pragma unroll
+        for (int k = 0; k < kRP; ++k) {
+            cpar[k] = A.cost_params[k];
+            asm volatile("" : "+v"(cpar[k]));  // (a value, not a re-loadable address)
+        }
+        const double* const cparams = kRP > 0 ? cpar : A.cost_params;
+#else
+        const double* const cparams = A.cost_params;
+#endif
 #pragma unroll 1
         for (int c = 0; c < nchunks; ++c) {
             const int s0 = c * kChunk;
@@ -757,7 +770,7 @@ ais_half_kernel(const AisArgs A0) {
                     }
                     double nlp, nll;
                     bool ev;
-                    loglike<D, COST, PC>(sprior, box, gbox, PK, A.eps, A.reps, y, A.cost_params,
+                    loglike<D, COST, PC>(sprior, box, gbox, PK, A.eps, A.reps, y, cparams,
                                          A.cost_data, A.cost_ndata, &rng, nlp, nll, ev, slogtab);
                     __builtin_amdgcn_sched_barrier(0);
                     n_eval += ev ? 1u : 0u;

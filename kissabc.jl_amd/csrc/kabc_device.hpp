@@ -314,6 +314,18 @@ constexpr int cost_pre_blocks(int cost, int D) {
             cost == KABC_COST_NOISY_BANANA) ? 1 : 0;
 }
 
+// Leading cost parameters a kernel may keep in REGISTERS for a whole launch (they are the same for
+// every lane and every transition).  Read through the pointer they are a global load per
+// transition on the consumer's dependent chain (the NORMAL-class kernel fetched gauss_dist's D
+// centres with four `global_load_dwordx4` in every sub-step).
+constexpr int cost_reg_params(int cost, int D) {
+    return cost == KABC_COST_GAUSS_DIST ? (D <= 8 ? D : 0)
+         : cost == KABC_COST_NORMAL_MEANSTD_SIM ? 3
+         : (cost == KABC_COST_DIRAC_SQ || cost == KABC_COST_ABS_DIFF || cost == KABC_COST_NORM_SHELL ||
+            cost == KABC_COST_NOISY_QUAD_DU || cost == KABC_COST_MIXTURE || cost == KABC_COST_NOISY_BANANA) ? 1
+         : 0;
+}
+
 // compile-time cost dispatch on the DeviceCost id (formulas: include/kabc_costs.h)
 template <int COST, int D>
 __device__ __forceinline__ double eval_cost(const double* xp, const double* __restrict__ params,

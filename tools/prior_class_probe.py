@@ -17,6 +17,7 @@ RD = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
 cases = [
     ("normal8", k.ApproxKernelizedPosterior(k.Factored(*[k.Normal(0, 5)] * 8), k.costs.GaussDist(np.zeros(8)), 1.0), 65536),
     ("readme_prior_gauss", k.ApproxKernelizedPosterior(RD, k.costs.GaussDist([2.0, 0.04]), 0.05), 65536),
+    ("c2", k.ApproxKernelizedPosterior(k.Factored(k.Normal(0, 5), k.Normal(0, 5)), k.costs.GaussDist([1.0, -0.5]), 0.1), 4096),
     ("socks", k.ApproxKernelizedPosterior(socks, k.costs.GaussDist([40.0, 0.8]), 3.0), 65536),
     ("general4", k.ApproxKernelizedPosterior(G4, k.costs.NormShell(2.0), 0.5), 65536),
     ("hier16_sim", k.ApproxKernelizedPosterior(H16, k.costs.HierGaussSim(np.random.default_rng(1).normal(size=14)), 0.3), 32768),
