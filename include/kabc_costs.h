@@ -115,7 +115,8 @@ KABC_HD int kabc_cost_aux_words(int id) { return id == KABC_COST_NORMAL_MEANSTD_
 
 /* params = (n, mean(tdata), std(tdata)); x = (mu, sigma).  The n draws are
  * mu + sigma z_j, so mean = mu + sigma mean(z), std = |sigma| std(z).
- * prepare: aux = (sum z_j, sum z_j^2) over the n standard normals of the stream.
+ * prepare: aux = (mean, standard deviation) of the n standard normals of the stream, from
+ *          (sum z_j, sum z_j^2) -- kabc_cost_normal_meanstd_moments.
  *
  * SUMMATION ORDER (part of the contract: it fixes the bits).  The n draws are independent, so
  * the sums are defined the way 64 lanes of a wavefront form them together:
@@ -157,6 +158,19 @@ KABC_HD void kabc_cost_normal_meanstd_slice(int n, int l, kabc_cost_rng_t* rng, 
     *psz = sz;
     *pszz = szz;
 }
+/* The prepared words: aux = (mean, standard deviation) of the n standard normals, from their
+ * sums (sum z, sum z^2).  These steps of README.md:43-49 do not depend on the walker's state
+ * either, so they belong to the prepare step (two divisions and a square root less on the
+ * chain of dependent transitions); same operations in the same order as when the cost is
+ * evaluated in place. */
+KABC_HD void kabc_cost_normal_meanstd_moments(int n, double sz, double szz, double* aux) {
+    double dn = (double)n;
+    double mz = sz / dn;
+    double vz = (szz - dn * mz * mz) / (dn - 1.0);
+    if (vz < 0.0) vz = 0.0;
+    aux[0] = mz;
+    aux[1] = kabc_sqrt(vz);
+}
 KABC_HD void kabc_cost_normal_meanstd_prepare(const double* params, kabc_cost_rng_t* rng,
                                               double* aux) {
     int n = (int)params[0];
@@ -168,8 +182,7 @@ KABC_HD void kabc_cost_normal_meanstd_prepare(const double* params, kabc_cost_rn
             b[l] = b[l] + b[l + off];
         }
     rng->slot += (uint32_t)kabc_sim_pairs(n);
-    aux[0] = a[0];
-    aux[1] = b[0];
+    kabc_cost_normal_meanstd_moments(n, a[0], b[0], aux);
 }
 KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* params,
                                             kabc_cost_rng_t* rng) {
@@ -180,14 +193,9 @@ KABC_HD double kabc_cost_normal_meanstd_sim(const double* x, const double* param
     } else {
         kabc_cost_normal_meanstd_prepare(params, rng, aux);
     }
-    const double sz = aux[0], szz = aux[1];
-    int n = (int)params[0];
-    double dn = (double)n;
-    double mz = sz / dn;
-    double vz = (szz - dn * mz * mz) / (dn - 1.0);
-    if (vz < 0.0) vz = 0.0;
+    const double mz = aux[0], svz = aux[1];
     double mean = x[0] + x[1] * mz;
-    double sd = kabc_fabs(x[1]) * kabc_sqrt(vz);
+    double sd = kabc_fabs(x[1]) * svz;
     double a = mean - params[1];
     double b = 50.0 * (sd - params[2]);
     return kabc_sqrt(a * a + b * b);

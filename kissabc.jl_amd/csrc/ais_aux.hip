@@ -5,7 +5,7 @@ namespace kabc {
 
 constexpr int kAuxBlock = 256;
 
-// KABC_COST_NORMAL_MEANSTD_SIM: aux = (sum z, sum z^2) of the n standard normals
+// KABC_COST_NORMAL_MEANSTD_SIM: aux = (mean, standard deviation) of the n standard normals
 __global__ void __launch_bounds__(kAuxBlock) aux_normal_meanstd_kernel(const AuxArgs A) {
     __shared__ __attribute__((aligned(16))) double slogtab[KABC_MATH_TAB_WORDS];
     static_assert(KABC_MATH_TAB_WORDS == 2 * kAuxBlock, "two table words per thread");
@@ -34,8 +34,10 @@ __global__ void __launch_bounds__(kAuxBlock) aux_normal_meanstd_kernel(const Aux
     }
     if (lane == 0) {
         const int64_t ws = A.word_stride ? A.word_stride : A.rows;
-        aux[(s * 2 + 0) * ws + r] = sz;
-        aux[(s * 2 + 1) * ws + r] = szz;
+        double m[2];
+        kabc_cost_normal_meanstd_moments(n, sz, szz, m);
+        aux[(s * 2 + 0) * ws + r] = m[0];
+        aux[(s * 2 + 1) * ws + r] = m[1];
     }
 }
 
