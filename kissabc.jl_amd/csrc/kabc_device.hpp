@@ -92,7 +92,9 @@ __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, d
             return (x >= a && x <= b && x == kabc_rint(x)) ? c0 : -KABC_INF;
         case KABC_PRIOR_NEGBINOMIAL: {
             if (!(x >= 0.0) || x != kabc_rint(x)) return -KABC_INF;
-            return c0 + x * c1 + kabc_lgamma_t(x + a, tab) - kabc_lgamma_t(x + 1.0, tab);
+            // lgamma(x + 1) of the integer x: a lookup of kabc_lgamma's own values below 256
+            // (include/kabc_math.h kabc_lgamma1p_int_t), ~150 instructions less per transition
+            return c0 + x * c1 + kabc_lgamma_t(x + a, tab) - kabc_lgamma1p_int_t(x, tab);
         }
         case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -c0 - kabc_div_rc(x, a, rb) : -KABC_INF;
         case KABC_PRIOR_GAMMA: {

@@ -105,6 +105,22 @@ def test_lgamma(orc):
     assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < 4e-14
 
 
+def test_lgamma1_table_holds_the_contract_functions_bits(orc):
+    """include/kabc_lgamma1_table.h (the lookup of lgamma(x + 1) for the integer arguments of the
+    NegativeBinomial log-density, kabc_lgamma1p_int_t) against kabc_lgamma itself as the oracle
+    build computes it: all 256 entries, bit for bit."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include",
+                        "kabc_lgamma1_table.h")
+    text = open(path).read()
+    body = text[text.index("KABC_LGAMMA1_VALUES") + len("KABC_LGAMMA1_VALUES"):text.rindex("#endif")]
+    vals = np.array([float.fromhex(t) for t in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", body)])
+    assert vals.size == 256
+    ref = orc.math_vec("lgamma", np.arange(1, 257, dtype=float))
+    assert np.array_equal(vals.view(np.uint64), ref.view(np.uint64))
+
+
 def test_box_muller_moments(orc):
     r = rng.integers(0, 2 ** 64, size=400000, dtype=np.uint64)
     z = orc.normal_pairs(r).ravel()
