@@ -223,7 +223,8 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
                                         int posterior, double eps, double reps, const double* y,
                                         const double* cost_params, const double* cost_data,
                                         int64_t ndata, kabc_cost_rng_t* rng, double& lp,
-                                        double& ll, bool& ev, const double* logtab = kabc_log_tab) {
+                                        double& ll, bool& ev, const double* logtab = kabc_log_tab,
+                                        const double* nbtab = nullptr) {
     double yp[D];
     // A cheap deterministic cost is evaluated for every lane and selected afterwards: the
     // divergent region around it (exec save / branch / restore) costs the consumer wave more
@@ -302,7 +303,7 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         else sum = gaussbox_logpdf_push<D, false, true>(GB, y, yp, in);
         lp = in ? sum : -KABC_INF;
     } else {
-        lp = factored_logpdf_push<D, false>(P, y, yp, logtab);
+        lp = factored_logpdf_push<D, false>(P, y, yp, logtab, nbtab);
     }
     ev = kabc_isfinite(lp);
     if (posterior == KABC_POSTERIOR_KERNELIZED) {
@@ -531,6 +532,11 @@ ais_half_kernel(const AisArgs A0) {
     __shared__ __attribute__((aligned(16))) double sgb[kGaussBox ? D : 1][8];
     // the producers' copy of the log table (include/kabc_math.h): per-lane lookups
     __shared__ __attribute__((aligned(16))) double slogtab[KABC_MATH_TAB_WORDS];
+    // GENERAL class: lgamma(k + r), k < kNbEntries, of the first kNbTabs NegativeBinomial
+    // components -- kabc_lgamma_t's own values, computed once per launch by the whole workgroup
+    // instead of once per transition by the consumer (kabc_device.hpp, the family's case)
+    constexpr int kNbTabs = (PC == kPriorGeneral) ? 2 : 0;
+    __shared__ double snb[kNbTabs > 0 ? kNbTabs * kNbEntries : 1];
     // prepared costs (include/kabc_costs.h): the parameter-independent part of the cost
     // of every sub-step, computed by the producers; word j of lane l at [buf][si][j][l]
     constexpr int kAuxW = cost_aux_c(COST);
@@ -617,7 +623,34 @@ ais_half_kernel(const AisArgs A0) {
     // the log table is staged by all four waves and read by the producers right away
     slogtab[threadIdx.x] = tab0;
     slogtab[threadIdx.x + kAisBlock] = tab1;
+    // NegativeBinomial components (GENERAL class, launches long enough to pay for it): slot j of
+    // snb = lgamma(k + r_j); which components have a slot is recomputed below from the same scan
+    [[maybe_unused]] const bool nb_on = kNbTabs > 0 && A.nt >= 8;
+    if constexpr (kNbTabs > 0) {
+        static_assert(kNbEntries == kAisBlock, "one table entry per thread");
+        if (nb_on) {
+            int slot = 0;
+            for (int k = 0; k < D && slot < kNbTabs; ++k) {  // (wave-uniform)
+                if (A.prior[k].kind == KABC_PRIOR_NEGBINOMIAL) {
+                    snb[slot * kNbEntries + threadIdx.x] =
+                        kabc_lgamma_t((double)threadIdx.x + A.prior[k].p[0], kabc_log_tab);
+                    ++slot;
+                }
+            }
+        }
+    }
     KABC_TIMED_BARRIER();
+    if constexpr (kNbTabs > 0) {
+        // p[2] of the staged NegativeBinomial components (a field the family does not use):
+        // the table slot, or -1.  After the barrier: the staging copy above is complete; before
+        // the next one: the consumer has not read the components yet.
+        if (threadIdx.x < D && sprior[threadIdx.x].kind == KABC_PRIOR_NEGBINOMIAL) {
+            int slot = 0;
+            for (int k = 0; k < (int)threadIdx.x; ++k)
+                slot += (sprior[k].kind == KABC_PRIOR_NEGBINOMIAL) ? 1 : 0;
+            sprior[threadIdx.x].p[2] = (nb_on && slot < kNbTabs) ? (double)slot : -1.0;
+        }
+    }
     if constexpr (kBoxRegs) {  // per-lane copies from LDS (vector registers: scalar ones ran
                                // out and spilled when these were loaded as uniform values)
 #pragma unroll
@@ -771,7 +804,8 @@ ais_half_kernel(const AisArgs A0) {
                     double nlp, nll;
                     bool ev;
                     loglike<D, COST, PC>(sprior, box, gbox, PK, A.eps, A.reps, y, cparams,
-                                         A.cost_data, A.cost_ndata, &rng, nlp, nll, ev, slogtab);
+                                         A.cost_data, A.cost_ndata, &rng, nlp, nll, ev, slogtab,
+                                         kNbTabs > 0 ? snb : nullptr);
                     __builtin_amdgcn_sched_barrier(0);
                     n_eval += ev ? 1u : 0u;
                     // accept(...)  src/types.jl:62-75, :96-104

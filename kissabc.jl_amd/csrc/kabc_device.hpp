@@ -66,11 +66,14 @@ __device__ __forceinline__ double comp_logpdf_simple(int kind, const PriorDev& q
     }
 }
 
+// entries of a per-component lgamma(k + r) table (NegativeBinomial, see the family's case below)
+constexpr int kNbEntries = 256;
 // tab: kabc_log_tab or the kernel's LDS copy of it (same values; the global table is a dependent
 // L2 round trip per log on the consumer's chain)
 __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, double b, double p2,
                                                            double p3, double c0, double c1, double rb,
-                                                           double x, const double* tab = kabc_log_tab) {
+                                                           double x, const double* tab = kabc_log_tab,
+                                                           const double* nbtab = nullptr) {
     switch (kind) {
         case KABC_PRIOR_UNIFORM: return (x >= a && x <= b) ? c0 : -KABC_INF;
         case KABC_PRIOR_NORMAL: {
@@ -93,8 +96,19 @@ __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, d
         case KABC_PRIOR_NEGBINOMIAL: {
             if (!(x >= 0.0) || x != kabc_rint(x)) return -KABC_INF;
             // lgamma(x + 1) of the integer x: a lookup of kabc_lgamma's own values below 256
-            // (include/kabc_math.h kabc_lgamma1p_int_t), ~150 instructions less per transition
-            return c0 + x * c1 + kabc_lgamma_t(x + a, tab) - kabc_lgamma1p_int_t(x, tab);
+            // (include/kabc_math.h kabc_lgamma1p_int_t), ~150 instructions less per transition.
+            // lgamma(x + r): the AIS kernel tabulates it per NegativeBinomial component for the
+            // launch (kNbEntries values of kabc_lgamma_t itself in LDS, ais_kernels.hpp); p2 is
+            // then the component's table slot (a field the family does not use), else < 0 / no table
+            double lga;
+            if (nbtab != nullptr && p2 >= 0.0) {  // (wave-uniform)
+                const bool in = (x >= 0.0) && (x < (double)kNbEntries);
+                lga = nbtab[(int)p2 * kNbEntries + (in ? (int)x : 0)];
+                if (x >= (double)kNbEntries) lga = kabc_lgamma_t(x + a, tab);
+            } else {
+                lga = kabc_lgamma_t(x + a, tab);
+            }
+            return c0 + x * c1 + lga - kabc_lgamma1p_int_t(x, tab);
         }
         case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -c0 - kabc_div_rc(x, a, rb) : -KABC_INF;
         case KABC_PRIOR_GAMMA: {
@@ -114,8 +128,9 @@ __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, d
 
 static __device__ __noinline__ double comp_logpdf_general(int kind, double a, double b, double p2,
                                                           double p3, double c0, double c1, double rb,
-                                                          double x, const double* tab) {
-    return comp_logpdf_general_body(kind, a, b, p2, p3, c0, c1, rb, x, tab);
+                                                          double x, const double* tab,
+                                                          const double* nbtab = nullptr) {
+    return comp_logpdf_general_body(kind, a, b, p2, p3, c0, c1, rb, x, tab, nbtab);
 }
 
 // Inlined up to kGeneralInlineD components: a call costs the caller its live registers
@@ -124,11 +139,12 @@ static __device__ __noinline__ double comp_logpdf_general(int kind, double a, do
 constexpr int kGeneralInlineD = 8;
 template <int D = KABC_MAX_DIM>
 __device__ __forceinline__ double comp_logpdf(int kind, const PriorDev& q, double x,
-                                              const double* tab = kabc_log_tab) {
+                                              const double* tab = kabc_log_tab,
+                                              const double* nbtab = nullptr) {
     if constexpr (D <= kGeneralInlineD)
-        return comp_logpdf_general_body(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x, tab);
+        return comp_logpdf_general_body(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x, tab, nbtab);
     else
-        return comp_logpdf_general(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x, tab);
+        return comp_logpdf_general(kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, x, tab, nbtab);
 }
 
 // the prepared block of an MvNormal prior (kabc_mvnormal.h) as a wave-uniform pointer
@@ -173,7 +189,8 @@ inline bool prior_is_simple(int kind) {
 template <int D, bool SIMPLE = false, bool FENCED = true>
 __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restrict__ P,
                                                        const double* x, double* xp,
-                                                       const double* tab = kabc_log_tab) {
+                                                       const double* tab = kabc_log_tab,
+                                                       const double* nbtab = nullptr) {
     double s = 0.0;
     [[maybe_unused]] int kind0 = 0;
 #pragma unroll
@@ -187,7 +204,7 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restric
         const bool disc = __builtin_amdgcn_readfirstlane(q.discrete) != 0;
         const double v = disc ? kabc_rint(x[k]) : x[k];
         xp[k] = v;
-        const double l = SIMPLE ? comp_logpdf_simple(kind, q, v) : comp_logpdf<D>(kind, q, v, tab);
+        const double l = SIMPLE ? comp_logpdf_simple(kind, q, v) : comp_logpdf<D>(kind, q, v, tab, nbtab);
         s = (k == 0) ? l : s + l;
     }
 #ifndef KABC_NO_MVN_DEVICE  // (A/B builds: the case compiled out)
