@@ -46,3 +46,20 @@ def test_negbin_lgamma_tables_bit_exact(k, orc, gpu_ctx, name, nt, kernelized):
     assert st["accepted"] > 0   # the chains move: the log-densities compared are not all -Inf
     if name == "beyond_table":
         assert np.max(got[..., 0]) >= 256   # counts past the tabulated range were visited
+
+
+def test_negbin_tables_in_a_hiprtc_compiled_kernel(k, orc, gpu_ctx):
+    """The same tables inside a half-generation kernel compiled at run time for a user cost
+    (kabc_compile_cost_plugin): the snippet is the built-in Rosenbrock formula, so the trajectory
+    must equal the built-in's and the oracle's."""
+    from tests.test_user_cost import ROSEN_SRC
+    user = k.costs.UserCost(ROSEN_SRC + "// negbin tables\n", dims=[2], posteriors=["kernelized"])
+    prior = _priors(k)["socks"]
+    N, nt, gens = 900, 12, 2
+    got = k.AisEnsemble(k.ApproxKernelizedPosterior(prior, user, 50.0), N, seed=9).init().advance(
+        gens, nt, collect=True)
+    ref = k.AisEnsemble(k.ApproxKernelizedPosterior(prior, k.costs.Rosenbrock(), 50.0), N,
+                        seed=9).init().advance(gens, nt, collect=True)
+    assert np.array_equal(got, ref)
+    o = orc.OracleAIS(k.ApproxKernelizedPosterior(prior, k.costs.Rosenbrock(), 50.0), N, seed=9).init()
+    assert np.array_equal(got, o.generations_sync(gens, nt))
