@@ -36,8 +36,9 @@ __global__ void __launch_bounds__(kAuxBlock) aux_normal_meanstd_kernel(const Aux
         const int64_t ws = A.word_stride ? A.word_stride : A.rows;
         double m[2];
         kabc_cost_normal_meanstd_moments(n, sz, szz, m);
-        aux[(s * 2 + 0) * ws + r] = m[0];
-        aux[(s * 2 + 1) * ws + r] = m[1];
+        const int64_t sl = A.ring > 0 ? (int64_t)((t0 + (uint64_t)s) % (uint64_t)A.ring) : s;
+        aux[(sl * 2 + 0) * ws + r] = m[0];
+        aux[(sl * 2 + 1) * ws + r] = m[1];
     }
 }
 

@@ -38,6 +38,10 @@ struct AuxArgs {
     const unsigned long long* t_dev;
     int64_t word_stride;
     const int32_t* skip_if;  // the kernel is a no-op while *skip_if != 0 (smc: the loop is over)
+    // smc, several passes ahead in one launch (nt = ring > 1): pass t goes to slot t mod ring of
+    // the buffer ([ring][W][word_stride]) -- smc_mcmc_kernel looks its pass up the same way, so
+    // no launch has to know how many of the prepared passes have been used (0: slot = sub-step)
+    int32_t ring;
 };
 
 // does a grid-wide pre-pass exist for this cost?  (built-ins only: a user cost's prepare step is

@@ -514,8 +514,16 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     double* d_aux = nullptr;
     AuxArgs xa;
     std::memset(&xa, 0, sizeof xa);
+    // One pre-pass launch per batch of iterations instead of one per pass, when an iteration is
+    // exactly one pass (no retries) and the ring of prepared passes stays small: README.md:80-84
+    // (100 particles) is bound by its four launches per iteration.  kAuxRing = the iterations the
+    // host enqueues between two looks at the control block (kBatch below).
+    constexpr int kAuxRing = 16;
+    const int aux_ring = (auxW && !comm && o->mcmc_retrys == 0 &&
+                          (size_t)auxW * (size_t)N * kAuxRing * sizeof(double) <= ((size_t)32 << 20))
+                             ? kAuxRing : 1;
     if (auxW) {
-        KABC_HIP_CHECK(bufs.alloc(&d_aux, (size_t)auxW * N));
+        KABC_HIP_CHECK(bufs.alloc(&d_aux, (size_t)auxW * N * aux_ring));
         xa.aux = d_aux + (comm ? wg_lo * kSmcBlock : 0);
         xa.cost_params = d_params;
         xa.cost_data = d_data;
@@ -524,15 +532,17 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         xa.rows = comm ? std::min<int64_t>(wg_n * kSmcBlock, N - wg_lo * kSmcBlock) : N;
         if (xa.rows < 0) xa.rows = 0;
         xa.seed = o->seed;
-        xa.nt = 1;
+        xa.nt = aux_ring;
+        xa.ring = aux_ring > 1 ? aux_ring : 0;
         xa.domain = KABC_DOM_SMC_COST;
         xa.t_dev = &ctrl->pass;
         xa.word_stride = N;
         xa.skip_if = &ctrl->done;
         ma.aux = d_aux;
+        ma.aux_ring = aux_ring;
     }
     auto run_pass = [&](hipStream_t st) {  // one propose / accept pass (+ its pre-pass)
-        if (auxW) launch_aux_prepass(cost->id, xa, st, 1);
+        if (auxW && aux_ring == 1) launch_aux_prepass(cost->id, xa, st, 1);
         mcmc(ma, st);
     };
     SmcLoopParams lpz;
@@ -669,6 +679,8 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     const int kBatch = (R <= kGroup) ? 16 : 1;   // iterations per host sync
     bool first = true;
     while (!looped && !comm) {
+        // (the next kBatch passes at once: pass t = *ctrl.pass + 1 + s in slot t mod kAuxRing)
+        if (auxW && aux_ring > 1) launch_aux_prepass(cost->id, xa, s, 1);
         for (int it = 0; it < kBatch; ++it) {
             KABC_HIP_CHECK(launch_select(sa, selG, s));
             bool ended = false;  // the iteration's end rode on the last pass_end launch

@@ -130,8 +130,10 @@ struct SmcMcmcArgs {
     unsigned long long* part;  // [workgroups][4], see smc_block_stats
     int64_t wg0, nwg;          // sharded cost loop: the workgroups of this launch ...
     int32_t sharded;           // ... when set, else all
-    // prepared cost words of this pass for every particle, [W][N] (ais_aux_kernels.hpp), or NULL
+    // prepared cost words of this pass for every particle, [W][N] (ais_aux_kernels.hpp), or NULL;
+    // aux_ring > 1: [aux_ring][W][N], pass t in slot t mod aux_ring (AuxArgs::ring)
     const double* aux;
+    int32_t aux_ring;
 };
 
 struct SmcFinalArgs {
@@ -839,7 +841,8 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
                 if (lprob < lM) {
                     kabc_cost_rng_t rng = {A.seed, pass, w, KABC_DOM_SMC_COST, 0u};
                     if (A.aux) {
-                        rng.aux = A.aux + i;
+                        const int64_t sl = A.aux_ring > 1 ? (int64_t)(pass % (uint64_t)A.aux_ring) : 0;
+                        rng.aux = A.aux + sl * (int64_t)kabc_cost_aux_words(COST) * A.N + i;
                         rng.aux_stride = (uint32_t)A.N;
                     }
                     const double Xp =
