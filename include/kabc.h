@@ -73,7 +73,11 @@ typedef enum kabc_prior_kind {
      * handle of kabc_mvnormal_register below.  All D components of the prior carry this kind,
      * the same handle and k = their index; D <= KABC_MAX_DIM.  include/kabc_mvnormal.h. */
     KABC_PRIOR_MVNORMAL = 11,
-    KABC_PRIOR__COUNT = 12
+    KABC_PRIOR__COUNT = 12,
+    /* kinds >= KABC_PRIOR_USER: families compiled at run time from a C snippet
+     * (kabc_compile_prior_plugin below) -- the reference's Factored takes ANY
+     * UnivariateDistribution (src/priors.jl:11). */
+    KABC_PRIOR_USER = 100
 } kabc_prior_kind_t;
 
 /* one univariate component of Factored(...) */
@@ -200,6 +204,51 @@ kabc_status_t kabc_compile_cost_plugin(const char* src, const int32_t* dims, int
  * (variant = 1 for priors without Beta / Gamma / LogNormal / NegativeBinomial components, else
  * 0), 3 smc init, 4 smc persistent loop, 5 / 6 ABCDE init / generation, 7 pfilter attempt. */
 kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family, int32_t D, int32_t variant);
+
+/* ---- user prior families ------------------------------------------------------
+ * The reference's Factored is a tuple of ANY UnivariateDistribution: `logpdf`, `rand` and the
+ * continuous / discrete split of push_p dispatch on each component's type (src/priors.jl:11,
+ * :31-33, :43; src/types.jl:30-32).  The families of kabc_prior_kind_t are built in; any other
+ * one is a C snippet defining
+ *   KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab);
+ *   KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w);
+ * x: the coordinate after push_p (rounded when the family is discrete); p: the component's
+ * kabc_prior_t.p[4]; -Inf outside the support; tab: the table kabc_log_t / kabc_log1p_t /
+ * kabc_lgamma_t of kabc_math.h take (the calling kernel's LDS copy).  rand draws from the
+ * component's window of the counter stream: kabc_slot(w, j), j < KABC_SLOTS_PER_DIM, and the
+ * helpers of kabc_sampling_base.h (kabc_sample_gamma1, kabc_sample_poisson).  Constants that are
+ * expensive to derive (a truncation's log-mass, a normaliser's lgamma) belong into the snippet
+ * text as literals: the host computes them once, as Distributions.jl does at construction.
+ * `discrete` != 0: push_p rounds the coordinate (round(Int, .), src/types.jl:32).
+ * The snippet alone is compiled at once by hipRTC (errors come back here with the compiler's
+ * message).  *out_kind (>= KABC_PRIOR_USER) goes into kabc_prior_t.kind.  A prior with such a
+ * component has no prebuilt kernels: every entry point that receives one compiles the kernel
+ * family it needs for that (prior kinds, cost) pair at first use (1-5 s, kept in an on-disk
+ * cache of code objects: KABC_RTC_CACHE_DIR, default next to the library) -- the way a user
+ * cost does.  length(prior) <= KABC_MAX_DIM for such priors. */
+kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32_t* out_kind);
+
+/* ---- kernels specialised for ONE model ------------------------------------------
+ * Compiles the kernel families of `families` (bit 0 AIS, 1 smc, 2 ABCDE, 3 pfilter; 0 = AIS +
+ * smc) for exactly this prior tuple and cost: every component's family and parameters are
+ * compile-time constants of the generated translation unit -- no family dispatch, no
+ * per-component parameter records in LDS, the normalisers folded.  Results are bit-identical to
+ * the prebuilt kernels' (same formulas, same operation order).  Afterwards kabc_ais_create* /
+ * kabc_smc_run / kabc_abcde_run / kabc_pfilter_run use the specialised kernels whenever they
+ * receive the same prior components (bit for bit), D and cost id; model->posterior and ->eps do
+ * not take part (the posterior kind is a template parameter of the AIS kernel, chosen at
+ * kabc_ais_create).  Priors made of Uniform / DiscreteUniform components only are left to the
+ * prebuilt kernels (their box test is already parameter-free); so are full-covariance
+ * MvNormal priors and length(prior) > KABC_MAX_DIM.  KABC_SPECIALIZE=1 in the environment makes
+ * every entry point specialise on its own at first sight of a model.  Without hipRTC (or with
+ * KABC_SPECIALIZE=0) the prebuilt kernels remain the path.  *out_handle (optional) identifies
+ * the registration for kabc_model_release. */
+#define KABC_FAMILY_AIS 1
+#define KABC_FAMILY_SMC 2
+#define KABC_FAMILY_ABCDE 4
+#define KABC_FAMILY_PFILTER 8
+kabc_status_t kabc_compile_model(const kabc_model_t* model, int32_t families, int32_t* out_handle);
+kabc_status_t kabc_model_release(int32_t handle);
 
 /* ---- AIS: sample(model, AIS(N), Ns; ntransitions, discard_initial, retry_sampling)
  *

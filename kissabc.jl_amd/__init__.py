@@ -8,14 +8,15 @@ from . import costs
 from ._cdefs import KABC_MAX_DIM
 from ._lib import Context, KabcError, LIB_PATH, default_context
 from .api import (ABCDE, AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity,
-                  MCMCThreads, pfilter,
+                  MCMCThreads, compile_model, pfilter,
                   Particles, sample, smc)
 from . import comm
 from .comm import Comm, EnsembleGroup
 from .costs import DeviceCost
 from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, InitFromSnippet,
                             LogNormal, MultivariateNormal, MvNormal, NegativeBinomial, Normal, Product,
-                            Truncated, TruncatedNormal, Uniform, UserInit, truncated)
+                            Laplace, Poisson, Truncated, TruncatedGamma, TruncatedNormal, Uniform, UserInit,
+                            UserPrior, truncated)
 
 __all__ = [
     "ABCDE", "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "CommonLogDensity",
@@ -24,4 +25,5 @@ __all__ = [
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
     "Exponential", "Gamma", "LogNormal", "Product", "MvNormal", "MultivariateNormal", "Context", "KabcError", "default_context", "LIB_PATH",
     "KABC_MAX_DIM", "comm", "Comm", "EnsembleGroup", "UserInit", "InitFromSnippet",
+    "UserPrior", "Poisson", "Laplace", "TruncatedGamma", "compile_model",
 ]

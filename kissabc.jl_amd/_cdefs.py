@@ -22,6 +22,8 @@ PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_BETA, PRIOR_DISCRETE_UNIFO
     PRIOR_NEGBINOMIAL, PRIOR_EXPONENTIAL, PRIOR_GAMMA, PRIOR_LOGNORMAL = range(1, 10)
 PRIOR_USER_INIT = 10
 PRIOR_MVNORMAL = 11
+PRIOR_USER = 100         # kinds >= this: families compiled at run time (kabc_compile_prior_plugin)
+FAMILY_AIS, FAMILY_SMC, FAMILY_ABCDE, FAMILY_PFILTER = 1, 2, 4, 8
 
 POSTERIOR_KERNELIZED, POSTERIOR_THRESHOLD, POSTERIOR_COMMON = 1, 2, 3
 
@@ -123,6 +125,9 @@ PROTOTYPES = {
     "kabc_plugin_precompile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "kabc_compile_cost_plugin": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32)]),
+    "kabc_compile_prior_plugin": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "kabc_compile_model": (C.c_int, [C.POINTER(Model), C.c_int32, C.POINTER(C.c_int32)]),
+    "kabc_model_release": (C.c_int, [C.c_int32]),
     "kabc_ais_create": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_uint64, C.POINTER(VP)]),
     "kabc_ais_create_batch": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_int32,
                                         C.POINTER(C.c_uint64), C.POINTER(VP)]),

@@ -116,6 +116,26 @@ class CommonLogDensity(_ApproxModel):
         return self.cost
 
 
+def compile_model(model_or_prior, cost=None, families=0):
+    """Compile kernels specialised for ONE model (kabc_compile_model, include/kabc.h): the prior
+    tuple's families and parameters become compile-time constants of a run-time compiled
+    translation unit.  compile_model(model) for an ApproxKernelizedPosterior / ApproxPosterior,
+    compile_model(prior, cost) for smc / ABCDE / pfilter; `families`: bit mask of
+    cd.FAMILY_AIS / _SMC / _ABCDE / _PFILTER (0 = AIS + smc).  Afterwards sample / smc / ... on
+    the same prior components and cost use the specialised kernels; results keep their bits.
+    Returns the registration's handle (0: the model is left to the prebuilt kernels)."""
+    if cost is None:
+        m = model_or_prior.to_c()
+        keep = model_or_prior
+    else:
+        keep = _ApproxModel(model_or_prior, cost, 1.0)
+        m = keep.to_c()
+    h = C.c_int32()
+    _lib.check(_lib.load().kabc_compile_model(C.byref(m), int(families), C.byref(h)))
+    del keep
+    return int(h.value)
+
+
 class AIS:
     """AIS(nparticles) -- src/KissABC.jl:21-23"""
 

@@ -150,6 +150,8 @@ __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
 //   GENERAL everything (Exponential, Beta, NegativeBinomial, Gamma, LogNormal ...)
 enum { kPriorBox = 0, kPriorSimple = 1, kPriorGeneral = 2, kPriorNormal = 3 };
 constexpr int kPriorClasses = 4;
+// GENERAL class: NegativeBinomial components whose lgamma(k + r) is tabulated per launch in LDS
+constexpr int kNbTabsGeneral = 2;
 
 struct BoxPrior {
     const double* lo;   // LDS, [D]
@@ -303,6 +305,12 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         else sum = gaussbox_logpdf_push<D, false, true>(GB, y, yp, in);
         lp = in ? sum : -KABC_INF;
     } else {
+#ifdef KABC_MODEL_SPEC
+        // a translation unit generated for one model (kabc_compile_model): families and
+        // parameters are compile-time constants (kabc_device.hpp model_logpdf_push)
+        if constexpr (D == kabc_mspec::D) lp = model_logpdf_push<D, kNbTabsGeneral>(y, yp, logtab, nbtab);
+        else
+#endif
         lp = factored_logpdf_push<D, false>(P, y, yp, logtab, nbtab);
     }
     ev = kabc_isfinite(lp);
@@ -535,7 +543,7 @@ ais_half_kernel(const AisArgs A0) {
     // GENERAL class: lgamma(k + r), k < kNbEntries, of the first kNbTabs NegativeBinomial
     // components -- kabc_lgamma_t's own values, computed once per launch by the whole workgroup
     // instead of once per transition by the consumer (kabc_device.hpp, the family's case)
-    constexpr int kNbTabs = (PC == kPriorGeneral) ? 2 : 0;
+    constexpr int kNbTabs = (PC == kPriorGeneral) ? kNbTabsGeneral : 0;
     __shared__ double snb[kNbTabs > 0 ? kNbTabs * kNbEntries : 1];
     // prepared costs (include/kabc_costs.h): the parameter-independent part of the cost
     // of every sub-step, computed by the producers; word j of lane l at [buf][si][j][l]
@@ -993,7 +1001,8 @@ inline dim3 ais_init_geom(const InitArgs& a, unsigned nchains) {
 // pcx = prior class + kPriorClasses * (posterior kind - 1)
 AisLaunch find_ais_kernel(int cost_id, int D, int pcx);
 constexpr int kAisVariants = 3 * kPriorClasses;
-void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains);
+struct ModelUnit;
+void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains, ModelUnit* unit);
 
 #endif
 

@@ -171,7 +171,29 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         return KABC_ERR_UNSUPPORTED;
     }
     AbcdeLaunch f_init, f_gen;
-    if (dyn) {
+    // (run-time compiled kernels are loaded on the CURRENT device)
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    ModelUnit* unit = nullptr;
+    for (int k = 0; k < D && dyn; ++k)
+        if (prior[k].kind >= KABC_PRIOR_USER) {
+            set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
+            return KABC_ERR_UNSUPPORTED;
+        }
+    if (!dyn)
+        if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
+    if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
+        const PluginKernel ki = unit_kernel(unit, kPfAbcdeInit, D, 0), kg = unit_kernel(unit, kPfAbcdeGen, D, 0);
+        if (ki.mod && kg.mod) {
+            f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
+            f_gen = AbcdeLaunch(kg.mod, &abcde_geom, (unsigned)kAbcdeBlock);
+        } else if (!unit_is_spec(unit)) {
+            return KABC_ERR_DEVICE;
+        } else {
+            unit = nullptr;
+        }
+    }
+    if (unit) {
+    } else if (dyn) {
         f_init = AbcdeLaunch(&l_init<0>);
         f_gen = AbcdeLaunch(&l_gen<0>);
     } else if (const CostPlugin* p = find_plugin(cost->id)) {

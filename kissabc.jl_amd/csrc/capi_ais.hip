@@ -67,7 +67,12 @@ static void launch_init_table(int D, const InitArgs& a, hipStream_t s, unsigned 
     fns[D - 1](a, s, nchains);
 }
 
-void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains) {
+void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains, ModelUnit* unit) {
+    if (unit) {  // user prior families / a specialised model: the unit's own init kernel
+        const PluginKernel k = unit_kernel(unit, kPfAisInit, D, 0);
+        if (k.mod) AisInitLaunch(k.mod, &ais_init_geom, (unsigned)kInitBlock)(a, s, nchains);
+        return;
+    }
     if (const CostPlugin* p = find_plugin(a.cost_id)) {
         const PluginKernel k = plugin_kernel(p, kPfAisInit, D, 0);
         using Fn = void (*)(const InitArgs&, hipStream_t, unsigned);
@@ -127,6 +132,7 @@ struct kabc_ais {
     uint64_t seed, t;
     int32_t rank, world;
     AisLaunch launch;
+    ModelUnit* unit;       // run-time compiled unit (user prior families / specialised model), else NULL
     double box_lp;
     bool initialised;
     // sample-trace streaming: device chunks filled in rotation by the kernels and
@@ -309,10 +315,32 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     }
     const int pc = isbox ? kPriorBox : allnormal ? kPriorNormal : gaussbox ? kPriorSimple : kPriorGeneral;
     static_assert(kPriorClasses == 4, "capi_plugin.hip decodes pcx with 4 prior classes");
-    AisLaunch fn = dyn ? AisLaunch()
-                       : find_ais_kernel(m->cost.id, m->D, pc + kPriorClasses * (m->posterior - 1));
-    if (!fn && !dyn && pc == kPriorNormal)  // plugins instantiate SIMPLE only
-        fn = find_ais_kernel(m->cost.id, m->D, kPriorSimple + kPriorClasses * (m->posterior - 1));
+    // (run-time compiled kernels are loaded on the CURRENT device)
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    // user prior families among the components, or a specialisation of exactly this model
+    // (kabc_compile_model): the kernels of that unit, GENERAL class (plugin_registry.hpp)
+    ModelUnit* unit = nullptr;
+    if (!dyn) {
+        if (kabc_status_t st = model_unit_for(m->prior, m->D, m->cost.id, &unit)) return st;
+    } else {
+        for (int k = 0; k < m->D; ++k)
+            if (m->prior[k].kind >= KABC_PRIOR_USER) {
+                set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, m->D);
+                return KABC_ERR_UNSUPPORTED;
+            }
+    }
+    AisLaunch fn;
+    if (unit) {
+        const PluginKernel uk = unit_kernel(unit, kPfAis, m->D, kPriorGeneral + kPriorClasses * (m->posterior - 1));
+        if (uk.mod) fn = AisLaunch(uk.mod, &ais_half_geom, (unsigned)kAisBlock);
+        if (!fn && unit_is_spec(unit)) unit = nullptr;  // (a specialisation that cannot be built: the prebuilt kernels)
+        else if (!fn) return KABC_ERR_DEVICE;            // (message set by the compilation / load)
+    }
+    if (!unit) {
+        fn = dyn ? AisLaunch() : find_ais_kernel(m->cost.id, m->D, pc + kPriorClasses * (m->posterior - 1));
+        if (!fn && !dyn && pc == kPriorNormal)  // plugins instantiate SIMPLE only
+            fn = find_ais_kernel(m->cost.id, m->D, kPriorSimple + kPriorClasses * (m->posterior - 1));
+    }
     if (!fn && !dyn) {
         set_error("no gfx950 kernel instantiated for cost id %d, D = %d", m->cost.id, m->D);
         return KABC_ERR_UNSUPPORTED;
@@ -344,6 +372,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         return KABC_ERR_INVALID_ARG;
     }
     h->launch = fn;
+    h->unit = unit;
     // BOX class: logpdf inside the box = c0_1 + ... + c0_D, summed left to right
     // exactly as logpdf(d::Factored, x) does (src/priors.jl:30-36)
     h->box_lp = h->prior.c[0].c0;
@@ -565,7 +594,7 @@ static kabc_status_t ais_init_enqueue(kabc_ais_t* h, int32_t retry_sampling) {
             a.chain_retries = h->d_chain_retries;
             a.stride_act = h->rows[hf] * h->D;
             a.stride_own = h->rows_owned[hf];
-            launch_ais_init(h->D, a, s, (unsigned)h->nchains);
+            launch_ais_init(h->D, a, s, (unsigned)h->nchains, h->unit);
             KABC_HIP_CHECK(hipGetLastError());
         }
     }

@@ -6,6 +6,8 @@
 
 #include "ais_kernels.hpp"
 #include "host_common.hpp"
+#include "plugin_registry.hpp"
+#include "prior_util_kernels.hpp"
 
 namespace kabc {
 
@@ -132,7 +134,14 @@ bool prepare_prior(const kabc_prior_t& pr, PriorDev& q) {
             if (!(a > 0) || !(b > 0)) return false;
             q.c0 = std::lgamma(a) + a * kabc_log(b);
             return true;
-        default: return false;
+        default: {
+            // a user family (kabc_compile_prior_plugin): parameters as given, no derived constants
+            int disc = 0;
+            if (pr.kind < KABC_PRIOR_USER || !user_prior_info(pr.kind, &disc)) return false;
+            q.discrete = disc;
+            q.rb = 0.0;
+            return true;
+        }
     }
 }
 
@@ -142,54 +151,6 @@ bool prepare_priors(const kabc_prior_t* prior, int D, PriorSet& out) {
     for (int k = 0; k < D; ++k)
         if (!prepare_prior(prior[k], out.c[k])) return false;
     return true;
-}
-
-// ---- Factored utility kernels (runtime D; not on the hot path) --------------
-struct PriorUtilArgs {
-    const double* x;
-    double* out;
-    int64_t n;
-    int32_t D;
-    int32_t mode;  // 0 logpdf, 1 push_p
-    uint64_t seed;
-    uint64_t attempt;
-    uint32_t first_walker;
-    uint32_t domain;
-    const PriorDev* prior;     // [D] prepared components (device; any D up to KABC_MAX_DIM_DYN)
-    const kabc_prior_t* raw;   // [D] raw components (device)
-};
-
-__global__ void __launch_bounds__(256) prior_logpdf_kernel(const PriorUtilArgs A) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.n) return;
-    double s = 0.0;
-    for (int k = 0; k < A.D; ++k) {
-        const double xv = A.x[i * A.D + k];
-        const PriorDev q = A.prior[k];
-        const double v = q.discrete ? kabc_rint(xv) : xv;
-        if (A.mode == 1) {
-            A.out[i * A.D + k] = v;
-        } else {
-            // logpdf(Factored, x) is evaluated on x as given (src/priors.jl:30-36)
-            // (an MvNormal component reads coordinates 0..k of the row: continuous, x as given)
-            const double l = q.kind == KABC_PRIOR_MVNORMAL
-                                 ? kabc_mvn_logpdf_comp(kabc_mvn_ptr_from_double(q.p[2]), A.D, k, A.x + i * A.D)
-                                 : comp_logpdf(q.kind, q, xv);
-            s = (k == 0) ? l : s + l;
-        }
-    }
-    if (A.mode == 0) A.out[i] = s;
-}
-
-__global__ void __launch_bounds__(256) prior_rand_kernel(const PriorUtilArgs A) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= A.n) return;
-    for (int k = 0; k < A.D; ++k) {
-        kabc_slotwin_t win = {A.seed, A.attempt, A.first_walker + (uint32_t)i, A.domain,
-                              (uint32_t)k * KABC_SLOTS_PER_DIM};
-        const kabc_prior_t pr = A.raw[k];
-        A.out[i * A.D + k] = kabc_sample_prior(&pr, &win);
-    }
 }
 
 }  // namespace kabc
@@ -344,6 +305,14 @@ static kabc_status_t prior_util(kabc_ctx_t* ctx, const kabc_prior_t* prior, int3
         }
     if (n == 0) return KABC_OK;
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    // (cost id 0: the utility kernels contain no cost; only user FAMILIES make a unit necessary --
+    // a specialisation registered for these components is for the samplers' kernels, not these)
+    ModelUnit* unit = nullptr;
+    bool has_user = false;
+    for (int k = 0; k < D; ++k) has_user = has_user || prior[k].kind >= KABC_PRIOR_USER;
+    if (has_user) {
+        if (kabc_status_t st = model_unit_for(prior, D, 0, &unit, false)) return st;
+    }
     PriorDev* d_prep = nullptr;
     kabc_prior_t* d_raw = nullptr;
     KABC_HIP_CHECK(hipMalloc(&d_prep, sizeof(PriorDev) * D));
@@ -370,10 +339,15 @@ static kabc_status_t prior_util(kabc_ctx_t* ctx, const kabc_prior_t* prior, int3
     A.first_walker = first_walker;
     A.domain = domain;
     const unsigned grid = (unsigned)((n + 255) / 256);
-    if (mode == 2)
+    if (unit) {  // user families among the components: the kernels compiled with their snippets
+        const PluginKernel k = unit_kernel(unit, mode == 2 ? kPfPriorRand : kPfPriorLogpdf, 1, 0);
+        if (!k.mod) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
+        KABC_HIP_CHECK(rtc_launch(k.mod, dim3(grid), dim3(256), &A, ctx->stream));
+    } else if (mode == 2) {
         hipLaunchKernelGGL(prior_rand_kernel, dim3(grid), dim3(256), 0, ctx->stream, A);
-    else
+    } else {
         hipLaunchKernelGGL(prior_logpdf_kernel, dim3(grid), dim3(256), 0, ctx->stream, A);
+    }
     KABC_HIP_CHECK(hipGetLastError());
     KABC_HIP_CHECK(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     KABC_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -19,9 +19,13 @@
 //   kabc_register_cost_plugin  a plugin .so prebuilt by hipcc from the same snippet +
 //       csrc/user_plugin.inc (every family and dimension at once, 15-40 s; also the only form
 //       that carries the run-time-dimension kernels for length(prior) > KABC_MAX_DIM).
+#include <dirent.h>
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <string>
@@ -126,14 +130,19 @@ static std::vector<std::string> rtc_include_dirs() {
     return dirs;
 }
 
-struct RtcPlugin {
+// ---- what gets compiled ---------------------------------------------------------------------
+// kernels compiled so far from one translation-unit recipe, per device
+struct RtcCache {
+    std::mutex mu;
+    std::map<std::string, void*> fns;  // "<device>|<name expression>" -> hipFunction_t
+    std::vector<hipModule_t> mods;
+};
+
+struct RtcPlugin : RtcCache {
     std::string src;        // the user's snippet
     std::string dim_cond;   // KABC_USER_DIM_OK(D)
     std::vector<int> dims;
     int pk_mask = 7;
-    std::mutex mu;
-    std::map<std::string, void*> fns;  // "<device>|<name expression>" -> hipFunction_t
-    std::vector<hipModule_t> mods;
 };
 
 static bool rtc_dim_listed(const RtcPlugin* R, int D) {
@@ -142,8 +151,199 @@ static bool rtc_dim_listed(const RtcPlugin* R, int D) {
     return false;
 }
 
-// compile `names` (kernel name expressions) from the snippet + `header` into one code object
-static kabc_status_t rtc_compile(const RtcPlugin* R, const char* header, bool fma_c_vgpr,
+// the cost part of a translation unit: the user's snippet and what the kernels need to know of it
+static std::string cost_head(const RtcPlugin* R) {
+    return "#define KABC_USER_DIM_OK(D) (" + R->dim_cond + ")\n#define KABC_USER_PK_MASK " +
+           std::to_string(R->pk_mask) + "\n#include \"kabc_philox.h\"\n" + R->src +
+           "\n#define KABC_USER_COST_DEFINED 1\n";
+}
+
+// ---- user prior families (kabc_compile_prior_plugin) ------------------------------------------
+struct PriorPlugin {
+    int32_t kind;
+    int32_t discrete;
+    std::string src;
+};
+static std::vector<PriorPlugin*> g_prior_plugins;  // kind = KABC_PRIOR_USER + index (g_mu)
+
+static const PriorPlugin* find_prior_plugin(int kind) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int i = kind - KABC_PRIOR_USER;
+    return (i >= 0 && i < (int)g_prior_plugins.size()) ? g_prior_plugins[(size_t)i] : nullptr;
+}
+
+bool user_prior_info(int kind, int* discrete) {
+    const PriorPlugin* p = find_prior_plugin(kind);
+    if (!p) return false;
+    if (discrete) *discrete = p->discrete;
+    return true;
+}
+
+// the prior part of a translation unit: every listed family's snippet under its own function
+// names + the dispatch the built-in switch statements fall through to (include/kabc_sampling.h
+// kabc_sample_prior, kabc_device.hpp comp_logpdf_general_body)
+static std::string priors_head(const std::vector<int>& kinds) {
+    if (kinds.empty()) return std::string();
+    std::string t = "#include \"kabc_sampling_base.h\"\n";
+    std::string lp = "#define KABC_USER_PRIOR_LOGPDF(kind, x, p, tab) (";
+    std::string rd = "#define KABC_USER_PRIOR_RAND(kind, p, w) (";
+    for (int k : kinds) {
+        const PriorPlugin* pp = find_prior_plugin(k);
+        const std::string sk = std::to_string(k);
+        t += "#define kabc_user_prior_logpdf kabc_user_prior_logpdf_" + sk +
+             "\n#define kabc_user_prior_rand kabc_user_prior_rand_" + sk + "\n" + (pp ? pp->src : std::string()) +
+             "\n#undef kabc_user_prior_logpdf\n#undef kabc_user_prior_rand\n";
+        lp += "(kind) == " + sk + " ? kabc_user_prior_logpdf_" + sk + "(x, p, tab) : ";
+        rd += "(kind) == " + sk + " ? kabc_user_prior_rand_" + sk + "(p, w) : ";
+    }
+    t += lp + "KABC_NAN)\n" + rd + "KABC_NAN)\n";
+    return t;
+}
+
+// a double as a C++17 literal with exactly its bits
+static std::string lit(double v) {
+    if (v != v) return "__builtin_nan(\"\")";
+    if (v == HUGE_VAL) return "__builtin_inf()";
+    if (v == -HUGE_VAL) return "(-__builtin_inf())";
+    char b[64];
+    std::snprintf(b, sizeof b, "%a", v);
+    return b;
+}
+
+// the model part of a specialised unit: the prepared components as constexpr data
+static std::string spec_head(const PriorDev* q, int D) {
+    std::string t = "#define KABC_MODEL_SPEC 1\nnamespace kabc_mspec {\nconstexpr int D = " + std::to_string(D) + ";\n";
+    std::string kind = "constexpr int KIND[D] = {", disc = "constexpr bool DISC[D] = {", P = "constexpr double P[D][4] = {",
+                c0 = "constexpr double C0[D] = {", c1 = "constexpr double C1[D] = {", rb = "constexpr double RB[D] = {";
+    for (int k = 0; k < D; ++k) {
+        const char* sep = k + 1 < D ? ", " : "};\n";
+        kind += std::to_string(q[k].kind) + sep;
+        disc += std::string(q[k].discrete ? "true" : "false") + sep;
+        P += "{" + lit(q[k].p[0]) + ", " + lit(q[k].p[1]) + ", " + lit(q[k].p[2]) + ", " + lit(q[k].p[3]) + "}" + sep;
+        c0 += lit(q[k].c0) + sep;
+        c1 += lit(q[k].c1) + sep;
+        rb += lit(q[k].rb) + sep;
+    }
+    return t + kind + disc + P + c0 + c1 + rb + "}\n";
+}
+
+// ---- compilation + the on-disk cache of code objects -----------------------------------------
+static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+    const unsigned char* p = (const unsigned char*)data;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= p[i];
+        h *= 0x100000001b3ull;
+    }
+    return h;
+}
+
+// hash of every header a unit is compiled against (the include directories' *.h / *.hpp / *.inc)
+// and of the compiler: a cached code object of older kernels must never be loaded
+static uint64_t toolchain_fingerprint() {
+    static uint64_t fp = 0;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (const std::string& d : rtc_include_dirs()) {
+            std::vector<std::string> names;
+            if (DIR* dir = opendir(d.c_str())) {
+                while (const dirent* e = readdir(dir)) {
+                    const std::string n = e->d_name;
+                    const size_t dot = n.rfind('.');
+                    const std::string ext = dot == std::string::npos ? "" : n.substr(dot);
+                    if (ext == ".h" || ext == ".hpp" || ext == ".inc") names.push_back(n);
+                }
+                closedir(dir);
+            }
+            std::sort(names.begin(), names.end());
+            for (const std::string& n : names) {
+                h = fnv1a(n.data(), n.size() + 1, h);
+                if (FILE* f = std::fopen((d + "/" + n).c_str(), "rb")) {
+                    char buf[65536];
+                    size_t got;
+                    while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) h = fnv1a(buf, got, h);
+                    std::fclose(f);
+                }
+            }
+        }
+        int maj = 0, min = 0;
+        if (auto ver = (hiprtcResult(*)(int*, int*))(g_rtc.dl ? dlsym(g_rtc.dl, "hiprtcVersion") : nullptr))
+            (void)ver(&maj, &min);
+        h = fnv1a(&maj, sizeof maj, h);
+        h = fnv1a(&min, sizeof min, h);
+        fp = h;
+    });
+    return fp;
+}
+
+// KABC_RTC_CACHE_DIR, else <library directory>/rtc_cache; "" or "0" disables
+static std::string rtc_cache_dir() {
+    if (const char* e = std::getenv("KABC_RTC_CACHE_DIR")) {
+        const std::string v(e);
+        return (v.empty() || v == "0") ? std::string() : v;
+    }
+    Dl_info info;
+    if (dladdr((const void*)&find_plugin, &info) && info.dli_fname) {
+        std::string lib(info.dli_fname);
+        const size_t sl = lib.rfind('/');
+        return (sl == std::string::npos ? std::string(".") : lib.substr(0, sl)) + "/rtc_cache";
+    }
+    return std::string();
+}
+
+static bool cache_load(const std::string& path, size_t nnames, std::vector<char>* code,
+                       std::vector<std::string>* lowered) {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    bool ok = false;
+    char magic[8];
+    uint32_t n = 0;
+    if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "KABCRTC1", 8) == 0 &&
+        std::fread(&n, 4, 1, f) == 1 && n == nnames) {
+        ok = true;
+        for (uint32_t i = 0; i < n && ok; ++i) {
+            uint32_t len = 0;
+            ok = std::fread(&len, 4, 1, f) == 1 && len < 4096;
+            std::string s(ok ? len : 0, '\0');
+            ok = ok && (len == 0 || std::fread(&s[0], 1, len, f) == len);
+            lowered->push_back(s);
+        }
+        uint64_t cs = 0;
+        ok = ok && std::fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < (1ull << 31);
+        if (ok) {
+            code->resize((size_t)cs);
+            ok = std::fread(code->data(), 1, (size_t)cs, f) == (size_t)cs;
+        }
+    }
+    std::fclose(f);
+    if (!ok) {
+        code->clear();
+        lowered->clear();
+    }
+    return ok;
+}
+
+static void cache_store(const std::string& dir, const std::string& path, const std::vector<char>& code,
+                        const std::vector<std::string>& lowered) {
+    (void)mkdir(dir.c_str(), 0777);
+    const std::string tmp = path + "." + std::to_string((long long)getpid()) + ".tmp";
+    FILE* f = std::fopen(tmp.c_str(), "wb");
+    if (!f) return;  // (a read-only install: compile every time)
+    const uint32_t n = (uint32_t)lowered.size();
+    const uint64_t cs = code.size();
+    bool ok = std::fwrite("KABCRTC1", 1, 8, f) == 8 && std::fwrite(&n, 4, 1, f) == 1;
+    for (const std::string& s : lowered) {
+        const uint32_t len = (uint32_t)s.size();
+        ok = ok && std::fwrite(&len, 4, 1, f) == 1 && (len == 0 || std::fwrite(s.data(), 1, len, f) == len);
+    }
+    ok = ok && std::fwrite(&cs, 8, 1, f) == 1 && std::fwrite(code.data(), 1, code.size(), f) == code.size();
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+}
+
+// compile `names` (kernel name expressions) from `head` (snippets, model constants) + `header`
+// (the kernel templates) into one code object
+static kabc_status_t rtc_compile(const std::string& head, const char* header, bool fma_c_vgpr,
                                  const std::vector<std::string>& names, std::vector<char>* code,
                                  std::vector<std::string>* lowered) {
     Hiprtc* H = hiprtc();
@@ -152,20 +352,34 @@ static kabc_status_t rtc_compile(const RtcPlugin* R, const char* header, bool fm
                   "by hipcc with kabc_register_cost_plugin)", g_rtc.why.c_str());
         return KABC_ERR_DEVICE;
     }
-    std::string text = "// generated by kabc_compile_cost_plugin\n#define KABC_USER_DIM_OK(D) (" +
-                       R->dim_cond + ")\n#define KABC_USER_PK_MASK " + std::to_string(R->pk_mask) +
-                       "\n#include \"kabc_philox.h\"\n" + R->src + "\n#define KABC_USER_COST_DEFINED 1\n";
+    std::string text = "// generated by libkabc_hip (capi_plugin.hip)\n" + head;
     if (fma_c_vgpr) text += "#define KABC_FMA_C_VGPR\n";
     if (header) text += std::string("#include \"") + header + "\"\n";
+    // the flags of csrc/Makefile: the arithmetic contract needs -ffp-contract=off
+    std::vector<std::string> opt = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                                    "-fno-fast-math"};
+    // the on-disk cache: keyed by everything that determines the code object
+    std::string cpath;
+    const std::string cdir = code ? rtc_cache_dir() : std::string();
+    if (!cdir.empty()) {
+        uint64_t h = fnv1a(text.data(), text.size(), toolchain_fingerprint());
+        uint64_t h2 = fnv1a(text.data(), text.size(), 0x9e3779b97f4a7c15ull ^ toolchain_fingerprint());
+        for (const std::string& n : names) {
+            h = fnv1a(n.data(), n.size() + 1, h);
+            h2 = fnv1a(n.data(), n.size() + 1, h2);
+        }
+        for (const std::string& o : opt) h = fnv1a(o.data(), o.size() + 1, h);
+        char nm[64];
+        std::snprintf(nm, sizeof nm, "/kabc_%016llx%016llx.co", (unsigned long long)h, (unsigned long long)h2);
+        cpath = cdir + nm;
+        if (cache_load(cpath, names.size(), code, lowered)) return KABC_OK;
+    }
     hiprtcProgram prog = nullptr;
-    if (H->CreateProgram(&prog, text.c_str(), "kabc_user_cost.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
+    if (H->CreateProgram(&prog, text.c_str(), "kabc_rtc_unit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
         set_error("hiprtcCreateProgram failed");
         return KABC_ERR_DEVICE;
     }
     for (const std::string& n : names) (void)H->AddNameExpression(prog, n.c_str());
-    // the flags of csrc/Makefile: the arithmetic contract needs -ffp-contract=off
-    std::vector<std::string> opt = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                                    "-fno-fast-math"};
     for (const std::string& d : rtc_include_dirs()) opt.push_back("-I" + d);
     std::vector<const char*> optp;
     for (const std::string& o : opt) optp.push_back(o.c_str());
@@ -176,7 +390,7 @@ static kabc_status_t rtc_compile(const RtcPlugin* R, const char* header, bool fm
         std::string log(ls, '\0');
         if (ls) (void)H->GetProgramLog(prog, &log[0]);
         if (log.size() > 3000) log = log.substr(0, 3000) + "...";
-        set_error("user cost failed to compile (%s):\n%s", H->GetErrorString(r), log.c_str());
+        set_error("run-time compilation failed (%s):\n%s", H->GetErrorString(r), log.c_str());
         (void)H->DestroyProgram(&prog);
         return KABC_ERR_INVALID_ARG;
     }
@@ -190,13 +404,15 @@ static kabc_status_t rtc_compile(const RtcPlugin* R, const char* header, bool fm
             (void)H->GetLoweredName(prog, n.c_str(), &low);
             lowered->push_back(low ? low : "");
         }
+        if (!cpath.empty()) cache_store(cdir, cpath, *code, *lowered);
     }
     (void)H->DestroyProgram(&prog);
     return KABC_OK;
 }
 
-// the kernel `want` of a family; the whole batch `names` is compiled together on a miss
-static void* rtc_kernel(RtcPlugin* R, const char* header, bool fma_c_vgpr,
+// the kernel `want` of a family on the CURRENT device (every entry point selects its context's
+// device before it looks kernels up); the whole batch `names` is compiled together on a miss
+static void* rtc_kernel(RtcCache* R, const std::string& head, const char* header, bool fma_c_vgpr,
                         const std::vector<std::string>& names, const std::string& want) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;  // (no device: the compilation still runs, the load fails)
@@ -206,11 +422,11 @@ static void* rtc_kernel(RtcPlugin* R, const char* header, bool fma_c_vgpr,
     if (it != R->fns.end()) return it->second;
     std::vector<char> code;
     std::vector<std::string> lowered;
-    if (rtc_compile(R, header, fma_c_vgpr, names, &code, &lowered) != KABC_OK) return nullptr;
+    if (rtc_compile(head, header, fma_c_vgpr, names, &code, &lowered) != KABC_OK) return nullptr;
     hipModule_t mod = nullptr;
     const hipError_t e = dev < 0 ? hipErrorNoDevice : hipModuleLoadData(&mod, code.data());
     if (e != hipSuccess) {
-        set_error("the user cost compiled (%zu bytes of gfx950 code for %s), but hipModuleLoadData failed: %s",
+        set_error("the kernels compiled (%zu bytes of gfx950 code for %s), but hipModuleLoadData failed: %s",
                   code.size(), want.c_str(), hipGetErrorString(e));
         return nullptr;
     }
@@ -222,13 +438,76 @@ static void* rtc_kernel(RtcPlugin* R, const char* header, bool fma_c_vgpr,
     }
     it = R->fns.find(pre + want);
     if (it == R->fns.end()) {
-        set_error("kernel %s is missing from the compiled user cost", want.c_str());
+        set_error("kernel %s is missing from the compiled unit", want.c_str());
         return nullptr;
     }
     return it->second;
 }
 
 static constexpr int kPriorClassesRt = 4;  // kPriorClasses of ais_kernels.hpp (static_assert there)
+
+// one kernel family compiled from `head`: `cost` is the COST template argument of the kernels
+// (a built-in DeviceCost id, or KABC_COST_USER when `head` carries a user cost), pk_mask the
+// posterior kinds the AIS kernel may be asked for
+static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int cost, int pk_mask,
+                                      int family, int D, int variant) {
+    PluginKernel k;
+    const std::string d = std::to_string(D), u = std::to_string(cost);
+    const std::string ais_init = "kabc::ais_init_kernel<" + d + ">";
+    auto smc_names = [&](int simple) {
+        const std::string sb = simple ? "true" : "false";
+        return std::vector<std::string>{"kabc::smc_init_kernel<" + d + ">",
+                                        "kabc::smc_mcmc_kernel<" + d + ", " + u + ", " + sb + ">",
+                                        "kabc::smc_loop_kernel<" + d + ", " + u + ", " + sb + ">"};
+    };
+    switch (family) {
+        case kPfAis: {
+            const int pc = variant % kPriorClassesRt, pk = variant / kPriorClassesRt + 1;
+            if (!((pk_mask >> (pk - 1)) & 1) || pc == 3) return k;  // (NORMAL class: the host falls back to SIMPLE)
+            const std::string half = "kabc::ais_half_kernel<" + d + ", " + u + ", " + std::to_string(pc) +
+                                     ", " + std::to_string(pk) + ">";
+            k.mod = rtc_kernel(R, head, "ais_kernels.hpp", true, {half, ais_init}, half);
+            break;
+        }
+        case kPfAisInit: k.mod = rtc_kernel(R, head, "ais_kernels.hpp", true, {ais_init}, ais_init); break;
+        case kPfSmcInit: {
+            // (requested before the pass kernels of the same run: compile for the class it will use)
+            const std::vector<std::string> n = smc_names(variant);
+            k.mod = rtc_kernel(R, head, "smc_loop_kernel.hpp", false, n, n[0]);
+            break;
+        }
+        case kPfSmc: {
+            const std::vector<std::string> n = smc_names(variant);
+            k.mod = rtc_kernel(R, head, "smc_loop_kernel.hpp", false, n, n[1]);
+            break;
+        }
+        case kPfSmcLoop: {
+            const std::vector<std::string> n = smc_names(variant);
+            k.mod = rtc_kernel(R, head, "smc_loop_kernel.hpp", false, n, n[2]);
+            break;
+        }
+        case kPfAbcdeInit:
+        case kPfAbcdeGen: {
+            const std::vector<std::string> n = {"kabc::abcde_init_kernel<" + d + ">",
+                                                "kabc::abcde_gen_kernel<" + d + ">"};
+            k.mod = rtc_kernel(R, head, "abcde_kernels.hpp", false, n, n[family == kPfAbcdeInit ? 0 : 1]);
+            break;
+        }
+        case kPfAttempt: {
+            const std::string n = "kabc::pf_attempt_kernel<" + d + ">";
+            k.mod = rtc_kernel(R, head, "pfilter_kernels.hpp", false, {n}, n);
+            break;
+        }
+        case kPfPriorLogpdf:
+        case kPfPriorRand: {
+            const std::vector<std::string> n = {"kabc::prior_logpdf_kernel", "kabc::prior_rand_kernel"};
+            k.mod = rtc_kernel(R, head, "prior_util_kernels.hpp", false, n, n[family == kPfPriorLogpdf ? 0 : 1]);
+            break;
+        }
+        default: break;
+    }
+    return k;
+}
 
 PluginKernel plugin_kernel(const CostPlugin* p, int family, int D, int variant) {
     PluginKernel k;
@@ -249,55 +528,171 @@ PluginKernel plugin_kernel(const CostPlugin* p, int family, int D, int variant) 
     }
     RtcPlugin* R = p->rtc;
     if (D < 1 || D > KABC_MAX_DIM || !rtc_dim_listed(R, D)) return k;
-    const std::string d = std::to_string(D), u = std::to_string((int)KABC_COST_USER);
-    const std::string ais_init = "kabc::ais_init_kernel<" + d + ">";
-    auto smc_names = [&](int simple) {
-        const std::string sb = simple ? "true" : "false";
-        return std::vector<std::string>{"kabc::smc_init_kernel<" + d + ">",
-                                        "kabc::smc_mcmc_kernel<" + d + ", " + u + ", " + sb + ">",
-                                        "kabc::smc_loop_kernel<" + d + ", " + u + ", " + sb + ">"};
-    };
-    switch (family) {
-        case kPfAis: {
-            const int pc = variant % kPriorClassesRt, pk = variant / kPriorClassesRt + 1;
-            if (!((R->pk_mask >> (pk - 1)) & 1) || pc == 3) return k;  // (NORMAL class: the host falls back to SIMPLE)
-            const std::string half = "kabc::ais_half_kernel<" + d + ", " + u + ", " + std::to_string(pc) +
-                                     ", " + std::to_string(pk) + ">";
-            k.mod = rtc_kernel(R, "ais_kernels.hpp", true, {half, ais_init}, half);
-            break;
-        }
-        case kPfAisInit: k.mod = rtc_kernel(R, "ais_kernels.hpp", true, {ais_init}, ais_init); break;
-        case kPfSmcInit: {
-            // (requested before the pass kernels of the same run: compile for the class it will use)
-            const std::vector<std::string> n = smc_names(variant);
-            k.mod = rtc_kernel(R, "smc_loop_kernel.hpp", false, n, n[0]);
-            break;
-        }
-        case kPfSmc: {
-            const std::vector<std::string> n = smc_names(variant);
-            k.mod = rtc_kernel(R, "smc_loop_kernel.hpp", false, n, n[1]);
-            break;
-        }
-        case kPfSmcLoop: {
-            const std::vector<std::string> n = smc_names(variant);
-            k.mod = rtc_kernel(R, "smc_loop_kernel.hpp", false, n, n[2]);
-            break;
-        }
-        case kPfAbcdeInit:
-        case kPfAbcdeGen: {
-            const std::vector<std::string> n = {"kabc::abcde_init_kernel<" + d + ">",
-                                                "kabc::abcde_gen_kernel<" + d + ">"};
-            k.mod = rtc_kernel(R, "abcde_kernels.hpp", false, n, n[family == kPfAbcdeInit ? 0 : 1]);
-            break;
-        }
-        case kPfAttempt: {
-            const std::string n = "kabc::pf_attempt_kernel<" + d + ">";
-            k.mod = rtc_kernel(R, "pfilter_kernels.hpp", false, {n}, n);
-            break;
-        }
-        default: break;
+    return rtc_family_kernel(R, cost_head(R), (int)KABC_COST_USER, R->pk_mask, family, D, variant);
+}
+
+// ---- model units -----------------------------------------------------------------------------
+struct ModelUnit : RtcCache {
+    std::string head;
+    int cost_tmpl = 0;   // COST template argument
+    int pk_mask = 7;
+    bool spec = false;
+    // a specialisation is found again by exactly its components, D and cost id
+    int cost_id = 0;
+    std::vector<kabc_prior_t> prior;
+    int handle = 0;      // kabc_compile_model registration (0: created by KABC_SPECIALIZE=1)
+    bool released = false;
+};
+static std::map<std::string, ModelUnit*> g_units;  // generic units by key (g_mu)
+static std::vector<ModelUnit*> g_specs;            // specialised units (g_mu)
+
+bool unit_is_spec(const ModelUnit* u) { return u && u->spec; }
+
+static std::vector<int> user_kinds_of(const kabc_prior_t* prior, int D) {
+    std::vector<int> ks;
+    for (int k = 0; k < D; ++k)
+        if (prior[k].kind >= KABC_PRIOR_USER) ks.push_back(prior[k].kind);
+    std::sort(ks.begin(), ks.end());
+    ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+    return ks;
+}
+
+// can (and should) this prior be specialised?  Not a pure box (its kernel class is
+// parameter-free already), not an MvNormal (a device block behind a pointer), D within the
+// register-resident kernels
+static bool spec_eligible(const kabc_prior_t* prior, int D) {
+    if (D < 1 || D > KABC_MAX_DIM) return false;
+    bool allbox = true;
+    for (int k = 0; k < D; ++k) {
+        const int kd = prior[k].kind;
+        if (kd == KABC_PRIOR_MVNORMAL || kd == KABC_PRIOR_USER_INIT) return false;
+        allbox = allbox && (kd == KABC_PRIOR_UNIFORM || kd == KABC_PRIOR_DISCRETE_UNIFORM);
     }
-    return k;
+    return !allbox;
+}
+
+static bool same_prior(const std::vector<kabc_prior_t>& a, const kabc_prior_t* b, int D) {
+    if ((int)a.size() != D) return false;
+    for (int k = 0; k < D; ++k)
+        if (a[(size_t)k].kind != b[k].kind || std::memcmp(a[(size_t)k].p, b[k].p, sizeof b[k].p) != 0) return false;
+    return true;
+}
+
+// the head of a unit for (prior kinds, cost); *cost_tmpl / *pk_mask as rtc_family_kernel wants them
+static kabc_status_t unit_head(const kabc_prior_t* prior, int D, int cost_id, bool spec, std::string* head,
+                               int* cost_tmpl, int* pk_mask) {
+    *cost_tmpl = cost_id;
+    *pk_mask = 7;
+    head->clear();
+    if (cost_id >= KABC_COST_USER) {
+        const CostPlugin* cp = find_plugin(cost_id);
+        if (!cp || !cp->rtc) {
+            set_error("a prior with user families / a specialised model needs its user cost in the hipRTC form "
+                      "(kabc_compile_cost_plugin), not a plugin .so built by hipcc (cost id %d)", cost_id);
+            return KABC_ERR_UNSUPPORTED;
+        }
+        *head += cost_head(cp->rtc);
+        *cost_tmpl = (int)KABC_COST_USER;
+        *pk_mask = cp->rtc->pk_mask;
+    }
+    *head += priors_head(user_kinds_of(prior, D));
+    if (spec) {
+        std::vector<PriorDev> q((size_t)D);
+        for (int k = 0; k < D; ++k)
+            if (!prepare_prior(prior[k], q[(size_t)k])) {
+                set_error("invalid prior (kind/parameters) of component %d", k + 1);
+                return KABC_ERR_INVALID_ARG;
+            }
+        *head += spec_head(q.data(), D);
+    }
+    return KABC_OK;
+}
+
+static bool specialize_env() {
+    const char* e = std::getenv("KABC_SPECIALIZE");
+    return e && *e && *e != '0';
+}
+static bool specialize_off() {
+    const char* e = std::getenv("KABC_SPECIALIZE");
+    return e && *e == '0';
+}
+
+static kabc_status_t make_spec_unit(const kabc_prior_t* prior, int D, int cost_id, int handle, ModelUnit** out) {
+    ModelUnit* u = new ModelUnit();
+    if (kabc_status_t st = unit_head(prior, D, cost_id, true, &u->head, &u->cost_tmpl, &u->pk_mask)) {
+        delete u;
+        return st;
+    }
+    u->spec = true;
+    u->cost_id = cost_id;
+    u->prior.assign(prior, prior + D);
+    u->handle = handle;
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_specs.push_back(u);
+    *out = u;
+    return KABC_OK;
+}
+
+kabc_status_t model_unit_for(const kabc_prior_t* prior, int D, int cost_id, ModelUnit** out, bool allow_spec) {
+    *out = nullptr;
+    if (!prior || D < 1) return KABC_OK;
+    const std::vector<int> uk = user_kinds_of(prior, D);
+    for (int k : uk)
+        if (!find_prior_plugin(k)) {
+            set_error("prior kind %d is not a registered user family (kabc_compile_prior_plugin)", k);
+            return KABC_ERR_INVALID_ARG;
+        }
+    if (!uk.empty() && D > KABC_MAX_DIM) {
+        set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    // 1. a specialisation of exactly this model
+    if (allow_spec && !specialize_off() && spec_eligible(prior, D)) {
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            for (ModelUnit* u : g_specs)
+                if (!u->released && u->cost_id == cost_id && same_prior(u->prior, prior, D)) {
+                    *out = u;
+                    return KABC_OK;
+                }
+        }
+        if (specialize_env() && hiprtc()) {
+            if (make_spec_unit(prior, D, cost_id, 0, out) == KABC_OK) return KABC_OK;
+            if (uk.empty()) return KABC_OK;  // (the prebuilt kernels serve)
+        }
+    }
+    if (uk.empty()) return KABC_OK;
+    // 2. the generic unit of these user families and this cost
+    std::string key = "c" + std::to_string(cost_id) + "|";
+    for (int k : uk) key += std::to_string(k) + ",";
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_units.find(key);
+        if (it != g_units.end()) {
+            *out = it->second;
+            return KABC_OK;
+        }
+    }
+    if (!hiprtc()) {
+        set_error("hipRTC is not available: %sa prior with user families has no prebuilt kernels", g_rtc.why.c_str());
+        return KABC_ERR_DEVICE;
+    }
+    ModelUnit* u = new ModelUnit();
+    if (kabc_status_t st = unit_head(prior, D, cost_id, false, &u->head, &u->cost_tmpl, &u->pk_mask)) {
+        delete u;
+        return st;
+    }
+    u->cost_id = cost_id;
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto ins = g_units.emplace(key, u);
+    if (!ins.second) delete u;
+    *out = ins.first->second;
+    return KABC_OK;
+}
+
+PluginKernel unit_kernel(ModelUnit* u, int family, int D, int variant) {
+    if (!u || D < 1 || D > KABC_MAX_DIM) return PluginKernel();
+    return rtc_family_kernel(u, u->head, u->cost_tmpl, u->pk_mask, family, D, variant);
 }
 
 bool cost_dim_ok_rt(int cost_id, int D) {
@@ -352,7 +747,7 @@ extern "C" kabc_status_t kabc_compile_cost_plugin(const char* src, const int32_t
     }
     // the snippet alone first: its errors come back now, with the compiler's message, not at the
     // first sample() / smc() call
-    if (kabc_status_t st = rtc_compile(R, nullptr, false, {}, nullptr, nullptr)) {
+    if (kabc_status_t st = rtc_compile(cost_head(R), nullptr, false, {}, nullptr, nullptr)) {
         delete R;
         return st;
     }
@@ -425,4 +820,121 @@ extern "C" kabc_status_t kabc_register_cost_plugin(const char* path, int32_t* ou
     g_plugins.push_back(p);
     *out_cost_id = p.id;
     return KABC_OK;
+}
+
+extern "C" kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32_t* out_kind) {
+    if (!src || !out_kind) {
+        set_error("kabc_compile_prior_plugin: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    PriorPlugin* P = new PriorPlugin();
+    P->src = src;
+    P->discrete = discrete ? 1 : 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        // (the same snippet registered again is the same family)
+        for (const PriorPlugin* q : g_prior_plugins)
+            if (q->src == P->src && q->discrete == P->discrete) {
+                *out_kind = q->kind;
+                delete P;
+                return KABC_OK;
+            }
+        P->kind = KABC_PRIOR_USER + (int32_t)g_prior_plugins.size();
+        g_prior_plugins.push_back(P);
+    }
+    // the snippet alone first, with both functions called the way the kernels call them: its
+    // errors come back now, with the compiler's message
+    const std::string sk = std::to_string(P->kind);
+    const std::string check = priors_head({P->kind}) +
+        "extern \"C\" __global__ void kabc_prior_check(double* o, const double* p, const kabc_slotwin_t* w) {\n"
+        "    o[0] = KABC_USER_PRIOR_LOGPDF(" + sk + ", o[1], p, kabc_log_tab);\n"
+        "    o[2] = KABC_USER_PRIOR_RAND(" + sk + ", p, w);\n}\n";
+    if (kabc_status_t st = rtc_compile(check, nullptr, false, {}, nullptr, nullptr)) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        P->src = "#error \"this prior family failed to compile at registration\"\n";  // (the kind stays taken)
+        return st;
+    }
+    *out_kind = P->kind;
+    return KABC_OK;
+}
+
+extern "C" kabc_status_t kabc_compile_model(const kabc_model_t* model, int32_t families, int32_t* out_handle) {
+    if (!model || !model->prior) {
+        set_error("kabc_compile_model: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    const int D = model->D;
+    if (out_handle) *out_handle = 0;
+    if (!spec_eligible(model->prior, D)) return KABC_OK;  // (left to the prebuilt kernels: include/kabc.h)
+    if (!cost_dim_ok_rt(model->cost.id, D)) {
+        set_error("DeviceCost id %d does not accept D = %d", model->cost.id, D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    if (!hiprtc()) {
+        set_error("hipRTC is not available: %sthe prebuilt kernels remain the path", g_rtc.why.c_str());
+        return KABC_ERR_DEVICE;
+    }
+    for (int k : user_kinds_of(model->prior, D))
+        if (!find_prior_plugin(k)) {
+            set_error("prior kind %d is not a registered user family (kabc_compile_prior_plugin)", k);
+            return KABC_ERR_INVALID_ARG;
+        }
+    ModelUnit* u = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (ModelUnit* v : g_specs)
+            if (!v->released && v->cost_id == model->cost.id && same_prior(v->prior, model->prior, D)) u = v;
+    }
+    if (!u) {
+        static int next_handle = 0;
+        int h;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            h = ++next_handle;
+        }
+        if (kabc_status_t st = make_spec_unit(model->prior, D, model->cost.id, h, &u)) return st;
+    }
+    if (out_handle) *out_handle = u->handle;
+    // compile (and, with a device, load) the requested families now
+    if (families == 0) families = KABC_FAMILY_AIS | KABC_FAMILY_SMC;
+    int dev = -1;
+    const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0;
+    bool simple = true;
+    for (int k = 0; k < D; ++k) simple = simple && prior_is_simple(model->prior[k].kind);
+    struct Req { int family, variant; };
+    std::vector<Req> reqs;
+    if (families & KABC_FAMILY_AIS) {
+        const int pk_lo = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 1;
+        const int pk_hi = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 3;
+        for (int pk = pk_lo; pk <= pk_hi; ++pk)
+            if ((u->pk_mask >> (pk - 1)) & 1) reqs.push_back({kPfAis, 2 + kPriorClassesRt * (pk - 1)});
+    }
+    if (families & KABC_FAMILY_SMC) reqs.push_back({kPfSmcLoop, simple ? 1 : 0});
+    if (families & KABC_FAMILY_ABCDE) reqs.push_back({kPfAbcdeGen, 0});
+    if (families & KABC_FAMILY_PFILTER) {
+        reqs.push_back({kPfAbcdeInit, 0});
+        reqs.push_back({kPfAttempt, 0});
+    }
+    for (const Req& r : reqs) {
+        set_error("%s", "");
+        const PluginKernel k = unit_kernel(u, r.family, D, r.variant);
+        if (k.mod) continue;
+        // without a device the code object is in the on-disk cache now; it is loaded at first use
+        if (!have_dev && std::strstr(get_error(), "hipModuleLoadData failed")) continue;
+        if (!get_error()[0]) set_error("kabc_compile_model: kernel family %d is not available for this model", r.family);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    set_error("%s", "");
+    return KABC_OK;
+}
+
+extern "C" kabc_status_t kabc_model_release(int32_t handle) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (ModelUnit* u : g_specs)
+        if (u->handle == handle && handle != 0 && !u->released) {
+            u->released = true;  // (handles that were created on it keep their kernels)
+            return KABC_OK;
+        }
+    set_error("kabc_model_release: %d is not a registered model", handle);
+    return KABC_ERR_INVALID_ARG;
 }

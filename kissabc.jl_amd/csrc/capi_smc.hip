@@ -42,7 +42,11 @@ KABC_DECL_LOOP(9)
 KABC_DECL_LOOP(10)
 KABC_DECL_LOOP(11)
 
-SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple) {
+SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple, ModelUnit* unit) {
+    if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
+        const PluginKernel k = unit_kernel(unit, kPfSmcLoop, D, simple ? 1 : 0);
+        return k.mod ? SmcLoopLaunch(k.mod) : SmcLoopLaunch();
+    }
     switch (cost_id) {
         case 1: return find_smc_loop_kernel_cost_1(D, simple);
         case 2: return find_smc_loop_kernel_cost_2(D, simple);
@@ -64,7 +68,11 @@ SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple) {
     }
 }
 
-SmcLaunch find_smc_kernel(int cost_id, int D, bool simple) {
+SmcLaunch find_smc_kernel(int cost_id, int D, bool simple, ModelUnit* unit) {
+    if (unit) {
+        const PluginKernel k = unit_kernel(unit, kPfSmc, D, simple ? 1 : 0);
+        return k.mod ? SmcLaunch(k.mod, &smc_mcmc_geom, (unsigned)kSmcBlock) : SmcLaunch();
+    }
     switch (cost_id) {
         case 1: return find_smc_kernel_cost_1(D, simple);
         case 2: return find_smc_kernel_cost_2(D, simple);
@@ -284,7 +292,25 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     }
     bool simple = true;
     for (int k = 0; k < D; ++k) simple = simple && prior_is_simple(prior[k].kind);
-    SmcLaunch mcmc = dyn ? SmcLaunch() : find_smc_kernel(cost->id, D, simple);
+    // (run-time compiled kernels are loaded on the CURRENT device)
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    // user prior families among the components, or a specialisation of exactly this model
+    ModelUnit* unit = nullptr;
+    if (!dyn) {
+        if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
+    } else {
+        for (int k = 0; k < D; ++k)
+            if (prior[k].kind >= KABC_PRIOR_USER) {
+                set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
+                return KABC_ERR_UNSUPPORTED;
+            }
+    }
+    SmcLaunch mcmc = dyn ? SmcLaunch() : find_smc_kernel(cost->id, D, simple, unit);
+    if (!mcmc && unit) {
+        if (!unit_is_spec(unit)) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
+        unit = nullptr;                                    // a specialisation that cannot be built
+        mcmc = find_smc_kernel(cost->id, D, simple);
+    }
     SmcDynLaunchFn dyn_fn = nullptr;
     if (dyn) {
         if (cost->id >= KABC_COST_USER) {
@@ -449,7 +475,11 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
             KABC_HIP_CHECK(hipStreamSynchronize(s));  // (c0 is on this stack frame)
         }
         std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
-        if (const CostPlugin* pl = find_plugin(cost->id)) {
+        if (unit) {
+            const PluginKernel k = unit_kernel(unit, kPfSmcInit, D, simple ? 1 : 0);
+            if (!k.mod) return KABC_ERR_DEVICE;
+            SmcInitLaunch(k.mod, &smc_init_geom, (unsigned)kSmcBlock)(a, s);
+        } else if (const CostPlugin* pl = find_plugin(cost->id)) {
             using Fn = void (*)(const SmcInitArgs&, hipStream_t);
             const PluginKernel k = plugin_kernel(pl, kPfSmcInit, D, simple ? 1 : 0);
             if (k.host) SmcInitLaunch((Fn)k.host)(a, s);
@@ -565,7 +595,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         const bool allow = !(env && env[0] == '0') && !tl_smc_no_loop && !comm && !auxW;
         const unsigned G = (unsigned)((N + kLoopBlock - 1) / kLoopBlock);
         SmcLoopLaunch loop_fn =
-            (allow && !dyn && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple) : SmcLoopLaunch();
+            (allow && !dyn && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple, unit) : SmcLoopLaunch();
         if (loop_fn) {
             SmcLoopScratch* lsc;
             KABC_HIP_CHECK(bufs.alloc(&lsc, 1));
@@ -887,7 +917,29 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         set_error("pfilter with length(prior) = %d > %d: built-in DeviceCosts only", D, KABC_MAX_DIM);
         return KABC_ERR_UNSUPPORTED;
     }
-    if (dyn) {
+    // (run-time compiled kernels are loaded on the CURRENT device)
+    KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    ModelUnit* unit = nullptr;
+    for (int k = 0; k < D && dyn; ++k)
+        if (prior[k].kind >= KABC_PRIOR_USER) {
+            set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
+            return KABC_ERR_UNSUPPORTED;
+        }
+    if (!dyn)
+        if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
+    if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
+        const PluginKernel ki = unit_kernel(unit, kPfAbcdeInit, D, 0), ka = unit_kernel(unit, kPfAttempt, D, 0);
+        if (ki.mod && ka.mod) {
+            f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
+            f_att = PfLaunch(ka.mod, &pf_geom, (unsigned)kPfBlock);
+        } else if (!unit_is_spec(unit)) {
+            return KABC_ERR_DEVICE;
+        } else {
+            unit = nullptr;
+        }
+    }
+    if (unit) {
+    } else if (dyn) {
         f_init = AbcdeLaunch(&pf_l_init<0>);
         f_att = PfLaunch(&pf_l_attempt<0>);
     } else if (const CostPlugin* p = find_plugin(cost->id)) {

@@ -122,7 +122,17 @@ __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, d
             const double z = kabc_div_rc(lx - a, b, rb);
             return -(z * z + KABC_LOG_2PI) / 2.0 - c0 - lx;
         }
-        default: return KABC_NAN;
+        default: {
+            // a user family (kabc_compile_prior_plugin): the snippet's kabc_user_prior_logpdf,
+            // compiled into this translation unit in front of the kernels (capi_plugin.hip)
+#ifdef KABC_USER_PRIOR_LOGPDF
+            if (kind >= KABC_PRIOR_USER) {
+                const double pp[4] = {a, b, p2, p3};
+                return KABC_USER_PRIOR_LOGPDF(kind, x, pp, tab);
+            }
+#endif
+            return KABC_NAN;
+        }
     }
 }
 
@@ -180,6 +190,57 @@ inline bool prior_is_simple(int kind) {
            kind == KABC_PRIOR_EXPONENTIAL;
 }
 
+#ifdef KABC_MODEL_SPEC
+// A translation unit generated for ONE model (kabc_compile_model, capi_plugin.hip) defines
+// namespace kabc_mspec { D, KIND[D], DISC[D], P[D][4], C0[D], C1[D], RB[D] } as constexpr data:
+// push_p + logpdf(d::Factored, x) with every component's family and parameters known to the
+// compiler -- the family switch folds away, the parameters are literals instead of LDS records,
+// `(alpha == 1) ? 0 : ...` and the like are decided at compile time.  Same formulas, same
+// operation order (comp_logpdf_general_body itself, inlined D times): same bits.
+constexpr int model_nb_slot(int k) {  // the NegativeBinomial components' lgamma(j + r) tables
+    int slot = 0;
+    for (int j = 0; j < k; ++j) slot += kabc_mspec::KIND[j] == KABC_PRIOR_NEGBINOMIAL ? 1 : 0;
+    return slot;
+}
+template <int D, int NBTABS, int K>
+__device__ __forceinline__ double model_comp(const double* x, double* xp, const double* tab,
+                                             const double* nbtab) {
+    constexpr int kind = kabc_mspec::KIND[K];
+    const double v = kabc_mspec::DISC[K] ? kabc_rint(x[K]) : x[K];
+    xp[K] = v;
+    // p[2] of a NegativeBinomial component is its table slot when the kernel keeps tables
+    constexpr double p2 = (kind == KABC_PRIOR_NEGBINOMIAL)
+                              ? (model_nb_slot(K) < NBTABS ? (double)model_nb_slot(K) : -1.0)
+                              : kabc_mspec::P[K][2];
+    return comp_logpdf_general_body(kind, kabc_mspec::P[K][0], kabc_mspec::P[K][1], p2,
+                                    kabc_mspec::P[K][3], kabc_mspec::C0[K], kabc_mspec::C1[K],
+                                    kabc_mspec::RB[K], v, tab, nbtab);
+}
+// (left to right: ((l0 + l1) + l2) + ..., as src/priors.jl:30-36 sums; a recursive template --
+// hipRTC has no <utility>)
+template <int D, int NBTABS, int K>
+struct ModelSum {
+    static __device__ __forceinline__ double run(const double* x, double* xp, const double* tab,
+                                                 const double* nbtab) {
+        const double s = ModelSum<D, NBTABS, K - 1>::run(x, xp, tab, nbtab);
+        return s + model_comp<D, NBTABS, K>(x, xp, tab, nbtab);
+    }
+};
+template <int D, int NBTABS>
+struct ModelSum<D, NBTABS, 0> {
+    static __device__ __forceinline__ double run(const double* x, double* xp, const double* tab,
+                                                 const double* nbtab) {
+        return model_comp<D, NBTABS, 0>(x, xp, tab, nbtab);
+    }
+};
+template <int D, int NBTABS = 0>
+__device__ __forceinline__ double model_logpdf_push(const double* x, double* xp, const double* tab,
+                                                    const double* nbtab) {
+    static_assert(D == kabc_mspec::D, "this translation unit was generated for another length(prior)");
+    return ModelSum<D, NBTABS, D - 1>::run(x, xp, tab, nbtab);
+}
+#endif
+
 // push_p (src/types.jl:27-32) followed by logpdf(d::Factored, x) = left-to-right
 // sum over components (src/priors.jl:30-36).  xp receives push_p(x).
 // P: the prepared components (in LDS on the hot path).
@@ -191,6 +252,12 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restric
                                                        const double* x, double* xp,
                                                        const double* tab = kabc_log_tab,
                                                        const double* nbtab = nullptr) {
+#ifdef KABC_MODEL_SPEC
+    if constexpr (D == kabc_mspec::D) {
+        (void)P;
+        return model_logpdf_push<D>(x, xp, tab, nullptr);
+    }
+#endif
     double s = 0.0;
     [[maybe_unused]] int kind0 = 0;
 #pragma unroll

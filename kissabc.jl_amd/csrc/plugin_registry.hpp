@@ -31,12 +31,39 @@ bool cost_dim_ok_rt(int cost_id, int D);
 // (hipRTC plugins, compiled at first use -- a family and dimension per compilation, 1-3 s).
 // `variant`: AIS pcx (prior class + kPriorClasses * (posterior kind - 1)); smc: simple prior 0/1.
 enum PluginFamily {
-    kPfAis = 0, kPfAisInit, kPfSmc, kPfSmcInit, kPfSmcLoop, kPfAbcdeInit, kPfAbcdeGen, kPfAttempt
+    kPfAis = 0, kPfAisInit, kPfSmc, kPfSmcInit, kPfSmcLoop, kPfAbcdeInit, kPfAbcdeGen, kPfAttempt,
+    kPfPriorLogpdf, kPfPriorRand  // (model units only: the Factored utility kernels)
 };
 struct PluginKernel {
     void* host = nullptr;
     void* mod = nullptr;
 };
 PluginKernel plugin_kernel(const CostPlugin* p, int family, int D, int variant);
+
+// ---- user prior families + model units (capi_plugin.hip) ------------------------------------
+// is `kind` a registered user family (kabc_compile_prior_plugin)?  *discrete: push_p rounds it
+bool user_prior_info(int kind, int* discrete);
+
+// A MODEL UNIT is the recipe of a run-time compiled translation unit for a (prior, cost) pair:
+//   * the cost's snippet when the cost is a user cost (hipRTC form),
+//   * the snippets of the user prior families among the components,
+//   * for a SPECIALISED unit (kabc_compile_model / KABC_SPECIALIZE=1): the prior tuple itself as
+//     constexpr data (kabc_device.hpp model_logpdf_push),
+// plus the kernels compiled from it so far (per device).  model_unit_for returns, in *out, the
+// unit the pair must run on (a user family among the components: there are no prebuilt kernels)
+// or may run on (a registered specialisation of exactly these components and cost id), or
+// nullptr when the prebuilt kernels serve.  A non-OK status: the pair needs a unit that cannot
+// be built (no hipRTC, a user family with a hipcc-built cost plugin, ...), message set.
+struct ModelUnit;
+}  // namespace kabc
+#include "kabc.h"
+namespace kabc {
+// allow_spec = false: only the unit user families make necessary (the Factored utility kernels)
+kabc_status_t model_unit_for(const kabc_prior_t* prior, int D, int cost_id, ModelUnit** out,
+                             bool allow_spec = true);
+bool unit_is_spec(const ModelUnit* u);
+// AIS variant (pcx): a unit instantiates the GENERAL prior class only (user families are not
+// "simple"; a specialised unit routes that class to the model's own constants)
+PluginKernel unit_kernel(ModelUnit* u, int family, int D, int variant);
 
 }  // namespace kabc

@@ -978,7 +978,8 @@ inline unsigned smc_grid(const Args& a) {
 }
 inline dim3 smc_mcmc_geom(const SmcMcmcArgs& a) { return dim3(smc_grid(a)); }
 inline dim3 smc_init_geom(const SmcInitArgs& a) { return dim3(smc_grid(a)); }
-SmcLaunch find_smc_kernel(int cost_id, int D, bool simple_prior);
+struct ModelUnit;
+SmcLaunch find_smc_kernel(int cost_id, int D, bool simple_prior, ModelUnit* unit = nullptr);
 #endif
 
 }  // namespace kabc

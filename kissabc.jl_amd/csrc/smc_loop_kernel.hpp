@@ -1153,7 +1153,7 @@ struct SmcLoopLaunch {
         return rtc_launch_cooperative(mod, G, (unsigned)kLoopBlock, &a, s);
     }
 };
-SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple_prior);
+SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple_prior, ModelUnit* unit = nullptr);
 
 #endif
 

@@ -63,10 +63,14 @@ class TruncatedNormal(UnivariateDistribution):
 
 
 def Truncated(d, lower, upper):
-    """Truncated(Normal(mu, sigma), lower, upper) as in README.md:40."""
-    if not isinstance(d, Normal):
-        raise TypeError("only Truncated(Normal(...), lo, hi) is on the device path")
-    return TruncatedNormal(d.mu, d.sigma, lower, upper)
+    """Truncated(Normal(mu, sigma), lower, upper) as in README.md:40 (a built-in family);
+    Truncated(Gamma(alpha, theta), lower, upper) is a run-time compiled family (UserPrior)."""
+    if isinstance(d, Normal):
+        return TruncatedNormal(d.mu, d.sigma, lower, upper)
+    if isinstance(d, Gamma):
+        return TruncatedGamma(d.alpha, d.theta, lower, upper)
+    raise TypeError("Truncated(Normal(...), lo, hi) and Truncated(Gamma(...), lo, hi) are on the device "
+                    "path; any other family: write it as a UserPrior snippet")
 
 
 truncated = Truncated
@@ -132,6 +136,209 @@ class LogNormal(UnivariateDistribution):
 
     def params(self):
         return (self.mu, self.sigma)
+
+
+# ---- families compiled at run time ---------------------------------------------------
+USER_PRIOR_SIGNATURE = (
+    "KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab);\n"
+    "KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w);")
+_user_kinds = {}
+
+
+class UserPrior(UnivariateDistribution):
+    """A prior family from a C snippet -- the device-path counterpart of "Factored takes any
+    UnivariateDistribution" (src/priors.jl:11; logpdf :31-33, rand :43, push_p src/types.jl:30-32).
+
+    `source` defines
+
+        KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab);
+        KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w);
+
+    x: the coordinate after push_p (rounded when `discrete`); p: `params` (at most four doubles);
+    -Inf outside the support; tab: what kabc_log_t / kabc_log1p_t / kabc_lgamma_t (kabc_math.h)
+    take.  rand draws from the component's window of the counter stream (kabc_slot(w, j), the
+    helpers of include/kabc_sampling_base.h).  Derived constants (a truncation's log-mass, a
+    normaliser) go into the snippet text as hexadecimal floating literals (`float.hex`): the host
+    computes them once, as Distributions.jl does when the distribution object is built.
+    The snippet is compiled by hipRTC at once (kabc_compile_prior_plugin, include/kabc.h); the
+    kernels of a prior that contains the family are compiled at first use."""
+
+    def __init__(self, source, params=(), discrete=False, name="user_prior"):
+        self.source, self.discrete, self.name = str(source), bool(discrete), name
+        self._params = tuple(float(v) for v in params)
+        if len(self._params) > 4:
+            raise ValueError("a prior component carries at most four parameters (kabc_prior_t.p[4]); "
+                             "put derived constants into the snippet as literals")
+        key = (self.source, self.discrete)
+        kind = _user_kinds.get(key)
+        if kind is None:
+            out = C.c_int32()
+            _lib.check(_lib.load().kabc_compile_prior_plugin(self.source.encode(), int(self.discrete),
+                                                             C.byref(out)))
+            kind = _user_kinds[key] = int(out.value)
+        self.kind = kind
+
+    def params(self):
+        return self._params
+
+    def __repr__(self):
+        return f"{self.name}({', '.join(repr(v) for v in self._params)})"
+
+
+def _hx(v):
+    """a double as a C literal with exactly its bits"""
+    v = float(v)
+    if math.isinf(v):
+        return "(-KABC_INF)" if v < 0 else "KABC_INF"
+    return v.hex()
+
+
+class Poisson(UserPrior):
+    """Poisson(lambda) of Distributions.jl: logpdf = x log(lambda) - lambda - lgamma(x + 1) on the
+    non-negative integers; p = (lambda, log lambda)."""
+    SOURCE = """
+KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab) {
+    if (!(x >= 0.0) || x != kabc_rint(x)) return -KABC_INF;
+    return x * p[1] - p[0] - kabc_lgamma_t(x + 1.0, tab);
+}
+KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
+    return kabc_sample_poisson(w, 0u, p[0]);
+}
+"""
+
+    def __init__(self, lam=1.0):
+        if not lam > 0:
+            raise ValueError("Poisson: lambda must be > 0")
+        self.lam = float(lam)
+        super().__init__(self.SOURCE, (self.lam, math.log(self.lam)), discrete=True, name="Poisson")
+
+    def __repr__(self):
+        return f"Poisson({self.lam!r})"
+
+
+class Laplace(UserPrior):
+    """Laplace(mu, theta): logpdf = -|x - mu| / theta - log(2 theta); p = (mu, theta, 1/theta,
+    log(2 theta)); rand by inversion of the CDF."""
+    SOURCE = """
+KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab) {
+    (void)tab;
+    return -kabc_div_rc(kabc_fabs(x - p[0]), p[1], p[2]) - p[3];
+}
+KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
+    const kabc_u128_t b = kabc_slot(w, 0);
+    const double u = kabc_u01(kabc_lo64(b));            /* (0, 1] */
+    const double e = -p[1] * kabc_log(u);               /* Exponential(theta) */
+    return (kabc_hi64(b) & 1ull) ? p[0] + e : p[0] - e;
+}
+"""
+
+    def __init__(self, mu=0.0, theta=1.0):
+        if not theta > 0:
+            raise ValueError("Laplace: theta must be > 0")
+        self.mu, self.theta = float(mu), float(theta)
+        super().__init__(self.SOURCE, (self.mu, self.theta, 1.0 / self.theta, math.log(2.0 * self.theta)),
+                         name="Laplace")
+
+    def __repr__(self):
+        return f"Laplace({self.mu!r}, {self.theta!r})"
+
+
+def _gamma_p(a, x):
+    """regularised lower incomplete gamma P(a, x) (series / Lentz continued fraction)"""
+    if x <= 0.0:
+        return 0.0
+    if math.isinf(x):
+        return 1.0
+    lg = math.lgamma(a)
+    if x < a + 1.0:
+        term = summ = 1.0 / a
+        n = a
+        for _ in range(10000):
+            n += 1.0
+            term *= x / n
+            summ += term
+            if abs(term) < abs(summ) * 1e-17:
+                break
+        return summ * math.exp(-x + a * math.log(x) - lg)
+    tiny = 1e-300
+    b = x + 1.0 - a
+    c = 1.0 / tiny
+    d = 1.0 / b
+    h = d
+    for i in range(1, 10000):
+        an = -i * (i - a)
+        b += 2.0
+        d = an * d + b
+        d = tiny if abs(d) < tiny else d
+        c = b + an / c
+        c = tiny if abs(c) < tiny else c
+        d = 1.0 / d
+        delta = d * c
+        h *= delta
+        if abs(delta - 1.0) < 1e-16:
+            break
+    return 1.0 - math.exp(-x + a * math.log(x) - lg) * h
+
+
+class TruncatedGamma(UserPrior):
+    """Truncated(Gamma(alpha, theta), lower, upper): the Gamma log-density minus the log-mass of
+    [lower, upper] inside it, -Inf outside; p = (alpha, theta, lower, upper), the normaliser
+    lgamma(alpha) + alpha log(theta) + logtp is a literal of the snippet.  rand: rejection from the
+    parent Gamma over the component's window (Distributions.jl's generic truncated sampler does
+    the same for a window of this mass)."""
+    TEMPLATE = """
+KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab) {
+    if (!(x >= p[2] && x <= p[3]) || !(x >= 0.0)) return -KABC_INF;
+    const double t1 = (p[0] == 1.0) ? 0.0 : (p[0] - 1.0) * kabc_log_t(x, tab);
+    return t1 - kabc_div_rc(x, p[1], %(rtheta)s) - %(norm)s;
+}
+KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
+    /* Marsaglia-Tsang proposals of the parent, two per pair of blocks, until one lands in
+     * [lower, upper]; beyond the window's slots: the nearer end of the interval to the mode */
+    const double a0 = p[0];
+    double boost = 1.0, a = a0;
+    if (a < 1.0) {
+        boost = kabc_exp(kabc_log(kabc_u01(kabc_lo64(kabc_slot(w, KABC_SLOTS_PER_DIM - 1u)))) / a);
+        a += 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / kabc_sqrt(9.0 * d);
+    for (uint32_t j = 0; j + 1u < KABC_SLOTS_PER_DIM - 1u; j += 2u) {
+        const kabc_u128_t bn = kabc_slot(w, j), bu = kabc_slot(w, j + 1u);
+        double z0, z1;
+        kabc_normal_pair(kabc_lo64(bn), kabc_hi64(bn), &z0, &z1);
+        const double us[2] = {kabc_u01(kabc_lo64(bu)), kabc_u01(kabc_hi64(bu))};
+        const double zs[2] = {z0, z1};
+        for (int i = 0; i < 2; ++i) {
+            double v = 1.0 + c * zs[i];
+            if (v <= 0.0) continue;
+            v = v * v * v;
+            if (kabc_log(us[i]) < 0.5 * zs[i] * zs[i] + d - d * v + d * kabc_log(v)) {
+                const double x = d * v * boost * p[1];
+                if (x >= p[2] && x <= p[3]) return x;
+            }
+        }
+    }
+    const double mode = (a0 > 1.0 ? (a0 - 1.0) : 0.0) * p[1];
+    return (kabc_fabs(p[2] - mode) < kabc_fabs(p[3] - mode)) ? p[2] : p[3];
+}
+"""
+
+    def __init__(self, alpha, theta, lower, upper):
+        alpha, theta, lower, upper = map(float, (alpha, theta, lower, upper))
+        if not (alpha > 0 and theta > 0 and upper > lower):
+            raise ValueError("Truncated(Gamma): alpha, theta > 0 and upper > lower")
+        lo = max(lower, 0.0)
+        tp = _gamma_p(alpha, upper / theta) - _gamma_p(alpha, lo / theta)
+        if not tp > 0:
+            raise ValueError("Truncated(Gamma): the interval has no mass")
+        self.alpha, self.theta, self.lower, self.upper = alpha, theta, lower, upper
+        self.logtp = math.log(tp)
+        norm = math.lgamma(alpha) + alpha * math.log(theta) + self.logtp
+        super().__init__(self.TEMPLATE % {"rtheta": _hx(1.0 / theta), "norm": _hx(norm)},
+                         (alpha, theta, lower, upper), name="TruncatedGamma")
+
+    def __repr__(self):
+        return f"Truncated(Gamma({self.alpha!r}, {self.theta!r}), {self.lower!r}, {self.upper!r})"
 
 
 class UserInit(UnivariateDistribution):

@@ -123,6 +123,31 @@ typedef struct prep {
 
 static double std_normal_cdf(double z) { return 0.5 * erfc(-z * M_SQRT1_2); }
 
+/* user prior families (kinds >= KABC_PRIOR_USER; the reference's Factored takes any
+ * UnivariateDistribution, src/priors.jl:11): the same C snippet the device path compiles with
+ * hipRTC (kabc_compile_prior_plugin), compiled with gcc by oracle.py and registered here under
+ * the same kind */
+typedef double (*orc_user_prior_logpdf_fn)(double, const double*, const double*);
+typedef double (*orc_user_prior_rand_fn)(const double*, const kabc_slotwin_t*);
+#define ORC_MAX_USER_PRIORS 256
+static struct {
+    orc_user_prior_logpdf_fn logpdf;
+    orc_user_prior_rand_fn rand;
+    int discrete;
+} g_user_prior[ORC_MAX_USER_PRIORS];
+int32_t orc_register_user_prior(int32_t kind, void* logpdf, void* rnd, int32_t discrete) {
+    if (kind < KABC_PRIOR_USER || kind >= KABC_PRIOR_USER + ORC_MAX_USER_PRIORS || !logpdf || !rnd)
+        return fail(KABC_ERR_INVALID_ARG, "bad user prior kind");
+    g_user_prior[kind - KABC_PRIOR_USER].logpdf = (orc_user_prior_logpdf_fn)logpdf;
+    g_user_prior[kind - KABC_PRIOR_USER].rand = (orc_user_prior_rand_fn)rnd;
+    g_user_prior[kind - KABC_PRIOR_USER].discrete = discrete != 0;
+    return KABC_OK;
+}
+static int user_prior_known(int kind) {
+    return kind >= KABC_PRIOR_USER && kind < KABC_PRIOR_USER + ORC_MAX_USER_PRIORS &&
+           g_user_prior[kind - KABC_PRIOR_USER].logpdf != 0;
+}
+
 /* derived constants of one component; host libm is used for the one-off
  * normalisers (lgamma, erfc), the math contract for everything else */
 static int prepare_prior(const kabc_prior_t* pr, prep_t* q) {
@@ -178,7 +203,11 @@ static int prepare_prior(const kabc_prior_t* pr, prep_t* q) {
             if (!(a > 0) || !(b > 0)) return 0;
             q->c0 = lgamma(a) + a * kabc_log(b);
             return 1;
-        default: return 0;
+        default:
+            if (!user_prior_known(pr->kind)) return 0;
+            q->discrete = g_user_prior[pr->kind - KABC_PRIOR_USER].discrete;
+            q->rb = 0.0;
+            return 1;
     }
 }
 
@@ -221,7 +250,9 @@ static double comp_logpdf(const prep_t* q, double x) {
             double z = kabc_div_rc(lx - a, b, q->rb);
             return -(z * z + KABC_LOG_2PI) / 2.0 - q->c0 - lx;
         }
-        default: return KABC_NAN;
+        default:
+            if (user_prior_known(q->kind)) return g_user_prior[q->kind - KABC_PRIOR_USER].logpdf(x, q->p, kabc_log_tab);
+            return KABC_NAN;
     }
 }
 
@@ -309,7 +340,8 @@ static void factored_rand(const kabc_prior_t* prior, int D, uint64_t seed, uint3
                           uint64_t attempt, uint32_t domain, double* out) {
     for (int k = 0; k < D; ++k) {
         kabc_slotwin_t w = {seed, attempt, walker, domain, (uint32_t)k * KABC_SLOTS_PER_DIM};
-        out[k] = kabc_sample_prior(&prior[k], &w);
+        out[k] = user_prior_known(prior[k].kind) ? g_user_prior[prior[k].kind - KABC_PRIOR_USER].rand(prior[k].p, &w)
+                                                 : kabc_sample_prior(&prior[k], &w);
     }
 }
 

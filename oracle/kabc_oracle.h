@@ -66,6 +66,8 @@ double orc_cost_eval(const kabc_cost_t* cost, int32_t D, const double* x, uint64
 double orc_cdf_g_inv(double u, double a);
 /* register the gcc-compiled twin of a user DeviceCost plugin under its id */
 int32_t orc_register_user_cost(int32_t id, void* fn);
+/* a user prior family (kind >= KABC_PRIOR_USER): logpdf(x, p, tab), rand(p, window) of its snippet */
+int32_t orc_register_user_prior(int32_t kind, void* logpdf, void* rnd, int32_t discrete);
 int32_t orc_register_user_init(int32_t id, void* fn);
 /* MvNormal(mu, Sigma) priors (include/kabc_mvnormal.h): the oracle's registry; the components it is
  * handed are resolved by the caller: p[1] = k, p[2] = bits of orc_mvnormal_block(handle), p[3] = D */

@@ -60,6 +60,7 @@ def load():
             "orc_cdf_g_inv": (C.c_double, [C.c_double, C.c_double]),
             "orc_register_user_cost": (C.c_int32, [C.c_int32, C.c_void_p]),
             "orc_register_user_init": (C.c_int32, [C.c_int32, C.c_void_p]),
+            "orc_register_user_prior": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
             "orc_mvnormal_register": (C.c_int32, [dp, dp, C.c_int32, C.POINTER(C.c_int32)]),
             "orc_mvnormal_block": (C.c_uint64, [C.c_int32]),
             "orc_ais_create": (C.c_int32, [C.POINTER(cd.Model), C.c_int64, C.c_uint64,
@@ -100,10 +101,46 @@ def _dp(a):
     return a.ctypes.data_as(cd.c_double_p)
 
 
+_user_prior_done = set()
+
+
+def register_user_prior(dist):
+    """Compile the C snippet of a kissabc_jl_amd.distributions.UserPrior with gcc and register it
+    with the oracle under the same kind, so that the oracle evaluates the same family."""
+    import hashlib
+    if dist.kind in _user_prior_done:
+        return
+    text = ('#include "kabc_sampling_base.h"\n' + dist.source +
+            "\ndouble orc_user_prior_logpdf_entry(double x, const double* p, const double* tab) {\n"
+            "    return kabc_user_prior_logpdf(x, p, tab);\n}\n"
+            "double orc_user_prior_rand_entry(const double* p, const kabc_slotwin_t* w) {\n"
+            "    return kabc_user_prior_rand(p, w);\n}\n")
+    tag = hashlib.sha1(text.encode()).hexdigest()[:16]
+    bdir = os.path.join(_HERE, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    so = os.path.join(bdir, f"libuserprior_{tag}.so")
+    if not os.path.exists(so):
+        src = os.path.join(bdir, f"userprior_{tag}.c")
+        with open(src, "w") as f:
+            f.write(text)
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-ffp-contract=off", "-mfma",
+                               "-I", os.path.join(os.path.dirname(_HERE), "include"), "-shared",
+                               "-o", so, src, "-lm"])
+    lib = _user_libs.get(so) or C.CDLL(so)
+    _user_libs[so] = lib
+    _check(load().orc_register_user_prior(dist.kind, C.cast(lib.orc_user_prior_logpdf_entry, C.c_void_p),
+                                          C.cast(lib.orc_user_prior_rand_entry, C.c_void_p),
+                                          int(dist.discrete)))
+    _user_prior_done.add(dist.kind)
+
+
 def _prior_c(fac):
     """kabc_prior_t[D] for the ORACLE: a full-covariance MvNormal is registered with the oracle's
     own registry and handed over resolved (p[1] = k, p[2] = the block's address as a double's
     bits, p[3] = D; include/kabc_mvnormal.h) -- the library resolves its own handles itself."""
+    for c in fac.p:   # user families: the oracle gets the same snippet, compiled for the host
+        if hasattr(c, "source") and c.kind >= cd.PRIOR_USER:
+            register_user_prior(c)
     if getattr(fac, "cov", None) is None:
         return fac.to_c()
     L = load()
@@ -121,6 +158,7 @@ def _prior_c(fac):
 
 def _model_c(model):
     m = model.to_c()
+    _prior_c(model.prior)   # (registers user families with the oracle)
     if getattr(model.prior, "cov", None) is not None:
         model._prior_c_oracle = _prior_c(model.prior)
         m.prior = C.cast(model._prior_c_oracle, C.POINTER(cd.Prior))

@@ -7,8 +7,8 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def load_prior_golden():
-    with open(os.path.join(GOLDEN, "priors_logpdf.json")) as f:
+def load_prior_golden(name="priors_logpdf.json"):
+    with open(os.path.join(GOLDEN, name)) as f:
         data = json.load(f)
     for c in data["cases"]:
         c["logpdf"] = np.array([(-np.inf if v == "-inf" else np.inf if v == "inf" else v)
@@ -23,6 +23,8 @@ def make_dist(k, kind, params):
         "Beta": k.Beta, "DiscreteUniform": k.DiscreteUniform,
         "NegativeBinomial": k.NegativeBinomial, "Exponential": k.Exponential,
         "Gamma": k.Gamma, "LogNormal": k.LogNormal,
+        # run-time compiled families (kabc_compile_prior_plugin)
+        "Poisson": k.Poisson, "Laplace": k.Laplace, "TruncatedGamma": k.TruncatedGamma,
     }[kind](*params)
 
 
