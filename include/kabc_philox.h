@@ -24,6 +24,15 @@ typedef struct kabc_u128 {
     uint32_t w[4];
 } kabc_u128_t;
 
+/* Rounds of the Philox4x32 bijection: part of the stream contract (device kernels and the CPU
+ * oracle compile the same value).  10 = the Random123 default (Philox4x32-10); 7 is the smallest
+ * count the Random123 paper reports as passing BigCrush ("Crush-resistant"), 30 % fewer
+ * instructions per block.  tests/test_math_contract.py pins both against an independent
+ * restatement of the round function. */
+#ifndef KABC_PHILOX_ROUNDS
+#define KABC_PHILOX_ROUNDS 10
+#endif
+
 #define KABC_PHILOX_M0 0xD2511F53u
 #define KABC_PHILOX_M1 0xCD9E8D57u
 #define KABC_PHILOX_W0 0x9E3779B9u
@@ -61,7 +70,7 @@ KABC_HD kabc_u128_t kabc_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, ui
 #if defined(__clang__)
 #pragma unroll
 #endif
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < KABC_PHILOX_ROUNDS; ++r) {
         uint64_t p0 = (uint64_t)KABC_PHILOX_M0 * (uint64_t)c0;
         uint64_t p1 = (uint64_t)KABC_PHILOX_M1 * (uint64_t)c2;
         uint32_t n0 = kabc_xor3((uint32_t)(p1 >> 32), c1, k0);
@@ -124,6 +133,9 @@ typedef struct kabc_cost_rng {
      * cost_pre_blocks).  Compiled into the translation units that define KABC_RNG_PREFETCH. */
     const double* pre;
     uint32_t pre_n;
+    /* distance between consecutive words of `pre` (1: a per-thread array; the batch size: one
+     * lane's column of an SoA block in LDS).  Whoever sets `pre` sets it. */
+    uint32_t pre_stride;
 #endif
 } kabc_cost_rng_t;
 
@@ -142,8 +154,8 @@ KABC_HD kabc_u128_t kabc_cost_rng_next(kabc_cost_rng_t* g) {
 KABC_HD void kabc_cost_rng_normal2(kabc_cost_rng_t* g, double* z0, double* z1) {
 #ifdef KABC_RNG_PREFETCH
     if (g->pre && g->slot < g->pre_n) {
-        *z0 = g->pre[2u * g->slot];
-        *z1 = g->pre[2u * g->slot + 1u];
+        *z0 = g->pre[(2u * g->slot) * g->pre_stride];
+        *z1 = g->pre[(2u * g->slot + 1u) * g->pre_stride];
         g->slot++;
         return;
     }

@@ -56,6 +56,13 @@ struct AisArgs {
     int32_t dbg_nt, dbg_s0;
 };
 
+// leading normal-pair blocks of the cost's stream that the AIS producers expand (0: none).  Bounded
+// by LDS: two buffers of kChunk sub-steps x 2 NPRE x 64 doubles beside the records.
+constexpr int ais_pre_blocks(int cost, int D) {
+    const int n = cost >= KABC_COST_USER ? 0 : cost_pre_blocks(cost, D);
+    return n <= 8 ? n : 0;
+}
+
 constexpr int kLateFrom = 10;  // D above this: the consumer keeps ONE set of partner-row registers
 constexpr int kCounterSlots = 1024;  // one 64-byte line per workgroup (mod 1024)
 
@@ -489,6 +496,22 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t
     }
 }
 
+// The leading normal pairs of a stochastic cost's stream (cost_pre_blocks), expanded by a producer
+// wave for the 64 walkers of the batch: block j of walker `lane` -> pre[2 j][lane], pre[2 j + 1][lane]
+// (what kabc_cost_rng_normal2 would compute in place: include/kabc_philox.h)
+template <int NPRE>
+__device__ __forceinline__ void produce_cost_normals(uint64_t seed, uint64_t t, uint32_t w_base, int lane,
+                                                     double (*pre)[kBatch], const double* logtab) {
+#pragma unroll 1
+    for (int j = 0; j < NPRE; ++j) {
+        const kabc_u128_t b = kabc_stream_block(seed, w_base + (uint32_t)lane, t, (uint32_t)j, KABC_DOM_AIS_COST);
+        double z0, z1;
+        kabc_normal_pair_tab(kabc_lo64(b), kabc_hi64(b), &z0, &z1, logtab);
+        pre[2 * j][lane] = z0;
+        pre[2 * j + 1][lane] = z1;
+    }
+}
+
 // producer side of a prepared cost: lane = walker of the batch, the same sequential
 // arithmetic kabc_cost_eval would do in place (include/kabc_costs.h)
 template <int COST, int W>
@@ -549,6 +572,16 @@ ais_half_kernel(const AisArgs A0) {
     // of every sub-step, computed by the producers; word j of lane l at [buf][si][j][l]
     constexpr int kAuxW = cost_aux_c(COST);
     __shared__ double saux[2][kChunk][kAuxW > 0 ? kAuxW : 1][kBatch];
+    // stochastic costs whose stream STARTS with normal pairs whatever the parameters
+    // (cost_pre_blocks: the hierarchical simulator's D - 2 group noises, ...): the producers
+    // expand those blocks for the sub-steps ahead -- all 64 lanes busy, three waves sharing the
+    // work -- and the consumer, the serial part of the chain, reads the variates from LDS
+    // instead of running Philox + Box-Muller itself (C4's prior + simulator under AIS: the
+    // consumer did 7 blocks per transition, more than all the rest of its sub-step).  The draws
+    // are counter-based, so expanding them early (or for a proposal the prior then rejects)
+    // changes nothing.
+    constexpr int kPre = ais_pre_blocks(COST, D);
+    __shared__ double spre[2][kChunk][kPre > 0 ? 2 * kPre : 1][kBatch];
 
     // (wave index as a scalar: role branches and record addresses are wave-uniform)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & (kWave - 1);
@@ -682,6 +715,8 @@ ais_half_kernel(const AisArgs A0) {
             if constexpr (kAuxW > 0)
                 prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)si, w_base, lane, saux[0][si],
                                               slogtab, r0, n_active);
+            if constexpr (kPre > 0)
+                produce_cost_normals<kPre>(seed_v, A.t0 + (uint64_t)si, w_base, lane, spre[0][si], slogtab);
         }
     }
     KABC_TIMED_BARRIER();
@@ -704,6 +739,9 @@ ais_half_kernel(const AisArgs A0) {
                 if constexpr (kAuxW > 0)
                     prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)s, w_base, lane,
                                                   saux[(c + 1) & 1][si], slogtab, r0, n_active);
+                if constexpr (kPre > 0)
+                    produce_cost_normals<kPre>(seed_v, A.t0 + (uint64_t)s, w_base, lane,
+                                               spre[(c + 1) & 1][si], slogtab);
             }
             KABC_TIMED_BARRIER();
         }
@@ -808,6 +846,11 @@ ais_half_kernel(const AisArgs A0) {
                     if constexpr (kAuxW > 0) {
                         rng.aux = &saux[(KABL & 2) ? 0 : (c & 1)][si][0][lane];
                         rng.aux_stride = kBatch;
+                    }
+                    if constexpr (kPre > 0) {
+                        rng.pre = &spre[(KABL & 2) ? 0 : (c & 1)][si][0][lane];
+                        rng.pre_n = (uint32_t)kPre;
+                        rng.pre_stride = (uint32_t)kBatch;
                     }
                     double nlp, nll;
                     bool ev;

@@ -1040,6 +1040,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                     if constexpr (kPre > 0) {
                         rng.pre = nx_pre;
                         rng.pre_n = (uint32_t)kPre;
+                        rng.pre_stride = 1u;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     KABC_LSTAMP(17)

@@ -28,10 +28,10 @@ static int32_t fail(int32_t code, const char* msg) {
 /* ------------------------------------------------------------------------- */
 /* independent Philox4x32-10 restatement (Salmon et al. SC'11, Fig. 2)        */
 /* ------------------------------------------------------------------------- */
-void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+void orc_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], int32_t rounds, uint32_t out[4]) {
     uint32_t x0 = ctr[0], x1 = ctr[1], x2 = ctr[2], x3 = ctr[3];
     uint32_t k0 = key[0], k1 = key[1];
-    for (int round = 0; round < 10; ++round) {
+    for (int round = 0; round < rounds; ++round) {
         if (round > 0) {
             k0 += 0x9E3779B9u;
             k1 += 0xBB67AE85u;
@@ -53,6 +53,12 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
     out[3] = x3;
 }
 
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    orc_philox4x32_r(ctr, key, 10, out);
+}
+/* the round count the stream contract was compiled with (include/kabc_philox.h) */
+int32_t orc_philox_rounds(void) { return KABC_PHILOX_ROUNDS; }
+
 typedef struct blk {
     uint64_t lo, hi;
     uint32_t w[4];
@@ -63,7 +69,7 @@ static blk_t stream(uint64_t seed, uint32_t walker, uint64_t t, uint32_t slot, u
     uint32_t ctr[4] = {walker, (uint32_t)t, slot, domain | ((uint32_t)(t >> 32) << 8)};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     blk_t b;
-    orc_philox4x32_10(ctr, key, b.w);
+    orc_philox4x32_r(ctr, key, KABC_PHILOX_ROUNDS, b.w);
     b.lo = ((uint64_t)b.w[1] << 32) | b.w[0];
     b.hi = ((uint64_t)b.w[3] << 32) | b.w[2];
     return b;

@@ -47,6 +47,8 @@ const char* orc_last_error(void);
 
 /* independent Philox4x32-10 (not the one in include/kabc_philox.h) */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_philox4x32_r(const uint32_t ctr[4], const uint32_t key[2], int32_t rounds, uint32_t out[4]);
+int32_t orc_philox_rounds(void);
 
 /* math-contract probes (vectorised wrappers over include/kabc_math.h) */
 void orc_math_vec(int32_t fn, int64_t n, const double* x, double* out);

@@ -47,6 +47,9 @@ def load():
             "orc_last_error": (C.c_char_p, []),
             "orc_philox4x32_10": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint32)]),
+            "orc_philox4x32_r": (None, [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_int32,
+                                        C.POINTER(C.c_uint32)]),
+            "orc_philox_rounds": (C.c_int32, []),
             "orc_math_vec": (None, [C.c_int32, C.c_int64, dp, dp]),
             "orc_normal_pairs": (None, [C.c_int64, C.POINTER(C.c_uint64), dp]),
             "orc_div_rc_vec": (None, [C.c_int64, dp, dp, dp]),
@@ -191,12 +194,16 @@ def div_rc(x, c):
     return out
 
 
-def philox(ctr, key):
+def philox(ctr, key, rounds=10):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)
     o = (C.c_uint32 * 4)()
-    load().orc_philox4x32_10(c, k, o)
+    load().orc_philox4x32_r(c, k, rounds, o)
     return list(o)
+
+
+def philox_rounds():
+    return load().orc_philox_rounds()
 
 
 def normal_pairs(r):

@@ -21,6 +21,34 @@ def test_philox_kat_oracle_restatement(orc):
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
 
 
+def _philox_py(ctr, key, rounds):
+    """Philox4x32-R written a third time, from the published round function (Salmon et al. SC'11):
+    multiply two counter words by the two constants, swap / xor with the round key, bump the key."""
+    x, kk = list(ctr), list(key)
+    M0, M1, W0, W1, mask = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xffffffff
+    for r in range(rounds):
+        if r:
+            kk = [(kk[0] + W0) & mask, (kk[1] + W1) & mask]
+        p0, p1 = M0 * x[0], M1 * x[2]
+        x = [(p1 >> 32) ^ x[1] ^ kk[0], p1 & mask, (p0 >> 32) ^ x[3] ^ kk[1], p0 & mask]
+    return x
+
+
+def test_philox_round_count_is_a_contract_parameter(orc):
+    """KABC_PHILOX_ROUNDS (include/kabc_philox.h): the Python restatement reproduces the
+    Random123 10-round vectors, and agrees with the C restatement at 7 and 10 rounds on random
+    inputs -- so a build with 7 rounds is pinned as firmly as the default."""
+    assert _philox_py([0] * 4, [0] * 2, 10) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert _philox_py([0xffffffff] * 4, [0xffffffff] * 2, 10) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    r = np.random.default_rng(3)
+    for _ in range(200):
+        c = [int(v) for v in r.integers(0, 2 ** 32, 4)]
+        kk = [int(v) for v in r.integers(0, 2 ** 32, 2)]
+        for R in (7, 10):
+            assert orc.philox(c, kk, R) == _philox_py(c, kk, R)
+    assert orc.philox_rounds() in (7, 10)
+
+
 def test_philox_shared_header_matches_restatement(orc, k):
     """kabc_philox.h (used by costs/sampling on host AND device) vs the oracle's
     independent Philox: a Uniform(0,1) prior draw is u01(lo64(block))."""
@@ -32,7 +60,7 @@ def test_philox_shared_header_matches_restatement(orc, k):
     for i in range(n):
         for dim in range(2):
             w = orc.philox([5 + i, 3, dim * 128, cd.DOM_SMC_INIT],
-                           [seed & 0xffffffff, seed >> 32])
+                           [seed & 0xffffffff, seed >> 32], orc.philox_rounds())
             lo = (w[1] << 32) | w[0]
             u = ((lo >> 12) + 0.5) * 2.0 ** -52
             assert draws[i, dim] == u
