@@ -60,7 +60,7 @@ KABC_HD double kabc_cost_gauss_dist(const double* x, int D, const double* params
         double d = x[k] - params[k];
         s += d * d;
     }
-    return kabc_sqrt(s);
+    return kabc_sqrt_dist(s);
 }
 
 KABC_HD double kabc_cost_rosenbrock(const double* x, int D) {
@@ -227,7 +227,7 @@ KABC_HD double kabc_cost_abs_diff(const double* x, const double* params) {
 KABC_HD double kabc_cost_norm_shell(const double* x, int D, const double* params) {
     double s = 0.0;
     for (int k = 0; k < D; ++k) s += x[k] * x[k];
-    return kabc_fabs(kabc_sqrt(s) - params[0]);
+    return kabc_fabs(kabc_sqrt_dist(s) - params[0]);
 }
 
 KABC_HD double kabc_cost_noisy_quad_du(const double* x, const double* params,

@@ -158,7 +158,7 @@ __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
 enum { kPriorBox = 0, kPriorSimple = 1, kPriorGeneral = 2, kPriorNormal = 3 };
 constexpr int kPriorClasses = 4;
 // GENERAL class: NegativeBinomial components whose lgamma(k + r) is tabulated per launch in LDS
-constexpr int kNbTabsGeneral = 2;
+constexpr int kNbTabsGeneral = kNbLg1Block;
 
 struct BoxPrior {
     const double* lo;   // LDS, [D]
@@ -567,7 +567,7 @@ ais_half_kernel(const AisArgs A0) {
     // components -- kabc_lgamma_t's own values, computed once per launch by the whole workgroup
     // instead of once per transition by the consumer (kabc_device.hpp, the family's case)
     constexpr int kNbTabs = (PC == kPriorGeneral) ? kNbTabsGeneral : 0;
-    __shared__ double snb[kNbTabs > 0 ? kNbTabs * kNbEntries : 1];
+    __shared__ double snb[kNbTabs > 0 ? (kNbTabs + 1) * kNbEntries : 1];  // (+ the lgamma(k + 1) block)
     // prepared costs (include/kabc_costs.h): the parameter-independent part of the cost
     // of every sub-step, computed by the producers; word j of lane l at [buf][si][j][l]
     constexpr int kAuxW = cost_aux_c(COST);
@@ -669,16 +669,20 @@ ais_half_kernel(const AisArgs A0) {
     [[maybe_unused]] const bool nb_on = kNbTabs > 0 && A.nt >= 8;
     if constexpr (kNbTabs > 0) {
         static_assert(kNbEntries == kAisBlock, "one table entry per thread");
-        if (nb_on) {
-            int slot = 0;
-            for (int k = 0; k < D && slot < kNbTabs; ++k) {  // (wave-uniform)
-                if (A.prior[k].kind == KABC_PRIOR_NEGBINOMIAL) {
+        int slot = 0;
+        bool has_nb = false;
+        for (int k = 0; k < D; ++k) {  // (wave-uniform)
+            if (A.prior[k].kind == KABC_PRIOR_NEGBINOMIAL) {
+                has_nb = true;
+                if (nb_on && slot < kNbTabs) {
                     snb[slot * kNbEntries + threadIdx.x] =
                         kabc_lgamma_t((double)threadIdx.x + A.prior[k].p[0], kabc_log_tab);
                     ++slot;
                 }
             }
         }
+        // the lgamma(k + 1) block: always there for a prior with such a component (one load per thread)
+        if (has_nb) snb[kNbLg1Block * kNbEntries + threadIdx.x] = kabc_lgamma1_tab[threadIdx.x];
     }
     KABC_TIMED_BARRIER();
     if constexpr (kNbTabs > 0) {

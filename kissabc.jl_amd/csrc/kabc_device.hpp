@@ -71,6 +71,9 @@ __device__ __forceinline__ bool wave_none(bool c) { return __builtin_amdgcn_ball
 
 // entries of a per-component lgamma(k + r) table (NegativeBinomial, see the family's case below)
 constexpr int kNbEntries = 256;
+// blocks of a kernel's NegativeBinomial tables: [0, kNbLg1Block) lgamma(k + r) of the first
+// components, block kNbLg1Block the copy of kabc_lgamma1_tab (lgamma(k + 1))
+constexpr int kNbLg1Block = 2;
 // tab: kabc_log_tab or the kernel's LDS copy of it (same values; the global table is a dependent
 // L2 round trip per log on the consumer's chain)
 __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, double b, double p2,
@@ -120,15 +123,31 @@ __device__ __forceinline__ double comp_logpdf_general_body(int kind, double a, d
             // lgamma(x + r): the AIS kernel tabulates it per NegativeBinomial component for the
             // launch (kNbEntries values of kabc_lgamma_t itself in LDS, ais_kernels.hpp); p2 is
             // then the component's table slot (a field the family does not use), else < 0 / no table
-            double lga;
-            if (nbtab != nullptr && p2 >= 0.0) {  // (wave-uniform)
-                const bool in = (x >= 0.0) && (x < (double)kNbEntries);
-                lga = nbtab[(int)p2 * kNbEntries + (in ? (int)x : 0)];
-                if (x >= (double)kNbEntries) lga = kabc_lgamma_t(x + a, tab);
+            // With tables (nbtab != NULL) lgamma(x + 1) comes from their last block too: the
+            // kernel's LDS copy of kabc_lgamma1_tab -- the table in global memory is a dependent
+            // L2 round trip per transition on the consumer's chain, and its wait also drains
+            // the partner-row prefetch of the next sub-step.
+            const bool in = (x >= 0.0) && (x < (double)kNbEntries);
+            const int ix = in ? (int)x : 0;
+            double lga, lg1;
+            if (nbtab != nullptr) {  // (wave-uniform)
+                static_assert(kNbEntries == KABC_LGAMMA1_N, "one index serves both tables");
+                lg1 = nbtab[kNbLg1Block * kNbEntries + ix];
+                if (p2 >= 0.0) {     // (wave-uniform)
+                    lga = nbtab[(int)p2 * kNbEntries + ix];
+                    if (x >= (double)kNbEntries) {
+                        lga = kabc_lgamma_t(x + a, tab);
+                        lg1 = kabc_lgamma_t(x + 1.0, tab);
+                    }
+                } else {
+                    lga = kabc_lgamma_t(x + a, tab);
+                    if (x >= (double)kNbEntries) lg1 = kabc_lgamma_t(x + 1.0, tab);
+                }
             } else {
                 lga = kabc_lgamma_t(x + a, tab);
+                lg1 = kabc_lgamma1p_int_t(x, tab);
             }
-            return c0 + x * c1 + lga - kabc_lgamma1p_int_t(x, tab);
+            return c0 + x * c1 + lga - lg1;
         }
         case KABC_PRIOR_EXPONENTIAL: return (x >= 0.0) ? -c0 - kabc_div_rc(x, a, rb) : -KABC_INF;
         case KABC_PRIOR_GAMMA: {
