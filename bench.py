@@ -94,11 +94,13 @@ def prior_class_problems(k):
     socks = k.Factored(k.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), k.Beta(15, 2))
     hier = k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 14)
     ybar = np.random.default_rng(1).normal(size=14)
+    four = k.Factored(k.Gamma(2.5, 0.7), k.LogNormal(0.3, 0.6), k.Beta(2, 3), k.Normal(0, 1))
     return [
         ("normal8_gauss_dist", k.ApproxKernelizedPosterior(
             k.Factored(*[k.Normal(0, 5)] * 8), k.costs.GaussDist(np.zeros(8)), 1.0), 65536, 8),
         ("socks_negbin_beta", k.ApproxKernelizedPosterior(socks, k.costs.GaussDist([40.0, 0.8]), 3.0),
          65536, 2),
+        ("four_family_d4", k.ApproxKernelizedPosterior(four, k.costs.NormShell(2.0), 0.5), 65536, 4),
         ("c4_hier_prior_sim", k.ApproxKernelizedPosterior(hier, k.costs.HierGaussSim(ybar), 0.3),
          32768, 16),
     ]
@@ -381,8 +383,28 @@ def main():
                                     "one wavefront's chain of dependent transitions, not by throughput")
         if cpu and isinstance(cpu.get("c2"), dict) and "value" in cpu["c2"]:
             extra["c2"]["cpu_baseline"] = cpu["c2"]
-        extra["by_prior_class"] = {
-            name: dict(kernel_leg(m, Nm, Dm), N=Nm, D=Dm) for name, m, Nm, Dm in prior_class_problems(k)}
+        # Each class on the prebuilt kernels and on the kernels specialised for the model
+        # (kabc_compile_model: the prior tuple's families and parameters as compile-time constants
+        # of a translation unit compiled by hipRTC at run time, cached on disk; same bits).
+        # `roofline_frac` etc. at the top level of a class are the specialised kernel's -- the path
+        # a user of compile_model(model) gets; `prebuilt` holds the other one.
+        bpc = {}
+        for name, m, Nm, Dm in prior_class_problems(k):
+            pre = kernel_leg(m, Nm, Dm)
+            entry = dict(pre, N=Nm, D=Dm, kernel="prebuilt")
+            try:
+                t0 = time.perf_counter()
+                hdl = k.compile_model(m, families=1)
+                t_compile = time.perf_counter() - t0
+                if hdl:
+                    spec = kernel_leg(m, Nm, Dm)
+                    k._lib.check(k._lib.load().kabc_model_release(hdl))
+                    entry = dict(spec, N=Nm, D=Dm, kernel="specialised (kabc_compile_model)",
+                                 compile_or_cache_load_s=t_compile, prebuilt=pre)
+            except Exception as e:   # hipRTC missing: the prebuilt kernels remain the path
+                entry["specialise_error"] = repr(e)
+            bpc[name] = entry
+        extra["by_prior_class"] = bpc
 
     smc = None
     if world == 1 and not args.no_smc:

@@ -132,6 +132,11 @@ int32_t kabc_version(void);
  * 9 kabc_pfilter_opts_t, 10 kabc_pfilter_result_t; -1 beyond.  A binding that mirrors the
  * structs by hand (ctypes, Julia `struct`) checks itself against this at load time. */
 int32_t kabc_abi_sizeof(int32_t which);
+/* offsetof() of the field-th member (declaration order, from 0) of the which-th struct (the
+ * numbering of kabc_abi_sizeof) as the library was compiled; -1 beyond.  Together with
+ * kabc_abi_sizeof this pins a hand-written mirror field by field (tests/test_julia_shim_static.py
+ * checks julia/KissABCHip.jl and kissabc.jl_amd/_cdefs.py against it). */
+int32_t kabc_abi_offsetof(int32_t which, int32_t field);
 const char* kabc_last_error(void);
 /* number of visible gfx950 devices (0 when none; never an error) */
 int32_t kabc_device_count(void);

@@ -106,6 +106,7 @@ VP = C.c_void_p
 PROTOTYPES = {
     "kabc_version": (C.c_int32, []),
     "kabc_abi_sizeof": (C.c_int32, [C.c_int32]),
+    "kabc_abi_offsetof": (C.c_int32, [C.c_int32, C.c_int32]),
     "kabc_mvnormal_register": (C.c_int, [c_double_p, c_double_p, C.c_int32, C.POINTER(C.c_int32)]),
     "kabc_last_error": (C.c_char_p, []),
     "kabc_device_count": (C.c_int32, []),

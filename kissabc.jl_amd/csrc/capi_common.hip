@@ -1,5 +1,6 @@
 // capi_common.hip -- context, error plumbing, prior preparation and the small
 // Factored utility kernels (logpdf / rand) of the C ABI (include/kabc.h).
+#include <cstddef>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -204,6 +205,46 @@ int32_t kabc_abi_sizeof(int32_t which) {
         (int32_t)sizeof(kabc_abcde_result_t), (int32_t)sizeof(kabc_pfilter_opts_t),
         (int32_t)sizeof(kabc_pfilter_result_t)};
     return (which >= 0 && which < (int32_t)(sizeof sz / sizeof sz[0])) ? sz[which] : -1;
+}
+int32_t kabc_abi_offsetof(int32_t which, int32_t field) {
+#define KABC_OFF(T, f) (int32_t)offsetof(T, f)
+    static const std::vector<std::vector<int32_t>> off = {
+        {KABC_OFF(kabc_prior_t, kind), KABC_OFF(kabc_prior_t, reserved), KABC_OFF(kabc_prior_t, p)},
+        {KABC_OFF(kabc_cost_t, id), KABC_OFF(kabc_cost_t, nparams), KABC_OFF(kabc_cost_t, params),
+         KABC_OFF(kabc_cost_t, ndata), KABC_OFF(kabc_cost_t, data)},
+        {KABC_OFF(kabc_model_t, prior), KABC_OFF(kabc_model_t, D), KABC_OFF(kabc_model_t, posterior),
+         KABC_OFF(kabc_model_t, eps), KABC_OFF(kabc_model_t, cost)},
+        {KABC_OFF(kabc_stats_t, proposals), KABC_OFF(kabc_stats_t, cost_evals), KABC_OFF(kabc_stats_t, accepted)},
+        {KABC_OFF(kabc_smc_opts_t, nparticles), KABC_OFF(kabc_smc_opts_t, alpha), KABC_OFF(kabc_smc_opts_t, mcmc_retrys),
+         KABC_OFF(kabc_smc_opts_t, verbose), KABC_OFF(kabc_smc_opts_t, mcmc_tol), KABC_OFF(kabc_smc_opts_t, epstol),
+         KABC_OFF(kabc_smc_opts_t, r_epstol), KABC_OFF(kabc_smc_opts_t, min_r_ess), KABC_OFF(kabc_smc_opts_t, max_stretch),
+         KABC_OFF(kabc_smc_opts_t, seed), KABC_OFF(kabc_smc_opts_t, max_iterations)},
+        {KABC_OFF(kabc_smc_iter_t, eps), KABC_OFF(kabc_smc_iter_t, ess), KABC_OFF(kabc_smc_iter_t, accepted),
+         KABC_OFF(kabc_smc_iter_t, resampled), KABC_OFF(kabc_smc_iter_t, flag), KABC_OFF(kabc_smc_iter_t, mcmc_passes),
+         KABC_OFF(kabc_smc_iter_t, reserved)},
+        {KABC_OFF(kabc_smc_result_t, theta), KABC_OFF(kabc_smc_result_t, cost), KABC_OFF(kabc_smc_result_t, alive),
+         KABC_OFF(kabc_smc_result_t, eps), KABC_OFF(kabc_smc_result_t, iterations), KABC_OFF(kabc_smc_result_t, n_alive),
+         KABC_OFF(kabc_smc_result_t, cost_evals), KABC_OFF(kabc_smc_result_t, proposals),
+         KABC_OFF(kabc_smc_result_t, iter_log), KABC_OFF(kabc_smc_result_t, iter_log_cap),
+         KABC_OFF(kabc_smc_result_t, kernel_ms_mcmc), KABC_OFF(kabc_smc_result_t, mcmc_launches)},
+        {KABC_OFF(kabc_abcde_opts_t, nparticles), KABC_OFF(kabc_abcde_opts_t, generations),
+         KABC_OFF(kabc_abcde_opts_t, eps_target), KABC_OFF(kabc_abcde_opts_t, alpha),
+         KABC_OFF(kabc_abcde_opts_t, proposal_width), KABC_OFF(kabc_abcde_opts_t, earlystop),
+         KABC_OFF(kabc_abcde_opts_t, verbose), KABC_OFF(kabc_abcde_opts_t, seed)},
+        {KABC_OFF(kabc_abcde_result_t, theta), KABC_OFF(kabc_abcde_result_t, cost), KABC_OFF(kabc_abcde_result_t, reached_eps),
+         KABC_OFF(kabc_abcde_result_t, reserved), KABC_OFF(kabc_abcde_result_t, generations_run),
+         KABC_OFF(kabc_abcde_result_t, nsims)},
+        {KABC_OFF(kabc_pfilter_opts_t, nparticles), KABC_OFF(kabc_pfilter_opts_t, q), KABC_OFF(kabc_pfilter_opts_t, eff_tol),
+         KABC_OFF(kabc_pfilter_opts_t, epstol), KABC_OFF(kabc_pfilter_opts_t, proposal_width),
+         KABC_OFF(kabc_pfilter_opts_t, max_iters), KABC_OFF(kabc_pfilter_opts_t, verbose),
+         KABC_OFF(kabc_pfilter_opts_t, reserved), KABC_OFF(kabc_pfilter_opts_t, seed)},
+        {KABC_OFF(kabc_pfilter_result_t, theta), KABC_OFF(kabc_pfilter_result_t, cost), KABC_OFF(kabc_pfilter_result_t, eps),
+         KABC_OFF(kabc_pfilter_result_t, eff), KABC_OFF(kabc_pfilter_result_t, iterations),
+         KABC_OFF(kabc_pfilter_result_t, nreps), KABC_OFF(kabc_pfilter_result_t, cost_evals)}};
+#undef KABC_OFF
+    if (which < 0 || which >= (int32_t)off.size()) return -1;
+    const std::vector<int32_t>& f = off[(size_t)which];
+    return (field >= 0 && field < (int32_t)f.size()) ? f[(size_t)field] : -1;
 }
 const char* kabc_last_error(void) { return get_error(); }
 

@@ -24,7 +24,7 @@
 # the Python ctypes mirror (api.py, comm.py) and from plain C (examples/abi_demo.c) by tests/.
 module KissABCHip
 
-using KissABC, Random, LinearAlgebra, Statistics
+using KissABC, Random, LinearAlgebra, Statistics, Printf
 import AbstractMCMC
 import AbstractMCMC: MCMCThreads
 import KissABC: Factored, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity, AIS, Particles
@@ -198,6 +198,13 @@ function __init__()
         want = ccall((:kabc_abi_sizeof, libkabc), Int32, (Int32,), Int32(i - 1))
         want == sizeof(T) || error("KissABCHip: sizeof($T) = $(sizeof(T)) but libkabc_hip has $want " *
                                    "(include/kabc.h changed; update the struct mirrors)")
+        for f in 1:fieldcount(T)                 # field by field: kabc_abi_offsetof
+            off = ccall((:kabc_abi_offsetof, libkabc), Int32, (Int32, Int32), Int32(i - 1), Int32(f - 1))
+            off == fieldoffset(T, f) || error("KissABCHip: $T.$(fieldname(T, f)) sits at $(fieldoffset(T, f)), " *
+                                              "libkabc_hip has it at $off")
+        end
+        ccall((:kabc_abi_offsetof, libkabc), Int32, (Int32, Int32), Int32(i - 1), Int32(fieldcount(T))) == -1 ||
+            error("KissABCHip: $T has fewer fields than the library's struct")
     end
 end
 
@@ -211,6 +218,92 @@ lower(d::NegativeBinomial) = KabcPrior(6, 0, (Float64(d.r), d.p, 0.0, 0.0))
 lower(d::Exponential) = KabcPrior(7, 0, (d.θ, 0.0, 0.0, 0.0))
 lower(d::Gamma) = KabcPrior(8, 0, (d.α, d.θ, 0.0, 0.0))
 lower(d::LogNormal) = KabcPrior(9, 0, (d.μ, d.σ, 0.0, 0.0))
+# ---- any other UnivariateDistribution: a prior family compiled at run time -----------------
+# Factored takes ANY UnivariateDistribution (src/priors.jl:11).  A family outside the built-in
+# kinds is a C snippet (kabc_user_prior_logpdf / kabc_user_prior_rand, include/kabc.h "user prior
+# families") registered with kabc_compile_prior_plugin; derived constants that are expensive to
+# form (a truncation's log-mass) go into the snippet text as hexadecimal literals, as
+# Distributions.jl keeps them in the distribution object.  The snippets below are the ones
+# kissabc.jl_amd/distributions.py ships (same text => same kind, same kernels).
+const user_prior_kinds = Dict{Tuple{String,Bool},Int32}()
+function user_prior_kind(src::String, discrete::Bool)
+    get!(user_prior_kinds, (src, discrete)) do
+        k = Ref{Int32}(0)
+        check(ccall((:kabc_compile_prior_plugin, libkabc), Cint, (Cstring, Int32, Ref{Int32}), src, Int32(discrete), k))
+        k[]
+    end
+end
+"UserPrior(csrc, params; discrete): a KabcPrior of a run-time compiled family (at most four parameters)"
+UserPrior(src::String, params; discrete::Bool = false) =
+    KabcPrior(user_prior_kind(src, discrete), 0, ntuple(i -> i <= length(params) ? Float64(params[i]) : 0.0, 4))
+hexlit(v::Float64) = isinf(v) ? (v < 0 ? "(-KABC_INF)" : "KABC_INF") : @sprintf("%a", v)   # the bits, as a C literal
+
+const POISSON_SRC = """
+KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab) {
+    if (!(x >= 0.0) || x != kabc_rint(x)) return -KABC_INF;
+    return x * p[1] - p[0] - kabc_lgamma_t(x + 1.0, tab);
+}
+KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
+    return kabc_sample_poisson(w, 0u, p[0]);
+}
+"""
+lower(d::Poisson) = UserPrior(POISSON_SRC, (d.λ, log(d.λ)); discrete = true)
+const LAPLACE_SRC = """
+KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab) {
+    (void)tab;
+    return -kabc_div_rc(kabc_fabs(x - p[0]), p[1], p[2]) - p[3];
+}
+KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
+    const kabc_u128_t b = kabc_slot(w, 0);
+    const double u = kabc_u01(kabc_lo64(b));            /* (0, 1] */
+    const double e = -p[1] * kabc_log(u);               /* Exponential(theta) */
+    return (kabc_hi64(b) & 1ull) ? p[0] + e : p[0] - e;
+}
+"""
+lower(d::Laplace) = UserPrior(LAPLACE_SRC, (d.μ, d.θ, 1 / d.θ, log(2 * d.θ)))
+# Truncated(Gamma(α, θ), lo, hi): the normaliser lgamma(α) + α log θ + logtp is a literal of the snippet
+function lower(d::Truncated{<:Gamma})
+    g = d.untruncated
+    norm = Distributions.loggamma(g.α) + g.α * log(g.θ) + d.logtp
+    src = """
+KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab) {
+    if (!(x >= p[2] && x <= p[3]) || !(x >= 0.0)) return -KABC_INF;
+    const double t1 = (p[0] == 1.0) ? 0.0 : (p[0] - 1.0) * kabc_log_t(x, tab);
+    return t1 - kabc_div_rc(x, p[1], $(hexlit(1 / g.θ))) - $(hexlit(norm));
+}
+KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
+    /* Marsaglia-Tsang proposals of the parent, two per pair of blocks, until one lands in
+     * [lower, upper]; beyond the window's slots: the nearer end of the interval to the mode */
+    const double a0 = p[0];
+    double boost = 1.0, a = a0;
+    if (a < 1.0) {
+        boost = kabc_exp(kabc_log(kabc_u01(kabc_lo64(kabc_slot(w, KABC_SLOTS_PER_DIM - 1u)))) / a);
+        a += 1.0;
+    }
+    const double d = a - 1.0 / 3.0, c = 1.0 / kabc_sqrt(9.0 * d);
+    for (uint32_t j = 0; j + 1u < KABC_SLOTS_PER_DIM - 1u; j += 2u) {
+        const kabc_u128_t bn = kabc_slot(w, j), bu = kabc_slot(w, j + 1u);
+        double z0, z1;
+        kabc_normal_pair(kabc_lo64(bn), kabc_hi64(bn), &z0, &z1);
+        const double us[2] = {kabc_u01(kabc_lo64(bu)), kabc_u01(kabc_hi64(bu))};
+        const double zs[2] = {z0, z1};
+        for (int i = 0; i < 2; ++i) {
+            double v = 1.0 + c * zs[i];
+            if (v <= 0.0) continue;
+            v = v * v * v;
+            if (kabc_log(us[i]) < 0.5 * zs[i] * zs[i] + d - d * v + d * kabc_log(v)) {
+                const double x = d * v * boost * p[1];
+                if (x >= p[2] && x <= p[3]) return x;
+            }
+        }
+    }
+    const double mode = (a0 > 1.0 ? (a0 - 1.0) : 0.0) * p[1];
+    return (kabc_fabs(p[2] - mode) < kabc_fabs(p[3] - mode)) ? p[2] : p[3];
+}
+"""
+    UserPrior(src, (g.α, g.θ, Float64(d.lower), Float64(d.upper)))
+end
+
 lower_prior(d::UnivariateDistribution) = KabcPrior[lower(d)]
 lower_prior(d::Factored) = KabcPrior[lower(c) for c in d.p]
 # vector-valued walkers (test/runtests.jl:30,186): products of univariate components run on the
@@ -523,7 +616,32 @@ function KissABC.pfilter(prior::Distribution, cost::DeviceCost, N; rng = Random.
     (P = particles_of(prior, theta, 1:Neff), C = Particles(C))     # src/smc.jl:334-340
 end
 
-export DeviceCost, UserCost, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
+"""
+    compile_model(model; families = 0) / compile_model(prior, cost; families = 0)
+Kernels specialised for ONE model (kabc_compile_model, include/kabc.h): the prior tuple's
+families and parameters become compile-time constants of a translation unit compiled by hipRTC.
+Afterwards `sample` / `smc` / `ABCDE` / `pfilter` on the same prior components and cost use them;
+results keep their bits.  Returns the registration's handle (0: left to the prebuilt kernels).
+"""
+function compile_model(model::DeviceModel; families::Integer = 0)
+    h = Ref{Int32}(0)
+    with_model(model) do cm
+        check(ccall((:kabc_compile_model, libkabc), Cint, (Ref{KabcModel}, Int32, Ref{Int32}), cm, Int32(families), h))
+    end
+    h[]
+end
+function compile_model(prior::Distribution, cost::DeviceCost; families::Integer = 2)
+    pri = lower_prior(prior)
+    h = Ref{Int32}(0)
+    GC.@preserve pri cost begin
+        cm = KabcModel(pointer(pri), length(pri), 0, 1.0, kcost(cost))
+        check(ccall((:kabc_compile_model, libkabc), Cint, (Ref{KabcModel}, Int32, Ref{Int32}), cm, Int32(families), h))
+    end
+    h[]
+end
+release_model(h::Integer) = check(ccall((:kabc_model_release, libkabc), Cint, (Int32,), Int32(h)))
+
+export DeviceCost, UserCost, UserPrior, compile_model, release_model, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
        AbsDiff, NormShell, NoisyQuadDU, Mixture, NoisyBanana, WienerRms, sample_sharded, unique_id,
        comm_init_rank
 end # module
