@@ -31,31 +31,38 @@ def unique_id():
     return bytes(buf)
 
 
-_UID_MAGIC = b"KABCUID1"
+_UID_MAGIC = b"KABCUID2"
 
 
-def _launch_stamp():
-    """Identity of the LAUNCH this process belongs to: (pid, kernel start time) of its parent.
-    Every local rank of one launch is a child of the same launcher process (torchrun's elastic
-    agent, mpirun's proxy, a Julia / shell driver), two launches never share the pair -- the start
-    time disambiguates a recycled pid -- so a file named after it cannot be a leftover of an
-    earlier job, however long ago or recently that job ran."""
-    ppid = os.getppid()
-    start = "0"
+def _proc_start(pid):
+    """kernel start time (clock ticks since boot) of a live process, or None"""
     try:
-        with open(f"/proc/{ppid}/stat", "rb") as f:
+        with open(f"/proc/{pid}/stat", "rb") as f:
             st = f.read()
-        start = st[st.rindex(b")") + 2:].split()[19].decode()   # field 22: starttime
+        return int(st[st.rindex(b")") + 2:].split()[19])   # field 22: starttime
     except (OSError, ValueError, IndexError):
-        pass
-    return f"p{ppid}-{start}"
+        return None
+
+
+def _publisher_alive(pid, start):
+    """Is the rank 0 that wrote a record still running?  A record outlives its launch only when
+    rank 0 was killed (its atexit hook never ran); (pid, start time) of a dead process never
+    matches a live one, a recycled pid has another start time.  KABC_RDZV_NO_LIVENESS=1 skips the
+    test (ranks in separate pid namespaces that share the rendezvous directory)."""
+    if os.environ.get("KABC_RDZV_NO_LIVENESS") == "1" or not os.path.isdir("/proc/self"):
+        return True
+    return _proc_start(pid) == start
 
 
 def rendezvous_key(world):
-    """Default name of the rendezvous file.  KABC_RDZV_KEY (any string the host guarantees
-    unique per launch, e.g. a scheduler job id) wins; otherwise the launcher's rendezvous
-    variables + the launch stamp.  Without either there is nothing that tells two concurrent
-    jobs of one user apart, and the id is refused rather than guessed."""
+    """Default name of the rendezvous file: KABC_RDZV_KEY (any string the host guarantees unique
+    per launch, e.g. a scheduler job id) or the launcher's rendezvous variables -- the same for
+    every rank of a launch WHATEVER process started it (torchrun's agent, a per-rank wrapper
+    shell, mpirun, ssh).  Two concurrent launches on one node cannot share MASTER_PORT; a leftover
+    of an EARLIER launch with the same variables is told apart by the record itself (the
+    publishing rank 0 must be alive: exchange_unique_id).  Without any of the variables there is
+    nothing that tells two concurrent jobs of one user apart, and the id is refused rather than
+    guessed."""
     clean = lambda v: "".join(ch if ch.isalnum() else "-" for ch in str(v))   # noqa: E731
     explicit = os.environ.get("KABC_RDZV_KEY")
     if explicit:
@@ -68,16 +75,20 @@ def rendezvous_key(world):
             "set.  Launch the ranks with torchrun / `python -m torch.distributed.run`, or set "
             "KABC_RDZV_KEY to a string unique to this launch (and identical on all its ranks), or "
             "pass the id yourself: Comm.init_rank(uid, rank, world)")
-    return f"{clean('_'.join(env))}_{_launch_stamp()}_w{world}"
+    return f"{clean('_'.join(env))}_w{world}"
 
 
 def exchange_unique_id(rank, world, key=None, directory=None, timeout=300.0, make_id=None):
     """Ship rank 0's RCCL unique id to the other ranks of ONE node through a file
     (the id is 128 opaque bytes; any channel the host owns would do -- a Julia host
-    would use Distributed or MPI.bcast).  The file is named after `key`
-    (default: rendezvous_key -- unique per launch, so no freshness heuristic is needed: a rank
-    may start minutes after rank 0 published and still finds the right id).  Rank 0 replaces
-    whatever is at the path atomically and removes the file when it exits."""
+    would use Distributed or MPI.bcast).  The file is named after `key` (default:
+    rendezvous_key); the record holds the id and (pid, start time) of the rank 0 that wrote it.
+    A reader takes a record only while that process is alive, so neither the record's age nor
+    the shape of the launcher matters: a rank may start minutes after rank 0 published, each
+    rank may sit under its own wrapper process, and the leftover of a killed job is never taken
+    for the id of the next one.  Rank 0 replaces whatever is at the path atomically and removes
+    the file when it exits."""
+    import struct
     make_id = make_id or unique_id
     if world == 1:
         return make_id()
@@ -89,7 +100,7 @@ def exchange_unique_id(rank, world, key=None, directory=None, timeout=300.0, mak
         uid = make_id()
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "wb") as f:
-            f.write(_UID_MAGIC + uid)
+            f.write(_UID_MAGIC + uid + struct.pack("<qq", os.getpid(), _proc_start(os.getpid()) or 0))
         os.replace(tmp, path)   # atomic: readers see the whole record or the previous file
         import atexit
 
@@ -101,16 +112,27 @@ def exchange_unique_id(rank, world, key=None, directory=None, timeout=300.0, mak
         atexit.register(_cleanup)
         return uid
     t0 = time.time()
+    seen_stale = False
+    nrec = len(_UID_MAGIC) + cd.KABC_COMM_ID_BYTES + 16
     while True:
         try:
             with open(path, "rb") as f:
                 rec = f.read()
-            if len(rec) == len(_UID_MAGIC) + cd.KABC_COMM_ID_BYTES and rec.startswith(_UID_MAGIC):
-                return rec[len(_UID_MAGIC):]
+            if len(rec) == nrec and rec.startswith(_UID_MAGIC):
+                pid, start = struct.unpack("<qq", rec[-16:])
+                if _publisher_alive(pid, start):
+                    return rec[len(_UID_MAGIC):-16]
+                seen_stale = True
         except OSError:
             pass
         if time.time() - t0 > timeout:
-            raise TimeoutError(f"rank {rank}: no unique id at {path} after {timeout:.0f}s")
+            raise TimeoutError(
+                f"rank {rank}: no unique id at {path} after {timeout:.0f}s"
+                + (" (a record is there, but the rank 0 that wrote it is gone: the leftover of an earlier launch)"
+                   if seen_stale else "")
+                + ".  Every rank of a launch must derive the same path: identical MASTER_ADDR / MASTER_PORT / "
+                  "TORCHELASTIC_RUN_ID, or KABC_RDZV_KEY=<string unique to this launch>, and a shared "
+                  "KABC_RDZV_DIR (default /tmp); ranks in separate pid namespaces: KABC_RDZV_NO_LIVENESS=1")
         time.sleep(0.02)
 
 

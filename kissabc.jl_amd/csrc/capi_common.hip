@@ -419,6 +419,15 @@ kabc_status_t kabc_mvnormal_register(const double* mu, const double* cov, int32_
         return KABC_ERR_INVALID_ARG;
     }
     std::lock_guard<std::mutex> lk(g_mvn_mu);
+    // the same (mu, Sigma) registered again -- priors built in a loop, a sweep's repeated models --
+    // is the same entry: nothing accumulates on the host or on the devices
+    for (size_t i = 0; i < g_mvn.size(); ++i)
+        if (g_mvn[i]->D == D && g_mvn[i]->host.size() == e->host.size() &&
+            std::memcmp(g_mvn[i]->host.data(), e->host.data(), sizeof(double) * e->host.size()) == 0) {
+            delete e;
+            *handle = (int32_t)(i + 1);
+            return KABC_OK;
+        }
     g_mvn.push_back(e);
     *handle = (int32_t)g_mvn.size();
     return KABC_OK;

@@ -267,7 +267,9 @@ __device__ __forceinline__ bool loop_barrier_wait(SmcLoopScratch* g, const LoopX
         // invalidate on gfx950 -- buffer_inv sc0 is workgroup scope, a no-op outside
         // threadgroup-split mode -- so the acquire side stays per workgroup; the saving of this
         // barrier is the release side.)
-        asm volatile("buffer_inv sc1" ::: "memory");
+        // (the invalidate completes asynchronously: wait for it HERE, before this wave passes the
+        // workgroup barrier that lets the other waves load -- not by the accident of the load below)
+        asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
         volatile unsigned* ab = &g->abort_flag;
         if (*ab) ok = false;
         *s_ok = ok ? 1 : 0;

@@ -1,9 +1,10 @@
 """The file rendezvous that ships rank 0's RCCL unique id to the other ranks of a node
 (kissabc_jl_amd.comm.exchange_unique_id): pure host logic, no GPU, no RCCL.
 
-The file is named after the LAUNCH (launcher variables + pid / start time of the common parent
-process), not judged by its age: a rank that starts long after rank 0 published must still find
-the id, and a leftover of an earlier job must never be taken for it."""
+The file is named after the launcher's rendezvous variables; the record carries (pid, start time)
+of the rank 0 that wrote it and is taken only while that process is alive.  So: a rank that starts
+long after rank 0 published still finds the id, the ranks may each sit under their own wrapper
+process, and a leftover of a killed job is never taken for the id of the next one."""
 import os
 import subprocess
 import sys
@@ -52,23 +53,35 @@ def test_late_rank_still_finds_the_id(comm, tmp_path, monkeypatch):
 
 
 def test_leftover_of_an_earlier_launch_is_never_read(comm, tmp_path, monkeypatch):
-    """Same rendezvous variables, another launch (another parent process / start time): the
-    name differs, so the stale record is invisible however fresh its mtime is."""
+    """Same rendezvous variables, an earlier launch whose rank 0 was killed (its atexit hook never
+    ran): the record names a process that is gone -- or whose pid was recycled, with another start
+    time -- and is ignored however fresh its mtime is; the timeout says so."""
+    import struct
     monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
     monkeypatch.setenv("MASTER_PORT", "29518")
-    monkeypatch.setattr(comm, "_launch_stamp", lambda: "p4242-1111")
-    stale = comm.exchange_unique_id(0, 2, directory=str(tmp_path))      # "earlier job", just now
-    monkeypatch.setattr(comm, "_launch_stamp", lambda: "p4242-2222")   # pid recycled, new start time
-    with pytest.raises(TimeoutError):
+    stale = comm.exchange_unique_id(0, 2, directory=str(tmp_path))      # "earlier job", just now ...
+    (path,) = list(tmp_path.iterdir())
+    rec = path.read_bytes()
+    pid, start = struct.unpack("<qq", rec[-16:])
+    assert pid == os.getpid() and start > 0
+    path.write_bytes(rec[:-16] + struct.pack("<qq", pid, start + 12345))   # ... by a process that is gone
+    with pytest.raises(TimeoutError, match="leftover of an earlier launch"):
         comm.exchange_unique_id(1, 2, directory=str(tmp_path), timeout=0.5)
+    path.write_bytes(rec[:-16] + struct.pack("<qq", 2 ** 22 + 7, start))   # no such pid
+    with pytest.raises(TimeoutError, match="KABC_RDZV_KEY"):
+        comm.exchange_unique_id(1, 2, directory=str(tmp_path), timeout=0.3)
     fresh = comm.exchange_unique_id(0, 2, directory=str(tmp_path))
     assert fresh != stale
     assert comm.exchange_unique_id(1, 2, directory=str(tmp_path), timeout=5) == fresh
+    # ranks in separate pid namespaces cannot see rank 0's pid: the test can be switched off
+    path.write_bytes(rec[:-16] + struct.pack("<qq", 2 ** 22 + 7, start))
+    monkeypatch.setenv("KABC_RDZV_NO_LIVENESS", "1")
+    assert comm.exchange_unique_id(1, 2, directory=str(tmp_path), timeout=5) == stale
 
 
 def test_truncated_or_foreign_record_is_not_an_id(comm, tmp_path):
     path = tmp_path / f"kabc_uid_{os.getuid()}_t2.bin"
-    path.write_bytes(b"\x01" * 128)          # right size for a bare id, no magic: not ours
+    path.write_bytes(b"\x01" * (8 + 128 + 16))          # right size, no magic: not ours
     with pytest.raises(TimeoutError):
         comm.exchange_unique_id(1, 2, key="t2", directory=str(tmp_path), timeout=0.3)
     fresh = comm.exchange_unique_id(0, 2, key="t2", directory=str(tmp_path))   # rank 0 replaces it
@@ -106,18 +119,23 @@ if rank == 0:
 """
 
 
-def test_two_processes_of_one_launch(k, tmp_path):
-    """Two real processes, children of this one (= the launcher): they derive the same default
-    key from MASTER_* + the launch stamp; rank 1 starts 6 s after rank 0 has published (the
-    old mtime rule rejected exactly this case and then timed out)."""
+@pytest.mark.parametrize("wrapped", [False, True], ids=["direct-children", "per-rank-wrapper-shells"])
+def test_two_processes_of_one_launch(k, tmp_path, wrapped):
+    """Two real processes derive the same default key from MASTER_*; rank 1 starts 6 s after rank 0
+    has published (an mtime rule rejected exactly this case and then timed out).  `wrapped`: each
+    rank runs under its OWN non-exec wrapper shell (torchrun --no-python wrapper.sh, mpirun
+    bash -c, per-rank ssh) -- the ranks then have different parent processes, which a key built
+    from the parent's pid cannot survive."""
     script = tmp_path / "child.py"
     script.write_text(_CHILD.format(root=ROOT, d=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519" if not wrapped else "29520")
     env.pop("KABC_RDZV_KEY", None)
-    p0 = subprocess.Popen([sys.executable, str(script), "0", "0", "9"], env=env,
-                          stdout=subprocess.PIPE, text=True)
-    p1 = subprocess.Popen([sys.executable, str(script), "1", "6", "0"], env=env,
-                          stdout=subprocess.PIPE, text=True)
+
+    def cmd(*a):
+        base = [sys.executable, str(script), *a]
+        return ["bash", "-c", " ".join(base) + "; exit $?"] if wrapped else base
+    p0 = subprocess.Popen(cmd("0", "0", "9"), env=env, stdout=subprocess.PIPE, text=True)
+    p1 = subprocess.Popen(cmd("1", "6", "0"), env=env, stdout=subprocess.PIPE, text=True)
     o1, _ = p1.communicate(timeout=120)
     o0, _ = p0.communicate(timeout=120)
     assert p0.returncode == 0 and p1.returncode == 0
