@@ -498,6 +498,11 @@ static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int 
             k.mod = rtc_kernel(R, head, "pfilter_kernels.hpp", false, {n}, n);
             break;
         }
+        case kPfSmcSmall: {
+            const std::string n = "kabc::smc_small_kernel<" + d + ", " + u + ", " + (variant ? "true" : "false") + ">";
+            k.mod = rtc_kernel(R, head, "smc_small_kernel.hpp", false, {n}, n);
+            break;
+        }
         case kPfPriorLogpdf:
         case kPfPriorRand: {
             const std::vector<std::string> n = {"kabc::prior_logpdf_kernel", "kabc::prior_rand_kernel"};
@@ -767,7 +772,7 @@ extern "C" kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family,
         set_error("kabc_plugin_precompile: %d is not a registered user cost", cost_id);
         return KABC_ERR_INVALID_ARG;
     }
-    if (family < kPfAis || family > kPfAttempt) {
+    if (family < kPfAis || (family > kPfAttempt && family != kPfSmcSmall)) {
         set_error("kabc_plugin_precompile: unknown kernel family %d", family);
         return KABC_ERR_INVALID_ARG;
     }

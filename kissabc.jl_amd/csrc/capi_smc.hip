@@ -10,6 +10,7 @@
 #include "host_common.hpp"
 #include "plugin_registry.hpp"
 #include "smc_loop_kernel.hpp"
+#include "smc_small_kernel.hpp"
 #include "smc_dyn_kernels.hpp"
 #include "abcde_kernels.hpp"
 #include "pfilter_kernels.hpp"
@@ -41,6 +42,44 @@ KABC_DECL_LOOP(8)
 KABC_DECL_LOOP(9)
 KABC_DECL_LOOP(10)
 KABC_DECL_LOOP(11)
+
+#define KABC_DECL_SMALL(id) SmcSmallLaunchFn find_smc_small_kernel_cost_##id(int D, bool simple);
+KABC_DECL_SMALL(1)
+KABC_DECL_SMALL(2)
+KABC_DECL_SMALL(3)
+KABC_DECL_SMALL(4)
+KABC_DECL_SMALL(5)
+KABC_DECL_SMALL(6)
+KABC_DECL_SMALL(7)
+KABC_DECL_SMALL(8)
+KABC_DECL_SMALL(9)
+KABC_DECL_SMALL(10)
+KABC_DECL_SMALL(11)
+
+SmcSmallLaunch find_smc_small_kernel(int cost_id, int D, bool simple, ModelUnit* unit) {
+    if (unit) {
+        const PluginKernel k = unit_kernel(unit, kPfSmcSmall, D, simple ? 1 : 0);
+        return k.mod ? SmcSmallLaunch(k.mod, &smc_small_geom, (unsigned)kSmallBlock) : SmcSmallLaunch();
+    }
+    switch (cost_id) {
+        case 1: return find_smc_small_kernel_cost_1(D, simple);
+        case 2: return find_smc_small_kernel_cost_2(D, simple);
+        case 3: return find_smc_small_kernel_cost_3(D, simple);
+        case 4: return find_smc_small_kernel_cost_4(D, simple);
+        case 5: return find_smc_small_kernel_cost_5(D, simple);
+        case 6: return find_smc_small_kernel_cost_6(D, simple);
+        case 7: return find_smc_small_kernel_cost_7(D, simple);
+        case 8: return find_smc_small_kernel_cost_8(D, simple);
+        case 9: return find_smc_small_kernel_cost_9(D, simple);
+        case 10: return find_smc_small_kernel_cost_10(D, simple);
+        case 11: return find_smc_small_kernel_cost_11(D, simple);
+        default: {
+            // (hipRTC user costs; a plugin .so built by hipcc has no such kernel: the other drivers serve)
+            const PluginKernel k = plugin_kernel(find_plugin(cost_id), kPfSmcSmall, D, simple ? 1 : 0);
+            return k.mod ? SmcSmallLaunch(k.mod, &smc_small_geom, (unsigned)kSmallBlock) : SmcSmallLaunch();
+        }
+    }
+}
 
 SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple, ModelUnit* unit) {
     if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
@@ -586,13 +625,77 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     kabc_status_t rc = KABC_OK;
     const int R = 1 + o->mcmc_retrys;
 
+    // Path 0: a small ensemble (N <= 256: the reference's default nparticles = 100) in ONE
+    // workgroup, the ensemble in LDS, workgroup barriers where the other drivers launch kernels or
+    // cross the device (smc_small_kernel.hpp).  A prepared cost's pre-pass stays grid-wide: one
+    // launch for the next kAuxRing passes, then one launch of this kernel for those passes.
+    // KABC_SMC_SMALL=0, or an explicit choice of one of the other drivers (KABC_SMC_LOOP set),
+    // skips it.
+    bool looped = false;
+    {
+        const char* env = std::getenv("KABC_SMC_SMALL");
+        const bool allow = !(env && env[0] == '0') && !std::getenv("KABC_SMC_LOOP") && !tl_smc_no_loop &&
+                           !comm && !dyn && N <= (int64_t)kSmallBlock && (!auxW || aux_ring > 1);
+        SmcSmallLaunch small_fn = allow ? find_smc_small_kernel(cost->id, D, simple, unit) : SmcSmallLaunch();
+        if (small_fn) {
+            SmcSmallArgs sm;
+            std::memset(&sm, 0, sizeof sm);
+            for (int b = 0; b < 2; ++b) {
+                sm.theta[b] = th[b];
+                sm.X[b] = X[b];
+                sm.lpi[b] = lp[b];
+            }
+            sm.alive = alive;
+            sm.ctrl = ctrl;
+            sm.log = d_log;
+            sm.log_cap = log_cap;
+            sm.cost_params = d_params;
+            sm.cost_data = d_data;
+            sm.cost_ndata = cost->ndata;
+            sm.N = N;
+            sm.seed = o->seed;
+            sm.max_stretch = o->max_stretch;
+            sm.alpha = alpha;
+            sm.min_r_ess = min_r_ess;
+            sm.loop = lpz;
+            sm.retry_n = R;
+            sm.max_passes = auxW ? aux_ring : 0;
+            sm.aux = auxW ? d_aux : nullptr;
+            sm.aux_ring = aux_ring;
+            PriorDev* d_prior;
+            KABC_HIP_CHECK(bufs.alloc(&d_prior, (size_t)KABC_MAX_DIM));
+            KABC_HIP_CHECK(hipMemcpyAsync(d_prior, &P, sizeof(PriorSet), hipMemcpyHostToDevice, s));
+            sm.prior = d_prior;
+            KABC_HIP_CHECK(hipEventRecord(ev0, s));
+            for (int64_t launches = 0;; ++launches) {
+                if (auxW) launch_aux_prepass(cost->id, xa, s, 1);
+                small_fn(sm, s);
+                KABC_HIP_CHECK(hipGetLastError());
+                if (launches == 0) KABC_HIP_CHECK(hipEventRecord(ev1, s));
+                KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+                KABC_HIP_CHECK(hipStreamSynchronize(s));
+                if (hc.done) break;
+                if (!auxW) {  // (without a ring the kernel only returns when the loop is over)
+                    set_error("smc: the small-ensemble kernel returned before the loop ended");
+                    return KABC_ERR_DEVICE;
+                }
+            }
+            float ms = 0.f;
+            if (hc.pass > 0 && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+                const unsigned long long first = auxW ? (hc.pass < (unsigned long long)aux_ring ? hc.pass : (unsigned long long)aux_ring) : hc.pass;
+                mcmc_ms = ms / (double)first;  // the first launch per pass: there is no separate propose+accept kernel
+                mcmc_timed = 1;
+            }
+            looped = true;
+        }
+    }
+
     // Path 1: the whole ε-loop as ONE persistent cooperative kernel (smc_loop_kernel.hpp) --
     // one thread per particle, for ensembles whose alive mask fits in LDS.  KABC_SMC_LOOP=0
     // selects the multi-kernel path below (also taken when the grid cannot be co-resident).
-    bool looped = false;
     {
         const char* env = std::getenv("KABC_SMC_LOOP");  // read per call: tests flip it
-        const bool allow = !(env && env[0] == '0') && !tl_smc_no_loop && !comm && !auxW;
+        const bool allow = !looped && !(env && env[0] == '0') && !tl_smc_no_loop && !comm && !auxW;
         const unsigned G = (unsigned)((N + kLoopBlock - 1) / kLoopBlock);
         SmcLoopLaunch loop_fn =
             (allow && !dyn && G <= (unsigned)kLoopMaxG) ? find_smc_loop_kernel(cost->id, D, simple, unit) : SmcLoopLaunch();

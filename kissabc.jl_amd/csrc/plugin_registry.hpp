@@ -32,7 +32,8 @@ bool cost_dim_ok_rt(int cost_id, int D);
 // `variant`: AIS pcx (prior class + kPriorClasses * (posterior kind - 1)); smc: simple prior 0/1.
 enum PluginFamily {
     kPfAis = 0, kPfAisInit, kPfSmc, kPfSmcInit, kPfSmcLoop, kPfAbcdeInit, kPfAbcdeGen, kPfAttempt,
-    kPfPriorLogpdf, kPfPriorRand  // (model units only: the Factored utility kernels)
+    kPfPriorLogpdf, kPfPriorRand,  // (model units only: the Factored utility kernels)
+    kPfSmcSmall                    // (hipRTC units: the one-workgroup smc driver, smc_small_kernel.hpp)
 };
 struct PluginKernel {
     void* host = nullptr;

@@ -1,6 +1,7 @@
 // smc_inst.hip -- instantiates smc_mcmc_kernel<D, COST> for one DeviceCost id
 // (-DKABC_INST_COST=<id>) and every dimension the cost accepts.
 #include "smc_loop_kernel.hpp"
+#include "smc_small_kernel.hpp"
 
 #ifndef KABC_INST_COST
 #error "compile with -DKABC_INST_COST=<cost id>"
@@ -43,10 +44,28 @@ static SmcLoopLaunchFn loop_table(int D, bool simple, std::integer_sequence<int,
     return simple ? fs[D - 1] : fg[D - 1];
 }
 
+template <int COST, int D, bool SIMPLE>
+static SmcSmallLaunchFn pick_small() {
+    if constexpr (cost_dim_ok_c(COST, D)) return &launch_smc_small<D, COST, SIMPLE>;
+    else return nullptr;
+}
+
+template <int COST, int... Ds>
+static SmcSmallLaunchFn small_table(int D, bool simple, std::integer_sequence<int, Ds...>) {
+    SmcSmallLaunchFn fs[] = {pick_small<COST, Ds + 1, true>()...};
+    SmcSmallLaunchFn fg[] = {pick_small<COST, Ds + 1, false>()...};
+    if (D < 1 || D > (int)sizeof...(Ds)) return nullptr;
+    return simple ? fs[D - 1] : fg[D - 1];
+}
+
 #define KABC_CAT2(a, b) a##b
 #define KABC_CAT(a, b) KABC_CAT2(a, b)
 SmcLaunchFn KABC_CAT(find_smc_kernel_cost_, KABC_INST_COST)(int D, bool simple) {
     return table<KABC_INST_COST>(D, simple, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+}
+
+SmcSmallLaunchFn KABC_CAT(find_smc_small_kernel_cost_, KABC_INST_COST)(int D, bool simple) {
+    return small_table<KABC_INST_COST>(D, simple, std::make_integer_sequence<int, KABC_MAX_DIM>{});
 }
 
 SmcLoopLaunchFn KABC_CAT(find_smc_loop_kernel_cost_, KABC_INST_COST)(int D, bool simple) {

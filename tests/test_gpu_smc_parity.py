@@ -39,12 +39,17 @@ def _cases(k):
     }
 
 
-@pytest.fixture(params=["loop", "kernels"])
+@pytest.fixture(params=["loop", "kernels", "default"])
 def smc_path(request, monkeypatch):
-    """Both device drivers of the ε-loop: the persistent cooperative kernel
-    (csrc/smc_loop_kernel.hpp, the default up to 65 536 particles) and the
-    kernel-per-phase path (KABC_SMC_LOOP=0; larger ensembles)."""
-    monkeypatch.setenv("KABC_SMC_LOOP", "1" if request.param == "loop" else "0")
+    """The device drivers of the ε-loop: the persistent cooperative kernel
+    (csrc/smc_loop_kernel.hpp, the default from 257 to 65 536 particles), the
+    kernel-per-phase path (KABC_SMC_LOOP=0; larger ensembles) and, with nothing selected
+    ("default"), whatever kabc_smc_run picks itself -- the one-workgroup kernel
+    (csrc/smc_small_kernel.hpp) up to 256 particles."""
+    if request.param == "default":
+        monkeypatch.delenv("KABC_SMC_LOOP", raising=False)
+    else:
+        monkeypatch.setenv("KABC_SMC_LOOP", "1" if request.param == "loop" else "0")
     return request.param
 
 
@@ -136,6 +141,55 @@ def test_loop_kernel_many_sizes(k, orc, gpu_ctx, monkeypatch):
             assert np.array_equal(got.info["theta_all"], ref["theta_all"])
             assert np.array_equal(got.C, ref["C"])
             assert got.info["cost_evals"] == ref["cost_evals"]
+
+
+def test_small_ensemble_kernel_many_cases(k, orc, gpu_ctx, monkeypatch):
+    """The one-workgroup driver (csrc/smc_small_kernel.hpp, N <= 256) away from the happy path:
+    the smallest legal ensembles, exactly 256 particles, heavy ties (integer-valued costs), α small
+    (large resample ratios), no resampling at all, retry passes, a prepared cost through the ring of
+    pre-pass words (README.md:31-49) with more iterations than one ring holds, ∞ costs, and a
+    user cost compiled at run time.  KABC_SMC_SMALL=0 gives the same bits on the other drivers."""
+    monkeypatch.delenv("KABC_SMC_LOOP", raising=False)
+    N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    du = k.Factored(k.DiscreteUniform(-20, 20), k.DiscreteUniform(-20, 20))
+    rd = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
+    H6 = k.Factored(k.Normal(0, 5), k.Uniform(0, 5), *[k.Normal(0, 1)] * 4)
+    noisy = k.costs.UserCost("""
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params, const double* data,
+                              int64_t ndata, kabc_cost_rng_t* rng) {
+    double z0, z1;
+    kabc_cost_rng_normal2(rng, &z0, &z1);
+    return kabc_fabs(x[0] - params[0]) + kabc_fabs(x[1] - params[1]) + 0.01 * kabc_fabs(z0);
+}
+""", dims=[2], params=[1.0, -0.5], name="l1_noisy")
+    orc.register_user_cost(noisy)
+    cases = [
+        (N2, k.costs.GaussDist([1.0, -0.5]), dict(nparticles=7, alpha=0.95, epstol=0.5)),
+        (N2, k.costs.GaussDist([1.0, -0.5]), dict(nparticles=37, alpha=0.9, epstol=0.05)),
+        (N2, k.costs.GaussDist([1.0, -0.5]), dict(nparticles=256, alpha=0.5, min_r_ess=0.2, epstol=0.05)),
+        (N2, k.costs.GaussDist([1.0, -0.5]), dict(nparticles=255, alpha=0.3, min_r_ess=0.05, epstol=0.02)),
+        (du, k.costs.GaussDist([3.0, -2.0]), dict(nparticles=200, alpha=0.8, epstol=0.5)),
+        (du, k.costs.GaussDist([3.0, -2.0]), dict(nparticles=129, alpha=0.99, min_r_ess=0.05, epstol=0.5)),
+        (N2, k.costs.NoisyBanana(0.5), dict(nparticles=222, alpha=0.9, epstol=0.01, mcmc_retrys=3, mcmc_tol=0.3)),
+        (k.Uniform(-10, 10), k.costs.Mixture(0.0), dict(nparticles=100, alpha=0.9, epstol=0.01, mcmc_retrys=50,
+                                                       mcmc_tol=0.9)),
+        (rd, k.costs.NormalMeanStdSim(1000, 2.0012, 0.0401), dict()),
+        (rd, k.costs.NormalMeanStdSim(77, 2.0012, 0.0401), dict(nparticles=250, alpha=0.9)),
+        (H6, k.costs.HierGaussSim(np.array([0.9, 1.3, 0.2, 1.1])), dict(nparticles=240, epstol=0.2)),
+        (N2, noisy, dict(nparticles=150, epstol=0.05)),
+    ]
+    for prior, cost, kw in cases:
+        for seed in (1, 2):
+            ref = orc.smc(prior, cost, seed=seed, **kw)
+            for small in ("1", "0"):
+                monkeypatch.setenv("KABC_SMC_SMALL", small)
+                got = k.smc(prior, cost, seed=seed, return_array=True, **kw)
+                assert got.info["log"] == ref["log"], (kw, seed, small)
+                assert got.eps == ref["eps"] and np.array_equal(got.info["alive"], ref["alive"])
+                assert np.array_equal(got.info["theta_all"], ref["theta_all"])
+                assert np.array_equal(got.C, ref["C"]) and np.array_equal(got.P, ref["P"])
+                assert got.info["cost_evals"] == ref["cost_evals"] and got.info["proposals"] == ref["proposals"]
+    assert ref["iterations"] > 3
 
 
 _C4_ORACLE = {}
