@@ -207,6 +207,22 @@ def cpu_baseline(k, budget_s, with_smc):
     return out
 
 
+def _valu_cycles():
+    """average issue cycles per VALU wave-instruction of the headline kernel: its static class mix
+    (profiles/r*_valu_mix.json) x the measured issue time per class"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_mix.json")))
+    if not files:
+        return 4.0, None
+    try:
+        m = json.load(open(files[-1]))
+        return float(m["avg_issue_cycles"]), os.path.basename(files[-1])
+    except Exception:
+        return 4.0, None
+
+
+VALU_CYCLES, VALU_MIX_FILE = _valu_cycles()
+
+
 def _pmc_table():
     """VALU wave-instructions per half-generation launch from the newest committed PMC
     summary (profiles/r*_pmc_insts.json: {"<nt>": {"SQ_INSTS_VALU": per-launch mean, ...}})."""
@@ -228,6 +244,8 @@ def main():
                     help="the setting the headline value is quoted on")
     ap.add_argument("--min-seconds", type=float, default=1.0,
                     help="repeat the K-step block until this much has been timed (per setting)")
+    ap.add_argument("--headline-seconds", type=float, default=7.0,
+                    help="timed device work of the headline setting (one uninterrupted stretch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true",
@@ -299,21 +317,36 @@ def main():
             sync()
             el_r += time.perf_counter() - t0
         kms_r, nl_r = ens.kernel_ms()
+        # exchange diagnostics (kabc_ais_exchange_us: hipEvent pairs on the stream the all-gather
+        # runs on, over the first 128 timed half-generations): max over the ranks
+        xch = None
+        if comm:
+            x = ens.exchange_us()
+            v = comm.allreduce_max([x["compute_us_per_half"], x["exchange_us_per_half"], x["exposed_us_per_half"]])
+            xch = {"compute_us_per_half": v[0], "exchange_us_per_half": v[1], "exposed_us_per_half": v[2],
+                   "chunks": x["chunks"],
+                   "note": "per half-generation, max over ranks: kernels / all-gather(s) on their stream / "
+                           "what the context stream then waits for the gathered half"}
         ens.set_timing(0)
         s1 = global_stats()
         if comm:
             el_r = comm.allreduce_max([el_r])[0]
-        return {"el": el_r, "kms": kms_r, "nl": nl_r, "blocks": blocks, "steps": steps,
+        return {"el": el_r, "kms": kms_r, "nl": nl_r, "blocks": blocks, "steps": steps, "exchange": xch,
                 "proposals": s1["proposals"] - s0["proposals"],
                 "cost_evals": s1["cost_evals"] - s0["cost_evals"],
                 "accepted": s1["accepted"] - s0["accepted"]}
 
     settings = [nt_head] if args.no_alt else sorted(set(NT_SET) | {nt_head})
     regions = {}
+    base_min = args.min_seconds
     for nt_r in settings:
         # the same K everywhere would make the nt = 1 block 100x shorter; the block count
-        # (min-seconds) evens the timed duration out instead
+        # (min-seconds) evens the timed duration out instead.  The headline setting runs
+        # --headline-seconds without a gap, so that an external sampler with a period of several
+        # seconds sees the GPU busy at least once.
+        args.min_seconds = max(base_min, args.headline_seconds) if nt_r == nt_head else base_min
         regions[nt_r] = timed_region(nt_r, args.steps, args.warmup if nt_r == nt_head else 5)
+    args.min_seconds = base_min
 
     def kernel_leg(model, N, Dm, nts=(NT_HEADLINE,)):
         """half-generation kernel time and evals/s of another single-GPU workload"""
@@ -381,6 +414,16 @@ def main():
                            workload="C2: AIS 4096 walkers, D=2, Normal(0,5)^2, gauss_dist, scale 0.1 "
                                     "(BASELINE.json configs[1]); 32 workgroups: bound by the latency of "
                                     "one wavefront's chain of dependent transitions, not by throughput")
+        # C2 is not a throughput workload: 32 workgroups, each ONE consumer wavefront working through
+        # its walkers' dependent transitions.  Its floor is that chain issued back to back --
+        # 0.36 us per sub-step (DESIGN.md 6 / profiles/r03_c2_ablation.txt: ~95 dependent issue
+        # slots of 3.8 ns) -- plus the launch boundary; `latency_floor_frac` = floor / measured is
+        # the number that can move (the contract roofline fraction cannot: 0.04 at best here).
+        for nt_s, v in list(extra["c2"].items()):
+            if isinstance(v, dict) and "kernel_avg_us" in v:
+                floor_us = 0.36 * int(nt_s) + 3.6
+                v["latency_floor_us"] = floor_us
+                v["latency_floor_frac"] = floor_us / v["kernel_avg_us"]
         if cpu and isinstance(cpu.get("c2"), dict) and "value" in cpu["c2"]:
             extra["c2"]["cpu_baseline"] = cpu["c2"]
         # Each class on the prebuilt kernels and on the kernels specialised for the model
@@ -466,7 +509,12 @@ def main():
             valu = None
             vi = (pmc.get(str(nt_r)) or {}).get("SQ_INSTS_VALU")
             if vi and kms > 0:
-                valu = vi * 4.0 / (SIMDS * CLOCK_HZ * kms * 1e-3)
+                # issue time per wave-instruction: the measured rates of this chip by class
+                # (profiles/r01m_valu_rate_8waves.json: f64 add / mul / fma and v_mad_u64_u32 issue
+                # in ~1.9 ns = 4.6 cycles per SIMD when 8 waves share it, other VALU in 4 cycles)
+                # weighted with the kernel's own instruction mix (profiles/r04_valu_mix.json, from
+                # the shipped code object: tools/kernel_disasm.py)
+                valu = vi * VALU_CYCLES / (SIMDS * CLOCK_HZ * kms * 1e-3)
             return {"value": reg["proposals"] / reg["el"], "unit": "evals/s",
                     "steps": reg["steps"], "blocks": reg["blocks"], "timed_s": reg["el"],
                     "ms_per_step": reg["el"] / (reg["steps"] * reg["blocks"]) * 1e3,
@@ -475,7 +523,8 @@ def main():
                     "roofline_frac": ach / HBM_PEAK_GBS, "valu_frac": valu,
                     "valu_wave_insts_per_launch": vi,
                     "cost_evals_per_s": reg["cost_evals"] / reg["el"],
-                    "accept_rate": reg["accepted"] / max(1, reg["proposals"])}
+                    "accept_rate": reg["accepted"] / max(1, reg["proposals"]),
+                    **({"exchange": reg["exchange"]} if reg.get("exchange") else {})}
 
         by_nt = {str(nt_r): summarise(nt_r, reg) for nt_r, reg in regions.items()}
         h = by_nt[str(nt_head)]
@@ -539,11 +588,12 @@ def main():
                          "algorithmic_bytes_per_launch": h["algorithmic_bytes_per_launch"],
                          "valu": {"frac": h["valu_frac"],
                                   "wave_insts_per_launch": h["valu_wave_insts_per_launch"],
-                                  "formula": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x "
-                                             "kernel time): the binding resource (state is "
-                                             "register-resident, HBM traffic is ~3 % of the "
-                                             "algorithmic bytes)",
-                                  "source": pmc_file}},
+                                  "issue_cycles_per_inst": VALU_CYCLES,
+                                  "formula": "SQ_INSTS_VALU x the mix-weighted measured issue cycles per "
+                                             "instruction / (1024 SIMDs x 2.4 GHz x kernel time): the "
+                                             "binding resource (state is register-resident, HBM traffic "
+                                             "is ~3 % of the algorithmic bytes)",
+                                  "source": pmc_file, "mix_source": VALU_MIX_FILE}},
             "by_ntransitions": by_nt,
         }
         out.update(extra)

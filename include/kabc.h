@@ -343,6 +343,15 @@ kabc_status_t kabc_ais_set_timing(kabc_ais_t* h, int32_t max_launches);
  * by `stride` (a pair per launch adds ~3 us of marker overhead to each figure); default 1 */
 kabc_status_t kabc_ais_set_timing_stride(kabc_ais_t* h, int32_t stride);
 double kabc_ais_kernel_ms(kabc_ais_t* h, int64_t* nlaunches);
+/* Exchange diagnostics of a sharded handle (kabc_ais_create_dist, one process per GPU) over the
+ * half-generations kabc_ais_advance has run since kabc_ais_set_timing (at most 128 of them),
+ * averages in MICROSECONDS per half-generation: out[0] compute -- the half's kernels on the context
+ * stream; out[1] exchange -- the all-gather(s) of the half on the stream they run on (summed over
+ * the exchange chunks); out[2] exposed -- how long the context stream then waits until the
+ * gathered half is available to it (equal to the exchange when there is one chunk, what the
+ * pipeline could not hide otherwise); out[3] the number of exchange chunks K.  Rewinds.  This is
+ * what tells a slow collective from a slow kernel in a multi-GPU run (bench.py prints it). */
+kabc_status_t kabc_ais_exchange_us(kabc_ais_t* h, double out[4]);
 /* Test hook: record (move, accepted, a, b, c, cost_evaluated) as 6 int32 per
  * walker and sub-step of the NEXT generation ([N_owned][ntransitions][6], walker-id
  * order; partner ids are row indices inside the complementary half).  0 disables. */

@@ -148,6 +148,7 @@ PROTOTYPES = {
     "kabc_ais_set_timing": (C.c_int, [VP, C.c_int32]),
     "kabc_ais_set_timing_stride": (C.c_int, [VP, C.c_int32]),
     "kabc_ais_kernel_ms": (C.c_double, [VP, C.POINTER(C.c_int64)]),
+    "kabc_ais_exchange_us": (C.c_int, [VP, c_double_p]),
     "kabc_ais_set_debug": (C.c_int, [VP, C.c_int32]),
     "kabc_ais_get_debug": (C.c_int, [VP, C.POINTER(C.c_int32), C.c_int64]),
     "kabc_ais_destroy": (C.c_int, [VP]),

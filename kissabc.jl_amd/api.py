@@ -268,6 +268,15 @@ class AisEnsemble:
         ms = _lib.load().kabc_ais_kernel_ms(self._h, C.byref(n))
         return ms, n.value
 
+    def exchange_us(self):
+        """kabc_ais_exchange_us: (compute, exchange, exposed) microseconds per half-generation and
+        the number of exchange chunks, over the half-generations timed since set_timing (sharded
+        handles; zeros otherwise)"""
+        out = (C.c_double * 4)()
+        _lib.check(_lib.load().kabc_ais_exchange_us(self._h, out))
+        return {"compute_us_per_half": out[0], "exchange_us_per_half": out[1],
+                "exposed_us_per_half": out[2], "chunks": int(out[3])}
+
     def set_debug(self, ntransitions):
         _lib.check(_lib.load().kabc_ais_set_debug(self._h, int(ntransitions)))
 

@@ -155,7 +155,21 @@ struct kabc_ais {
     std::vector<int32_t> ev_n;  // launches bracketed by pair i
     size_t ev_used;
     kabc_stats_t last;  // counters at the last kabc_ais_advance return
+    // exchange diagnostics of a sharded handle (kabc_ais_exchange_us): per timed half-generation
+    // three events on the context stream -- e0 the half's kernels start, e1 they have ended, e2 the
+    // gathered half is available to the stream -- and a pair per exchange chunk on the stream the
+    // gather runs on
+    struct XT {
+        hipEvent_t e0, e1, e2;
+        hipEvent_t x0[KABC_MAX_EXCHANGE_CHUNKS], x1[KABC_MAX_EXCHANGE_CHUNKS];
+        bool closed;
+    };
+    std::vector<XT> xt;
+    size_t xt_used;
+    int xt_open;  // entry whose e2 is still to be recorded (pipelined exchange), else -1
 };
+
+static constexpr size_t kXtHalves = 128;
 
 static kabc_status_t check_handle(const kabc_ais_t* h) {
     if (!h) {
@@ -432,6 +446,8 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->open_count = 0;
     h->ev_used = 0;
     h->last = kabc_stats_t{0, 0, 0};
+    h->xt_used = 0;
+    h->xt_open = -1;
     h->d_cost_params = h->d_cost_data = nullptr;
     h->cost_ndata = m->cost.ndata;
     h->own_halves = (ext0 == nullptr);
@@ -920,20 +936,49 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
     if (!out_samples || ngenerations == 0) {
         for (int64_t g = 0; g < ngenerations; ++g) {
             for (int hf = 0; hf < 2; ++hf) {
+                // exchange diagnostics: this half-generation is timed while entries are left
+                kabc_ais::XT* xt = (h->comm && h->timing && h->xt_used < h->xt.size()) ? &h->xt[h->xt_used] : nullptr;
                 if (!h->comm || h->xk == 1) {
+                    if (xt) keep(hipEventRecord(xt->e0, s) == hipSuccess ? KABC_OK : KABC_ERR_DEVICE);
                     if (local_err == KABC_OK) keep(kabc_ais_half_generation(h, hf, ntransitions, nullptr));
+                    if (xt) {
+                        (void)timing_close_pair(h);  // (the kernel pair ends before the collective)
+                        (void)hipEventRecord(xt->e1, s);
+                        (void)hipEventRecord(xt->x0[0], s);
+                    }
                     // the one collective of the design: rebuild half hf on every rank
                     if (h->comm)
                         keep(comm_allgather_inplace(h->comm, h->d_half[hf], (size_t)h->cper[hf] * h->D));
+                    if (xt) {
+                        (void)hipEventRecord(xt->x1[0], s);
+                        (void)hipEventRecord(xt->e2, s);
+                        xt->closed = true;
+                        ++h->xt_used;
+                    }
                 } else {
                     // pipelined: the kernels read the half gathered last (fence), then chunk k
                     // is gathered on the exchange stream while the kernels of chunk k + 1 run
                     keep(comm_exchange_fence(h->comm));
+                    if (h->xt_open >= 0) {  // the previous half's gathers have landed for this stream
+                        (void)hipEventRecord(h->xt[(size_t)h->xt_open].e2, s);
+                        h->xt[(size_t)h->xt_open].closed = true;
+                        h->xt_open = -1;
+                    }
+                    if (xt) (void)hipEventRecord(xt->e0, s);
                     for (int k = 0; k < h->xk; ++k) {
                         if (local_err == KABC_OK)
                             keep(launch_half_seg(h, hf, h->seg[hf][k], ntransitions, nullptr));
+                        if (xt && k == h->xk - 1) {
+                            (void)timing_close_pair(h);
+                            (void)hipEventRecord(xt->e1, s);
+                        }
                         keep(comm_exchange_chunk(h->comm, chunk_base(h, hf, k),
-                                                 (size_t)h->cper[hf] * h->D, k));
+                                                 (size_t)h->cper[hf] * h->D, k, xt ? xt->x0[k] : nullptr,
+                                                 xt ? xt->x1[k] : nullptr));
+                    }
+                    if (xt) {
+                        h->xt_open = (int)h->xt_used;
+                        ++h->xt_used;
                     }
                 }
                 if (local_err && !h->comm) return local_err;
@@ -941,6 +986,11 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
             if (local_err == KABC_OK) h->t += (uint64_t)ntransitions;
         }
         if (h->comm && h->xk > 1) keep(comm_exchange_fence(h->comm));
+        if (h->xt_open >= 0) {
+            (void)hipEventRecord(h->xt[(size_t)h->xt_open].e2, s);
+            h->xt[(size_t)h->xt_open].closed = true;
+            h->xt_open = -1;
+        }
         if (h->comm) {
             uint64_t bad = local_err != KABC_OK;
             const kabc_status_t st = kabc_comm_allreduce_sum_u64(h->comm, &bad, 1);
@@ -1266,6 +1316,71 @@ kabc_status_t kabc_ais_set_timing(kabc_ais_t* h, int32_t max_launches) {
         h->ev.push_back(e);
     }
     h->ev_n.assign((size_t)(max_launches > 0 ? max_launches : 0), 0);
+    // exchange diagnostics of a sharded handle: up to kXtHalves half-generations
+    for (kabc_ais::XT& x : h->xt) {
+        (void)hipEventDestroy(x.e0);
+        (void)hipEventDestroy(x.e1);
+        (void)hipEventDestroy(x.e2);
+        for (int k = 0; k < h->xk; ++k) {
+            (void)hipEventDestroy(x.x0[k]);
+            (void)hipEventDestroy(x.x1[k]);
+        }
+    }
+    h->xt.clear();
+    h->xt_used = 0;
+    h->xt_open = -1;
+    if (h->comm && max_launches > 0) {
+        const size_t nh = (size_t)max_launches < kXtHalves ? (size_t)max_launches : kXtHalves;
+        for (size_t i = 0; i < nh; ++i) {
+            kabc_ais::XT x;
+            std::memset(&x, 0, sizeof x);
+            KABC_HIP_CHECK(hipEventCreate(&x.e0));
+            KABC_HIP_CHECK(hipEventCreate(&x.e1));
+            KABC_HIP_CHECK(hipEventCreate(&x.e2));
+            for (int k = 0; k < h->xk; ++k) {
+                KABC_HIP_CHECK(hipEventCreate(&x.x0[k]));
+                KABC_HIP_CHECK(hipEventCreate(&x.x1[k]));
+            }
+            h->xt.push_back(x);
+        }
+    }
+    return KABC_OK;
+}
+
+kabc_status_t kabc_ais_exchange_us(kabc_ais_t* h, double out[4]) {
+    if (check_handle(h) || !out) return KABC_ERR_INVALID_ARG;
+    out[0] = out[1] = out[2] = 0.0;
+    out[3] = (double)h->xk;
+    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+    KABC_HIP_CHECK(hipStreamSynchronize(h->ctx->stream));
+    if (h->comm && h->comm->xstream) KABC_HIP_CHECK(hipStreamSynchronize(h->comm->xstream));
+    double comp = 0.0, exch = 0.0, expo = 0.0;
+    int64_t n = 0;
+    for (size_t i = 0; i < h->xt_used; ++i) {
+        const kabc_ais::XT& x = h->xt[i];
+        if (!x.closed) continue;
+        float c = 0.f, e = 0.f, xs = 0.f;
+        if (hipEventElapsedTime(&c, x.e0, x.e1) != hipSuccess || hipEventElapsedTime(&e, x.e1, x.e2) != hipSuccess)
+            continue;
+        bool ok = true;
+        for (int k = 0; k < h->xk && ok; ++k) {
+            float g = 0.f;
+            ok = hipEventElapsedTime(&g, x.x0[k], x.x1[k]) == hipSuccess;
+            xs += g;
+        }
+        if (!ok) continue;
+        comp += c;
+        expo += e;
+        exch += xs;
+        ++n;
+    }
+    for (size_t i = 0; i < h->xt_used; ++i) h->xt[i].closed = false;
+    h->xt_used = 0;
+    if (n) {
+        out[0] = comp / (double)n * 1e3;
+        out[1] = exch / (double)n * 1e3;
+        out[2] = expo / (double)n * 1e3;
+    }
     return KABC_OK;
 }
 
@@ -1347,6 +1462,15 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h) {
     if (h->d_dbg) (void)hipFree(h->d_dbg);
     if (h->d_aux) (void)hipFree(h->d_aux);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+    for (kabc_ais::XT& x : h->xt) {
+        (void)hipEventDestroy(x.e0);
+        (void)hipEventDestroy(x.e1);
+        (void)hipEventDestroy(x.e2);
+        for (int k = 0; k < h->xk; ++k) {
+            (void)hipEventDestroy(x.x0[k]);
+            (void)hipEventDestroy(x.x1[k]);
+        }
+    }
     delete h;
     return KABC_OK;
 }

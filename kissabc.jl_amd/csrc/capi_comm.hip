@@ -297,7 +297,7 @@ kabc_status_t comm_allgather_many(kabc_comm* c, double** bases, const size_t* co
 }
 
 // ---- pipelined exchange ---------------------------------------------------------------
-kabc_status_t comm_exchange_chunk(kabc_comm* c, double* base, size_t count, int k) {
+kabc_status_t comm_exchange_chunk(kabc_comm* c, double* base, size_t count, int k, hipEvent_t t0, hipEvent_t t1) {
     if (c->single_process) {
         set_error("this communicator belongs to a single-process group: use the *_multi entry points");
         return KABC_ERR_INVALID_ARG;
@@ -307,9 +307,12 @@ kabc_status_t comm_exchange_chunk(kabc_comm* c, double* base, size_t count, int 
     if (kabc_status_t st = exchange_setup(c)) return st;
     KABC_HIP_CHECK(hipEventRecord(c->ev_chunk[k], c->ctx->stream));
     KABC_HIP_CHECK(hipStreamWaitEvent(c->xstream, c->ev_chunk[k], 0));
-    if (count == 0) return KABC_OK;
-    KABC_NCCL_CHECK(R, R->AllGather(base + (size_t)c->rank * count, base, count, ncclDouble,
-                                    (ncclComm_t)c->nccl, c->xstream));
+    // (t0 / t1: optional timing events around the gather on the exchange stream)
+    if (t0) KABC_HIP_CHECK(hipEventRecord(t0, c->xstream));
+    if (count != 0)
+        KABC_NCCL_CHECK(R, R->AllGather(base + (size_t)c->rank * count, base, count, ncclDouble,
+                                        (ncclComm_t)c->nccl, c->xstream));
+    if (t1) KABC_HIP_CHECK(hipEventRecord(t1, c->xstream));
     return KABC_OK;
 }
 

@@ -107,7 +107,8 @@ kabc_status_t comm_allgather_inplace_multi(kabc_comm** comms, double** bases, in
 // kernels of chunk k + 1 run on the context stream ------------------------------------
 // records "the kernels of chunk k are done" on the context stream(s) and gathers the chunk
 // ([world][count] doubles at base / bases[i]) on the exchange stream(s) behind it
-kabc_status_t comm_exchange_chunk(kabc_comm* c, double* base, size_t count, int k);
+kabc_status_t comm_exchange_chunk(kabc_comm* c, double* base, size_t count, int k, hipEvent_t t0 = nullptr,
+                                  hipEvent_t t1 = nullptr);
 kabc_status_t comm_exchange_chunk_multi(kabc_comm** comms, double** bases, int n, size_t count, int k);
 // the context stream(s) wait until every gather issued so far has landed (before the next
 // half-generation reads the gathered half; `all_ranks`: also until no peer still reads this
