@@ -3,7 +3,8 @@ processes repeat C4 `smc` on the persistent loop kernel for a few seconds beside
 memory system busy with AIS generations; every result must equal the process's first.  A short
 run only catches a gross regression of the loop kernel's device-wide barrier -- the race this
 round's XCD-aware barrier had needed ~10^4 contended calls to show (profiles/r03_contention.txt) --
-but it keeps the tool, and the multi-process set-up it needs, exercised."""
+but it keeps the tool, and the multi-process set-up it needs, exercised; the 60-second
+three-process soak below is the one that counts."""
 import os
 import subprocess
 import sys
@@ -19,3 +20,25 @@ def test_smc_loop_kernel_is_deterministic_under_gpu_sharing(gpu_ctx):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DIFFERING" not in r.stdout, r.stdout + r.stderr
     assert r.stdout.count("all identical") == 3
+
+
+def test_contention_soak_three_processes_sixty_seconds(gpu_ctx):
+    """The soak that finds what parity tests cannot (a store-visibility hole in a hand-rolled
+    device-wide barrier shows under contention only): THREE processes repeat C4 `smc` on the
+    persistent loop kernel for 60 s beside a fourth that saturates the memory system with AIS
+    generations; every one of the several hundred results must equal its process's first.  Fresh
+    child processes (spawned, never exec'ed over a process that holds the GPU)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "contention_stress.py"), "smc_loop", "3", "ais", "60"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "DIFFERING" not in r.stdout, r.stdout + r.stderr
+    assert r.stdout.count("all identical") == 4
+    runs = [int(ln.split()[2]) for ln in r.stdout.splitlines() if ln.startswith("smc_loop runs")]
+    assert len(runs) == 3 and sum(runs) >= 300, r.stdout     # (a stalled process would pass vacuously)
+
+
+def test_pipelined_exchange_is_deterministic_under_gpu_sharing(gpu_ctx):
+    """four emulated ranks with three exchange chunks each (second stream, event chains) beside a
+    process running the kernel-per-phase smc path: 15 s"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "contention_stress.py"), "sharded", "2", "smc_kernels", "15"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DIFFERING" not in r.stdout, r.stdout + r.stderr
