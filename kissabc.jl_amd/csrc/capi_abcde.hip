@@ -4,8 +4,6 @@
 #include <cmath>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
-
 #define KABC_ABCDE_SINGLE_UNIT 1
 #include "abcde_kernels.hpp"
 #include "host_common.hpp"
@@ -37,10 +35,6 @@ static AbcdeLaunchFn pick_gen(int D, std::integer_sequence<int, Ds...>) {
 // ---- rank structure (the donor draw was O(N) per particle) ------------------------
 constexpr int64_t kRankMinN = 4096;  // below this the two scans are cheaper than building it
 
-__global__ void __launch_bounds__(256) wm_iota_kernel(unsigned* v, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) v[i] = (unsigned)i;
-}
 // bit b of every element of the sequence entering level b, packed 64 per word
 __global__ void __launch_bounds__(256) wm_bits_kernel(const unsigned* seq, int64_t n, int b,
                                                       unsigned long long* bits, int64_t words) {
@@ -75,35 +69,179 @@ __global__ void __launch_bounds__(1024) wm_count_kernel(const unsigned long long
     if (threadIdx.x == 0) *nz = (unsigned)n - s_run;
 }
 
+// ---- the cost order: an LSD radix sort of (cost key, particle index) written for this path ---
+// (replaces hipcub::DeviceRadixSort: no device library call is left on the path).  8-bit digits over
+// the order-preserving 64-bit key of the cost, three launches per digit:
+//   rs_hist    per tile of 2048 keys, the count of every digit value          counts[256][G]
+//   rs_scan    exclusive prefix over (digit value, tile) -- one workgroup
+//   rs_scatter every key to offset[digit][tile] + its STABLE rank inside the tile: rounds of 256
+//              consecutive positions; inside a wavefront the lanes holding the same digit are found
+//              with eight ballots (match-any), the leader of each group publishes the group's size,
+//              earlier wavefronts of the round and earlier rounds of the tile are added from LDS
+// LSD needs every pass stable; nothing here depends on the order atomics retire in.
+constexpr int kRsBlock = 256;
+constexpr int kRsItems = 8;
+constexpr int kRsTile = kRsBlock * kRsItems;
+constexpr int kRsBuckets = 256;
+
+__device__ __forceinline__ unsigned long long rs_key_of(double x) {  // total order; -0.0 folds onto +0.0
+    const unsigned long long u = kabc_bits(x + 0.0);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double rs_val_of(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffULL) : ~k;
+    return kabc_from_bits(u);
+}
+__global__ void __launch_bounds__(256) rs_keys_kernel(const double* delta, int64_t n, unsigned long long* keys,
+                                                      unsigned* vals) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        keys[i] = rs_key_of(delta[i]);
+        vals[i] = (unsigned)i;
+    }
+}
+__global__ void __launch_bounds__(256) rs_values_kernel(const unsigned long long* keys, int64_t n, double* sorted) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) sorted[i] = rs_val_of(keys[i]);
+}
+__global__ void __launch_bounds__(kRsBlock) rs_hist_kernel(const unsigned long long* keys, int64_t n, int shift,
+                                                           unsigned* counts, unsigned G) {
+    __shared__ unsigned s_h[kRsBuckets];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kRsTile;
+#pragma unroll
+    for (int r = 0; r < kRsItems; ++r) {
+        const int64_t p = base + (int64_t)r * kRsBlock + threadIdx.x;
+        if (p < n) atomicAdd(&s_h[(unsigned)(keys[p] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    counts[(size_t)threadIdx.x * G + blockIdx.x] = s_h[threadIdx.x];
+}
+// exclusive prefix, in place, over m = 256 * G counts in (digit value, tile) order
+__global__ void __launch_bounds__(1024) rs_scan_kernel(unsigned* counts, int64_t m) {
+    __shared__ unsigned s_w[16];
+    __shared__ unsigned s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int64_t i0 = 0; i0 < m; i0 += 1024) {
+        const int64_t i = i0 + threadIdx.x;
+        const unsigned c = i < m ? counts[i] : 0u;
+        const unsigned incl = wave_scan_incl(c);
+        if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        unsigned off = s_run, tot = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (q < (int)(threadIdx.x >> 6)) off += s_w[q];
+            tot += s_w[q];
+        }
+        if (i < m) counts[i] = off + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 0) s_run += tot;
+        __syncthreads();
+    }
+}
+__global__ void __launch_bounds__(kRsBlock) rs_scatter_kernel(const unsigned long long* kin, const unsigned* vin,
+                                                              unsigned long long* kout, unsigned* vout, int64_t n,
+                                                              int shift, const unsigned* offsets, unsigned G) {
+    __shared__ unsigned s_off[kRsBuckets];                  // next free slot of every digit value
+    __shared__ unsigned s_wc[kRsBlock / kWave][kRsBuckets];  // this round's group sizes per wavefront
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
+    s_off[tid] = offsets[(size_t)tid * G + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < kRsBlock / kWave; ++w) s_wc[w][tid] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kRsTile;
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < kRsItems; ++r) {
+        const int64_t p = base + (int64_t)r * kRsBlock + tid;
+        const bool in = p < n;
+        const unsigned long long key = in ? kin[p] : 0ull;
+        const unsigned val = in ? vin[p] : 0u;
+        const unsigned d = (unsigned)(key >> shift) & 255u;
+        // lanes of this wavefront with the same digit (and in range)
+        unsigned long long peers = __ballot(in);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long m = __ballot((d >> b) & 1u);
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const unsigned before = (unsigned)__popcll(peers & below);
+        if (in && before == 0u) s_wc[wid][d] = (unsigned)__popcll(peers);  // the group's leader
+        __syncthreads();
+        if (in) {
+            unsigned dst = s_off[d] + before;
+            for (int w = 0; w < wid; ++w) dst += s_wc[w][d];
+            kout[dst] = key;
+            vout[dst] = val;
+        }
+        __syncthreads();
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < kRsBlock / kWave; ++w) {
+            t += s_wc[w][tid];
+            s_wc[w][tid] = 0;
+        }
+        s_off[tid] += t;
+        __syncthreads();
+    }
+}
+// stable partition of a wavelet-matrix level by its bit: zeros first, then ones, each in order --
+// straight from the level's own rank words (wm_bits / wm_count above)
+__global__ void __launch_bounds__(256) wm_partition_kernel(const unsigned* sin, unsigned* sout, int64_t n, int b,
+                                                           const unsigned long long* bits, const unsigned* cnt,
+                                                           const unsigned* nz) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const unsigned v = sin[p];
+    const int64_t w = p >> 6;
+    const unsigned l = (unsigned)(p & 63);
+    const unsigned long long m = l ? (~0ull >> (64 - l)) : 0ull;
+    const unsigned ones = cnt[w] + (unsigned)__popcll(bits[w] & m);
+    sout[((v >> b) & 1u) ? (int64_t)*nz + ones : p - ones] = v;
+}
+
 struct RankStructure {
     double* sorted = nullptr;
-    unsigned *iota = nullptr, *seq[2] = {nullptr, nullptr}, *cnt = nullptr, *nz = nullptr;
+    unsigned *seq[2] = {nullptr, nullptr}, *cnt = nullptr, *nz = nullptr;
     unsigned long long* bits = nullptr;
-    void* tmp = nullptr;
-    size_t tmp_bytes = 0;
+    unsigned long long* keys[2] = {nullptr, nullptr};
+    unsigned* vals[2] = {nullptr, nullptr};
+    unsigned* counts = nullptr;  // [256][G]
+    unsigned G = 0;
     int levels = 0;
     int64_t words = 0;
 };
 
 // sorted costs + wavelet matrix of the cost-sorted particle order, all on stream s
 static hipError_t build_rank(const RankStructure& R, const double* delta, int64_t N, hipStream_t s) {
-    size_t tb = R.tmp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(R.tmp, tb, delta, R.sorted, R.iota, R.seq[0],
-                                                      (int)N, 0, 64, s);
+    const unsigned g256 = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(rs_keys_kernel, dim3(g256), dim3(256), 0, s, delta, N, R.keys[0], R.vals[0]);
     int cur = 0;
-    const unsigned g256 = (unsigned)((R.words * 64 + 255) / 256);
-    for (int b = R.levels - 1; b >= 0 && e == hipSuccess; --b) {
+    for (int shift = 0; shift < 64; shift += 8) {
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(R.G), dim3(kRsBlock), 0, s, R.keys[cur], N, shift, R.counts, R.G);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(1), dim3(1024), 0, s, R.counts, (int64_t)kRsBuckets * R.G);
+        // (the last pass writes the particle order where the wavelet matrix starts from)
+        unsigned* vout = shift == 56 ? R.seq[0] : R.vals[1 - cur];
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(R.G), dim3(kRsBlock), 0, s, R.keys[cur], R.vals[cur],
+                           R.keys[1 - cur], vout, N, shift, R.counts, R.G);
+        cur ^= 1;
+    }
+    hipLaunchKernelGGL(rs_values_kernel, dim3(g256), dim3(256), 0, s, R.keys[cur], N, R.sorted);
+    int sc = 0;
+    const unsigned gw = (unsigned)((R.words * 64 + 255) / 256);
+    for (int b = R.levels - 1; b >= 0; --b) {
         unsigned long long* bits = R.bits + (size_t)b * R.words;
-        hipLaunchKernelGGL(wm_bits_kernel, dim3(g256), dim3(256), 0, s, R.seq[cur], N, b, bits, R.words);
+        hipLaunchKernelGGL(wm_bits_kernel, dim3(gw), dim3(256), 0, s, R.seq[sc], N, b, bits, R.words);
         hipLaunchKernelGGL(wm_count_kernel, dim3(1), dim3(1024), 0, s, bits, R.words, N,
                            R.cnt + (size_t)b * R.words, R.nz + b);
         if (b > 0) {  // stable partition by bit b: the sequence entering the next level
-            tb = R.tmp_bytes;
-            e = hipcub::DeviceRadixSort::SortKeys(R.tmp, tb, R.seq[cur], R.seq[1 - cur], (int)N, b, b + 1, s);
-            cur ^= 1;
+            hipLaunchKernelGGL(wm_partition_kernel, dim3(g256), dim3(256), 0, s, R.seq[sc], R.seq[1 - sc], N, b, bits,
+                               R.cnt + (size_t)b * R.words, R.nz + b);
+            sc ^= 1;
         }
     }
-    return e == hipSuccess ? hipGetLastError() : e;
+    return hipGetLastError();
 }
 
 }  // namespace kabc
@@ -277,21 +415,17 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         while ((1ll << R.levels) < N) ++R.levels;
         R.words = (N + 64) / 64;  // one word past position N (rank queries at p = N)
         KABC_HIP_CHECK(alloc((void**)&R.sorted, sizeof(double) * N));
-        KABC_HIP_CHECK(alloc((void**)&R.iota, sizeof(unsigned) * N));
         KABC_HIP_CHECK(alloc((void**)&R.seq[0], sizeof(unsigned) * N));
         KABC_HIP_CHECK(alloc((void**)&R.seq[1], sizeof(unsigned) * N));
         KABC_HIP_CHECK(alloc((void**)&R.bits, sizeof(unsigned long long) * R.levels * R.words));
         KABC_HIP_CHECK(alloc((void**)&R.cnt, sizeof(unsigned) * R.levels * R.words));
         KABC_HIP_CHECK(alloc((void**)&R.nz, sizeof(unsigned) * R.levels));
-        size_t t1 = 0, t2 = 0;
-        KABC_HIP_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, t1, (const double*)nullptr, (double*)nullptr,
-                                                          (const unsigned*)nullptr, (unsigned*)nullptr, (int)N,
-                                                          0, 64, s));
-        KABC_HIP_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, t2, (const unsigned*)nullptr,
-                                                         (unsigned*)nullptr, (int)N, 0, 1, s));
-        R.tmp_bytes = t1 > t2 ? t1 : t2;
-        KABC_HIP_CHECK(alloc(&R.tmp, R.tmp_bytes));
-        hipLaunchKernelGGL(wm_iota_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, R.iota, N);
+        R.G = (unsigned)((N + kRsTile - 1) / kRsTile);
+        for (int b = 0; b < 2; ++b) {
+            KABC_HIP_CHECK(alloc((void**)&R.keys[b], sizeof(unsigned long long) * N));
+            KABC_HIP_CHECK(alloc((void**)&R.vals[b], sizeof(unsigned) * N));
+        }
+        KABC_HIP_CHECK(alloc((void**)&R.counts, sizeof(unsigned) * (size_t)kRsBuckets * R.G));
         A.sorted_delta = R.sorted;
         A.wm_bits = R.bits;
         A.wm_cnt = R.cnt;
