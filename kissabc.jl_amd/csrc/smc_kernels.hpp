@@ -788,6 +788,16 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
     const int64_t i = wg * kSmcBlock + threadIdx.x;
     unsigned long long n_eval = 0, n_acc = 0, n_prop = 0;
     if (A.ctrl->done || !A.ctrl->pass_open) return;  // uniform no-op
+    // the log / sin-cos table of the arithmetic contract in LDS: a particle's pass takes one log, one
+    // Box-Muller pair and, for a simulator cost, several more -- each a dependent gather from the
+    // table; with two waves per SIMD (the rows of a 16-parameter particle fill the registers) the
+    // L2 round trip of the table in global memory is not hidden.  Same values.
+    __shared__ __attribute__((aligned(16))) double s_logtab[KABC_MATH_TAB_WORDS];
+    static_assert(KABC_MATH_TAB_WORDS % kSmcBlock == 0, "the workgroup stages the table in equal parts");
+#pragma unroll
+    for (int j = 0; j < KABC_MATH_TAB_WORDS / kSmcBlock; ++j)
+        s_logtab[threadIdx.x + j * kSmcBlock] = kabc_log_tab[threadIdx.x + j * kSmcBlock];
+    __syncthreads();
     const int cur = A.ctrl->cur;
     const bool gather = A.ctrl->use_ridx != 0;
     const uint64_t pass = A.ctrl->pass + 1u;
@@ -820,7 +830,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
             b += (b >= lo);
             b += (b >= hi);
             double z0, z1;
-            kabc_normal_pair(kabc_lo64(B1), kabc_hi64(B1), &z0, &z1);
+            kabc_normal_pair_tab(kabc_lo64(B1), kabc_hi64(B1), &z0, &z1, s_logtab);
             const double s = A.max_stretch * z0 / kabc_sqrt((double)D);
             const int64_t sa = remap ? (int64_t)A.cidx[(unsigned)a % ess] : a;
             const int64_t sb = remap ? (int64_t)A.cidx[(unsigned)b % ess] : b;
@@ -832,14 +842,14 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
                 const double W = (tb[k] - ta[k]) * s;
                 prop[k] = th[k] + W;
             }
-            const double lprob = kabc_log(kabc_u01(kabc_lo64(B2)));
+            const double lprob = kabc_log_t(kabc_u01(kabc_lo64(B2)), s_logtab);
             n_prop = 1;
-            const double lpp = factored_logpdf_push<D, SIMPLE>(A.prior, prop, xp);
+            const double lpp = factored_logpdf_push<D, SIMPLE>(A.prior.c, prop, xp, s_logtab);
             if (!(lpp < 0.0 && !kabc_isfinite(lpp))) {  // :173
                 double lM = lpp - lpi + 0.0;
                 if (!(lM < 0.0)) lM = (lM != lM) ? lM : 0.0;
                 if (lprob < lM) {
-                    kabc_cost_rng_t rng = {A.seed, pass, w, KABC_DOM_SMC_COST, 0u};
+                    kabc_cost_rng_t rng = {A.seed, pass, w, KABC_DOM_SMC_COST, 0u, 0u, nullptr, s_logtab};
                     if (A.aux) {
                         const int64_t sl = A.aux_ring > 1 ? (int64_t)(pass % (uint64_t)A.aux_ring) : 0;
                         rng.aux = A.aux + sl * (int64_t)kabc_cost_aux_words(COST) * A.N + i;

@@ -25,7 +25,10 @@ if __name__ == "__main__":
     prior, cost = c4_problem()
     N = 32768
     kw = dict(nparticles=N, alpha=0.95, epstol=0.05, seed=1)
+    if "--spec" in sys.argv:   # kernels specialised for this model (kabc_compile_model)
+        k.compile_model(prior, cost, families=2)
     k.smc(prior, cost, **kw)  # warm-up
+    k.smc(prior, cost, **kw)
     t0 = time.perf_counter()
     r = k.smc(prior, cost, return_array=True, **kw)
     wall = time.perf_counter() - t0
