@@ -143,14 +143,17 @@ mode = {mode!r}
 if mode == "rank":          # one process per GPU: unique id -> ncclCommInitRank
     comm = k.Comm.from_env()
     ens = k.AisEnsemble(model, 1024, seed=11, comm=comm).init()
+    ens.set_timing(32, stride=1)
     ens.advance(5, 7)
+    xch = ens.exchange_us()      # kabc_ais_exchange_us: hipEvents around kernels and all-gathers
+    ens.set_timing(0)
     x = ens.ensemble()
     st = ens.stats()
     red = comm.allreduce_sum([st["proposals"], 3])
     mx = comm.allreduce_max([1.5, -2.0])
     comm.barrier()
     ens.close(); comm.close()
-    extra = {{"red": red, "mx": mx}}
+    extra = {{"red": red, "mx": mx, "xch": xch}}
 elif mode == "all":         # one process: ncclCommInitAll + grouped all-gather
     grp = k.EnsembleGroup(model, 1024, seed=11, devices=[0], backend="rccl").init()
     grp.advance(5, 7)
@@ -188,6 +191,10 @@ def test_rccl_world1_through_the_c_abi(tmp_path):
     assert np.array_equal(x1, x0)
     assert s1["proposals"] == s0["proposals"] == 1024 * 5 * 7 and s1["accepted"] == s0["accepted"]
     assert s1["red"] == [1024 * 5 * 7, 3] and s1["mx"] == [1.5, -2.0]
+    # the exchange diagnostics of the first multi-GPU run exist at world 1 already
+    xc = s1["xch"]
+    assert xc["chunks"] == 1 and xc["compute_us_per_half"] > 1.0 and xc["exchange_us_per_half"] > 0.0
+    assert 0.0 <= xc["exposed_us_per_half"] < 1e4
     x2, s2 = _run_child(tmp_path, "all")
     assert np.array_equal(x2, x0) and s2["accepted"] == s0["accepted"]
 
@@ -199,6 +206,7 @@ def test_rccl_world1_pipelined_chunks(tmp_path):
     x1, s1 = _run_child(tmp_path, "rank", KABC_EXCHANGE_CHUNKS="3")
     assert np.array_equal(x1, x0) and s1["accepted"] == s0["accepted"]
     assert s1["red"] == [1024 * 5 * 7, 3]
+    assert s1["xch"]["chunks"] == 3 and s1["xch"]["exchange_us_per_half"] > 0.0
     x2, s2 = _run_child(tmp_path, "all", KABC_EXCHANGE_CHUNKS="4")
     assert np.array_equal(x2, x0) and s2["accepted"] == s0["accepted"]
 
@@ -206,7 +214,7 @@ def test_rccl_world1_pipelined_chunks(tmp_path):
 def _bench(extra_env, launcher):
     env = dict(os.environ, KABC_FORCE_COLLECTIVE="1", **extra_env)
     cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1",
-                      "--no-cpu-baseline", "--min-seconds", "0.05"]
+                      "--no-cpu-baseline", "--min-seconds", "0.05", "--headline-seconds", "0.05"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
@@ -220,6 +228,11 @@ def test_bench_with_communicator_env_launch():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["roofline"]["frac"] > 0
     assert set(d["by_ntransitions"]) == {"1", "16", "100"} and d["config"]["ntransitions"] == 100
     assert d["smc_c4"]["iterations"] > 100 and d["smc_c4"]["wall_ms"] > 0
+    # the fields the first multi-GPU run will be read by: exchange / exposed / compute per half, chunks
+    for nt in ("16", "100"):
+        x = d["by_ntransitions"][nt]["exchange"]
+        assert x["chunks"] >= 1 and x["compute_us_per_half"] > 0 and x["exchange_us_per_half"] > 0
+        assert x["exposed_us_per_half"] >= 0
 
 
 def test_bench_under_the_drivers_launcher():
