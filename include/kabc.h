@@ -228,7 +228,7 @@ kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family, int32_t D,
  * The snippet alone is compiled at once by hipRTC (errors come back here with the compiler's
  * message).  *out_kind (>= KABC_PRIOR_USER) goes into kabc_prior_t.kind.  A prior with such a
  * component has no prebuilt kernels: every entry point that receives one compiles the kernel
- * family it needs for that (prior kinds, cost) pair at first use (1-5 s, kept in an on-disk
+ * family it needs for that (prior kinds, cost) pair at first use (2-20 s by prior class, kept in an on-disk
  * cache of code objects: KABC_RTC_CACHE_DIR, default next to the library) -- the way a user
  * cost does.  length(prior) <= KABC_MAX_DIM for such priors. */
 kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32_t* out_kind);
