@@ -125,6 +125,11 @@ struct RecGeom {
 };
 
 // SoA record buffer of one chunk, lane-contiguous (conflict-free ds_read_b64)
+template <int Q>
+struct SubStepIx {  // a sub-step's index within its chunk, as a type
+    static constexpr int value = Q;
+};
+
 template <int D>
 struct ChunkRec {
     uint32_t mva[kChunk][kBatch];   // (move << 30) | partner row a
@@ -257,7 +262,7 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
             hi[k] = B.hi[k];
         }
         bool in = true;
-        if (B.dmask == 0u) {  // wave-uniform: all components continuous, push_p = identity
+        if (__builtin_amdgcn_readfirstlane((int)B.dmask) == 0) {  // wave-uniform (a scalar branch): all components continuous, push_p = identity
             if constexpr (D >= 2 && D <= 8) in = box_contains<D>(y, lo, hi);
             else {
 #pragma unroll
@@ -308,7 +313,7 @@ __device__ __forceinline__ void loglike(const PriorDev* __restrict__ P, const Bo
         bool in;
         double sum;
         if constexpr (PC == kPriorNormal) sum = gaussbox_logpdf_push<D, true, false>(GB, y, yp, in);
-        else if (GB.dmask == 0u) sum = gaussbox_logpdf_push<D, false, false>(GB, y, yp, in);  // wave-uniform
+        else if (__builtin_amdgcn_readfirstlane((int)GB.dmask) == 0) sum = gaussbox_logpdf_push<D, false, false>(GB, y, yp, in);  // wave-uniform
         else sum = gaussbox_logpdf_push<D, false, true>(GB, y, yp, in);
         lp = in ? sum : -KABC_INF;
     } else {
@@ -763,6 +768,9 @@ ais_half_kernel(const AisArgs A0) {
 #else
         const double* const cparams = A.cost_params;
 #endif
+        // wave-uniform conditions of the sub-step as SCALARS (evaluated on a lane value inside the
+        // `active` region they become lane masks: a v_cndmask + v_cmp + s_andn2 each, per sub-step)
+        const bool dbg_on = __builtin_amdgcn_readfirstlane(A.dbg != nullptr ? 1 : 0) != 0;
 #pragma unroll 1
         for (int c = 0; c < nchunks; ++c) {
             const int s0 = c * kChunk;
@@ -779,14 +787,22 @@ ais_half_kernel(const AisArgs A0) {
                 double r0a[D], r0b[D], r1a[kLate ? 1 : D], r1b[kLate ? 1 : D];
                 load_row<D>(comp_row(R.mva[0][lane] & 0x3fffffffu), r0a);
                 load_row<D>(comp_row(R.bb[0][lane]), r0b);
-                auto substep = [&](const int si, const double (&pa)[D], const double (&pb)[D],
+                // `si` is a compile-time constant (SubStepIx<q>): every LDS address of the
+                // sub-step is then (scalar buffer base + lane) + an immediate offset, not a
+                // handful of VALU shifts and adds on the consumer's issue stream per sub-step.
+                auto substep = [&](auto SI, const double (&pa)[D], const double (&pb)[D],
                                    double (&na)[D], double (&nb)[D]) __attribute__((always_inline)) {
+                    constexpr int si = decltype(SI)::value;
                     const uint64_t t = A.t0 + (uint64_t)(s0 + si);
                     // (1) every LDS word of this sub-step in one batch, plus the partner
                     //     ids of the next one
-                    const int sn = (si + 1 < ns) ? si + 1 : si;
+                    constexpr int sq = si + 1 < kChunk ? si + 1 : si;
                     const uint32_t mva = R.mva[si][lane];
-                    const uint32_t mvan = R.mva[sn][lane], bn = R.bb[sn][lane];
+                    uint32_t mvan = R.mva[sq][lane], bn = R.bb[sq][lane];
+                    if (sq >= ns) {  // (scalar) the chunk's last sub-step: no next one in it
+                        mvan = mva;
+                        bn = R.bb[si][lane];
+                    }
                     const double logu = R.logu[si][lane];
                     double zs[D + 1];
 #pragma unroll
@@ -900,7 +916,7 @@ ais_half_kernel(const AisArgs A0) {
                     // updates both: 8 v_mov_b64 per sub-step)
 #pragma unroll
                     for (int k = 0; k < D; ++k) asm volatile("" : "+v"(x[k]));
-                    if (A.dbg) {
+                    if (dbg_on) {  // (a scalar: one s_cbranch, no lane mask on the consumer's stream)
                         int32_t* d = A.dbg + (r * A.dbg_nt + (A.dbg_s0 + s0 + si)) * 6;
                         d[0] = (int32_t)move;
                         d[1] = acc ? 1 : 0;
@@ -913,15 +929,15 @@ ais_half_kernel(const AisArgs A0) {
                 // an error (src/types.jl:69-70) is sticky and reported after the launch; the
                 // remaining sub-steps still run (their result is discarded by the host), which
                 // keeps the loop bounds wave-uniform
+                static_assert(kChunk == 3, "the consumer spells out kChunk sub-steps");
                 if constexpr (kLate) {
-#pragma unroll 1
-                    for (int si = 0; si < ns; ++si) substep(si, r0a, r0b, r0a, r0b);
+                    substep(SubStepIx<0>{}, r0a, r0b, r0a, r0b);
+                    if (ns > 1) substep(SubStepIx<1>{}, r0a, r0b, r0a, r0b);
+                    if (ns > 2) substep(SubStepIx<2>{}, r0a, r0b, r0a, r0b);
                 } else {
-#pragma unroll 1
-                    for (int si = 0; si < ns; si += 2) {
-                        substep(si, r0a, r0b, r1a, r1b);
-                        if (si + 1 < ns) substep(si + 1, r1a, r1b, r0a, r0b);
-                    }
+                    substep(SubStepIx<0>{}, r0a, r0b, r1a, r1b);
+                    if (ns > 1) substep(SubStepIx<1>{}, r1a, r1b, r0a, r0b);
+                    if (ns > 2) substep(SubStepIx<2>{}, r0a, r0b, r1a, r1b);
                 }
             }
             KABC_TIMED_BARRIER();
