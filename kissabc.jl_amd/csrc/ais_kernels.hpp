@@ -177,10 +177,21 @@ struct BoxPrior {
 // v_cmp results disappear -- SALU instructions cost a wave an issue slot each, and these sat on
 // a dependent VALU -> SALU -> VALU chain (C3: 155.4 -> 149.6 us per launch at ntransitions =
 // 100).  Lanes still enabled at the end are inside the box; EXEC is restored before the
-// statement ends.  NaN compares false, as `y >= lo && y <= hi` does.
+// statement ends.  NaN compares false, as `y >= lo && y <= hi` does.  The surviving EXEC is handed
+// back as the boolean itself (inverse ballot): a flag register set under the narrowed EXEC and
+// compared afterwards was three VALU instructions more.
 #define KABC_BOXP(k) \
     "v_cmpx_ge_f64_e32 vcc, %[y" #k "], %[l" #k "]\n\tv_cmpx_le_f64_e32 vcc, %[y" #k "], %[h" #k "]\n\t"
 #define KABC_BOXO(k) [y##k] "v"(y[k]), [l##k] "v"(lo[k]), [h##k] "v"(hi[k])
+#if __has_builtin(__builtin_amdgcn_inverse_ballot_w64)
+#define KABC_BOX_ASM(BODY, ...)                                                                   \
+    unsigned long long saved, inside;                                                             \
+    asm volatile("s_mov_b64 %[sv], exec\n\t" BODY "s_mov_b64 %[in], exec\n\ts_mov_b64 exec, %[sv]" \
+                 : [in] "=&s"(inside), [sv] "=&s"(saved)                                          \
+                 : __VA_ARGS__                                                                    \
+                 : "vcc");                                                                        \
+    return __builtin_amdgcn_inverse_ballot_w64(inside);
+#else  // (a hipRTC older than the one hipcc ships with -- the copy bundled with PyTorch, say)
 #define KABC_BOX_ASM(BODY, ...)                                                                   \
     unsigned flag = 0;                                                                            \
     unsigned long long saved;                                                                     \
@@ -189,6 +200,7 @@ struct BoxPrior {
                  : __VA_ARGS__                                                                    \
                  : "vcc");                                                                        \
     return flag != 0u;
+#endif
 template <int D>
 __device__ __forceinline__ bool box_contains(const double* y, const double* lo, const double* hi);
 template <>
@@ -404,14 +416,16 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t
         // partner rows b (DE, walk) and c (walk): drawn for every lane, kept by the 3/7 that use
         // them -- 27 of 64 lanes is one pass either way, and the list indirection goes
         const kabc_u128_t B2 = kabc_stream_block(seed, w, t, 2u, KABC_DOM_AIS_MOVE);
-        int64_t b = (int64_t)kabc_index32(kabc_lo64(B2), (uint32_t)nc - 1u);
-        b += (b >= (int64_t)a);
-        const int64_t lo = (int64_t)a < b ? (int64_t)a : b, hi = (int64_t)a < b ? b : (int64_t)a;
-        int64_t c = (int64_t)kabc_index32(kabc_hi64(B2), (uint32_t)nc - 2u);
-        c += (c >= lo);
-        c += (c >= hi);
-        R.bb[si][lane] = move >= 2 ? (uint32_t)b : a;  // (a: valid row for the consumer's unconditional prefetch)
-        R.cc[si][lane] = move >= 2 ? (uint32_t)c : a;
+        // (32-bit: row numbers fit 30 bits, mva packs them so -- the same values as the
+        // contract's 64-bit formulation at a third of the instructions)
+        uint32_t b = kabc_index32(kabc_lo64(B2), (uint32_t)nc - 1u);
+        b += (b >= a) ? 1u : 0u;
+        const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+        uint32_t c = kabc_index32(kabc_hi64(B2), (uint32_t)nc - 2u);
+        c += (c >= lo) ? 1u : 0u;
+        c += (c >= hi) ? 1u : 0u;
+        R.bb[si][lane] = move >= 2 ? b : a;  // (a: valid row for the consumer's unconditional prefetch)
+        R.cc[si][lane] = move >= 2 ? c : a;
     }
     R.mva[si][lane] = ((uint32_t)move << 30) | a;
     // -- compaction of the move-dependent extra work (wave ballot + mbcnt)
