@@ -6,6 +6,7 @@ only ever used by tests/, smoke() and bench.py's cpu_baseline leg.)
 """
 import ctypes as C
 import os
+import threading
 
 from . import _cdefs
 
@@ -117,18 +118,44 @@ def default_context(device=0):
     return ctx
 
 
+# Page-locked blocks whose arrays have died, kept for the next result of the same size: pinning
+# 268 MB (an smc result at 2 M particles x 16) costs as much as copying into it ten times.
+_pinned_free = {}            # nbytes -> [address, ...]
+_pinned_free_bytes = 0
+_pinned_lock = threading.Lock()
+
+
+def _pinned_cache_cap():
+    return int(float(os.environ.get("KABC_PINNED_CACHE_MB", "1024")) * (1 << 20))
+
+
 class _PinnedBlock:
-    """One kabc_host_alloc allocation, released when the last numpy view dies."""
+    """One kabc_host_alloc allocation; when the last numpy view dies it goes back to the free list
+    (or to the driver, beyond KABC_PINNED_CACHE_MB)."""
 
     def __init__(self, nbytes):
+        global _pinned_free_bytes
+        with _pinned_lock:
+            lst = _pinned_free.get(nbytes)
+            if lst:
+                self.ptr, self.nbytes = lst.pop(), nbytes
+                _pinned_free_bytes -= nbytes
+                return
         p = C.c_void_p()
         check(load().kabc_host_alloc(C.c_size_t(nbytes), C.byref(p)))
         self.ptr, self.nbytes = p.value, nbytes
 
     def __del__(self):
+        global _pinned_free_bytes
         try:
             if self.ptr and _lib is not None:
-                _lib.kabc_host_free(C.c_void_p(self.ptr))
+                with _pinned_lock:
+                    keep = _pinned_free_bytes + self.nbytes <= _pinned_cache_cap()
+                    if keep:
+                        _pinned_free.setdefault(self.nbytes, []).append(self.ptr)
+                        _pinned_free_bytes += self.nbytes
+                if not keep:
+                    _lib.kabc_host_free(C.c_void_p(self.ptr))
         except Exception:
             pass
         self.ptr = None
@@ -136,8 +163,8 @@ class _PinnedBlock:
 
 def pinned_empty(shape, dtype="float64"):
     """numpy array over page-locked host memory (kabc_host_alloc): the destination of
-    the sample trace, so that kabc_ais_advance can DMA it while the kernels run.
-    Falls back to ordinary memory when pinning fails or KABC_PINNED_TRACE=0."""
+    the sample trace, so that kabc_ais_advance can DMA it while the kernels run, and of large
+    smc / ABCDE results.  Falls back to ordinary memory when pinning fails or KABC_PINNED_TRACE=0."""
     import numpy as np
     dt = np.dtype(dtype)
     n = int(np.prod(shape)) * dt.itemsize
@@ -150,6 +177,16 @@ def pinned_empty(shape, dtype="float64"):
     buf = (C.c_char * n).from_address(blk.ptr)
     buf._kabc_block = blk
     return np.frombuffer(buf, dtype=dt).reshape(shape)
+
+
+def result_empty(shape, dtype="float64"):
+    """destination of a result copy: page-locked from 1 MiB on (the copy then runs at the PCIe
+    rate instead of faulting fresh pages in one by one), ordinary memory below"""
+    import numpy as np
+    dt = np.dtype(dtype)
+    if int(np.prod(shape)) * dt.itemsize >= (1 << 20):
+        return pinned_empty(shape, dt)
+    return np.empty(shape, dtype=dt)
 
 
 MATH_FN = {"log": 0, "exp": 1, "log1p": 2, "lgamma": 3, "sincos2pi": 4, "sqrt": 5, "rint": 6,

@@ -407,8 +407,8 @@ def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.01
     N, D = int(nparticles), len(fac)
     n_alloc = max(N, 1)
     t_host0 = time.perf_counter()
-    theta = np.empty((n_alloc, D))
-    Cst = np.empty(n_alloc)
+    theta = _lib.result_empty((n_alloc, D))
+    Cst = _lib.result_empty(n_alloc)
     alive = np.zeros(n_alloc, dtype=np.uint8)
     log = (cd.SmcIter * 4096)()
     r = cd.SmcResult()

@@ -150,13 +150,23 @@ static void launch_smc_init(int D, const SmcInitArgs& a, hipStream_t s,
 struct DevBufs {
     kabc_ctx_t* ctx = nullptr;                         // set: buffers come from / go back to its cache
     std::vector<std::pair<size_t, void*>> held;
-    static constexpr size_t kPoolCap = 512ull << 20;   // bytes kept per context
+    // bytes kept per context: 4 GiB of the 288 (the working set of smc at 2 M particles x 16 is
+    // 0.9 GB: with the former 512 MiB every call allocated and freed two 268 MB buffers);
+    // KABC_POOL_MB overrides
+    static size_t pool_cap() {
+        static const size_t cap = [] {
+            const char* e = std::getenv("KABC_POOL_MB");
+            const double mb = e ? std::atof(e) : 4096.0;
+            return (size_t)((mb > 0.0 ? mb : 0.0) * (double)(1 << 20));
+        }();
+        return cap;
+    }
     ~DevBufs() {
         for (auto& e : held) {
             if (!e.second) continue;
             if (ctx) {
                 std::lock_guard<std::mutex> lk(ctx->pool_mu);
-                if (ctx->pool_bytes + e.first <= kPoolCap) {
+                if (ctx->pool_bytes + e.first <= pool_cap()) {
                     ctx->pool.push_back(e);
                     ctx->pool_bytes += e.first;
                     continue;
@@ -195,12 +205,14 @@ struct DevBufs {
 using namespace kabc;
 
 namespace kabc {
-// workgroups of the select kernel: one per 2048 particles, at most 16 (32 from 131 072
-// particles on: a device-wide barrier costs ~1.7-2.4 us and grows with the count);
+// workgroups of the select kernel: one per 2048 particles, at most 16 (32 from 2^17 particles
+// on, 64 from 2^19, 128 from 2^21: its passes over the costs stream at the rate of the CUs it
+// occupies, its five device-wide barriers cost 2.4 us each at 32 workgroups and 5 at 128 --
+// measured at 2 M particles: 118 -> 83 us per call, profiles/r04_smc_large.txt);
 // KABC_SMC_SELECT_BLOCKS overrides
 static unsigned select_blocks(int64_t N) {
     long g = (long)((N + 2047) / 2048);
-    const long cap = N >= (1 << 17) ? kSelMaxBlocks : 16;
+    const long cap = N >= (1 << 21) ? 128 : N >= (1 << 19) ? 64 : N >= (1 << 17) ? 32 : 16;
     if (g > cap) g = cap;
     if (const char* e = std::getenv("KABC_SMC_SELECT_BLOCKS")) {
         const long v = std::atol(e);
@@ -211,7 +223,7 @@ static unsigned select_blocks(int64_t N) {
     if (g > kSelMaxBlocks) g = kSelMaxBlocks;
     return g < 1 ? 1u : (unsigned)g;
 }
-// The kernel's device-wide barrier needs its G <= 32 workgroups resident at the same time:
+// The kernel's device-wide barrier needs its G <= 128 workgroups resident at the same time:
 // for G > 1 it is launched with hipLaunchCooperativeKernel, which guarantees co-residency or
 // fails with an error (another process / stream holding the CUs cannot leave the grid half
 // resident and spinning).  The guarantee costs ~20 us per launch (measured: C4 on this path

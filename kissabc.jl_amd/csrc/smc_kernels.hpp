@@ -73,7 +73,7 @@ struct SmcInitArgs {
 constexpr int kSelBins = 1024;      // histogram bins per narrowing round
 constexpr int kSelCand = 4096;      // candidate keys narrowed in LDS
 constexpr int kSelRounds = 7;       // 7 x 10 bits > 64: global narrowing rounds at most
-constexpr int kSelMaxBlocks = 32;   // workgroups of the select kernel
+constexpr int kSelMaxBlocks = 128;  // workgroups of the select kernel (capi_smc.hip select_blocks)
 
 // global scratch of the multi-workgroup select kernel: zeroed once by the host, left
 // zeroed by every call (barrier words excepted: the generation only ever counts up)
@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
         KABC_SEL_BARRIER(g, G)
         n = nn = 0;
         kmin = kmaxn = ~0ull;
-        for (unsigned b = 0; b < G; ++b) {  // G <= 32: every thread reads them all
+        for (unsigned b = 0; b < G; ++b) {  // G <= 128: every thread reads them all
             const unsigned long long* p = g->part_stats[b];
             n += (long long)p[0];
             nn += (long long)p[1];

@@ -115,6 +115,31 @@ def test_c4_full_size_bit_exact(k, orc, gpu_ctx, monkeypatch, path, blocks):
     assert r.info["cost_evals"] == ro["cost_evals"] and r.info["proposals"] == ro["proposals"]
 
 
+def test_select_on_128_workgroups_bit_exact(k, orc, gpu_ctx, monkeypatch):
+    """The kernel-per-phase path beyond the loop kernel's range, its select kernel on 128
+    workgroups (what 2^21 particles and more get by default; 140 000 particles are 137 tiles, a
+    ragged last slice): everything equals the oracle's bit for bit, and the default choice
+    (32 workgroups at this size) gives the same arrays."""
+    monkeypatch.setenv("KABC_SMC_LOOP", "0")
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from smc_c4_probe import c4_problem
+    prior, cost = c4_problem()
+    kw = dict(nparticles=140000, alpha=0.95, epstol=0.25, seed=3)
+    monkeypatch.setenv("KABC_SMC_SELECT_BLOCKS", "128")
+    r = k.smc(prior, cost, return_array=True, **kw)
+    monkeypatch.delenv("KABC_SMC_SELECT_BLOCKS", raising=False)
+    r32 = k.smc(prior, cost, return_array=True, **kw)
+    ro = orc.smc(prior, cost, **kw)
+    assert r.info["iterations"] == ro["iterations"] > 20
+    for rr in (r, r32):
+        assert rr.eps == ro["eps"] and np.array_equal(rr.info["theta_all"], ro["theta_all"])
+        assert [it["eps"] for it in rr.info["log"]] == [it["eps"] for it in ro["log"]]
+        assert [it["ess"] for it in rr.info["log"]] == [it["ess"] for it in ro["log"]]
+        assert np.array_equal(rr.info["alive"], ro["alive"]) and np.array_equal(rr.C, ro["C"])
+
+
 def test_loop_kernel_many_sizes(k, orc, gpu_ctx, monkeypatch):
     """The persistent kernel's selection machinery away from the happy path: particle
     counts that are not multiples of 256 or 64, one workgroup, heavy ties (discrete
