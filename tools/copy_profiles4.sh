@@ -3,21 +3,21 @@ S=${1:?gpurun_out dir}; P=profiles
 cp $S/bench.json $P/r04_bench.json
 for NT in 1 16 100; do
   cp $S/bench_under_rocprof_nt$NT.json $P/r04_bench_under_rocprof_nt$NT.json
-  cp $(ls $S/stats_nt$NT/*/*kernel_stats.csv | head -1) $P/r04_kernel_stats_nt$NT.csv
+  cp $(ls -t $S/stats_nt$NT/*/*kernel_stats.csv | head -1) $P/r04_kernel_stats_nt$NT.csv
 done
 cp $S/pmc_insts.json $P/r04_pmc_insts.json
 cp $S/pmc_traffic_nt100.json $P/r04_pmc_traffic_nt100.json
 cp $S/pmc_traffic_smc_loop.json $P/r04_pmc_traffic_smc_loop.json
-cp $(ls $S/smc_stats/*/*kernel_stats.csv | head -1) $P/r04_smc_c4_loop_kernel_stats.csv
+cp $(ls -t $S/smc_stats/*/*kernel_stats.csv | head -1) $P/r04_smc_c4_loop_kernel_stats.csv
 cp $S/smc_c4.txt $P/r04_smc_c4.txt
 cp $S/smc_c4_spec.txt $P/r04_smc_c4_spec.txt
 cp $S/config_sweep.jsonl $P/r04_config_sweep.jsonl
-cp $(ls $S/readme_stats/*/*kernel_stats.csv | head -1) $P/r04_readme_kernel_stats.csv
+cp $(ls -t $S/readme_stats/*/*kernel_stats.csv | head -1) $P/r04_readme_kernel_stats.csv
 cp $S/readme_under_rocprof.json $P/r04_readme_under_rocprof.json
-cp $(ls $S/readme_smc_stats/*/*kernel_stats.csv | head -1) $P/r04_readme_smc_kernel_stats.csv
+cp $(ls -t $S/readme_smc_stats/*/*kernel_stats.csv | head -1) $P/r04_readme_smc_kernel_stats.csv
 cp $S/smc_small.json $P/r04_smc_small.json
 cp $S/spec_probe.json $P/r04_spec_probe.json
-cp $(ls $S/spec_stats/*/*kernel_stats.csv | head -1) $P/r04_spec_kernel_stats.csv
+cp $(ls -t $S/spec_stats/*/*kernel_stats.csv | head -1) $P/r04_spec_kernel_stats.csv
 cp $S/smc_scaling.jsonl $P/r04_smc_scaling.jsonl
 cp $S/abcde.json $P/r04_abcde.json
 grep '^cycles' $S/pmc_collect.log | sed "s/^cycles //" > /tmp/_cyc.txt

@@ -12,6 +12,14 @@ os.environ.setdefault("KABC_NO_TORCH_PRELOAD", "1")
 import kissabc_jl_amd as k  # noqa: E402
 import bench  # noqa: E402
 
+# entries of earlier builds are dead weight (the key holds a fingerprint of every header): the tree
+# that travels to the GPU box carries the current ones only
+cache = os.path.join(os.path.dirname(k.LIB_PATH), "rtc_cache")
+if os.path.isdir(cache) and not os.environ.get("KABC_RTC_CACHE_DIR"):
+    for f in os.listdir(cache):
+        if f.startswith("kabc_") and f.endswith(".co"):
+            os.remove(os.path.join(cache, f))
+
 out = {}
 for name, model, N, D in bench.prior_class_problems(k):
     t0 = time.perf_counter()
