@@ -210,6 +210,7 @@ namespace kabc {
 // occupies, its five device-wide barriers cost 2.4 us each at 32 workgroups and 5 at 128 --
 // measured at 2 M particles: 118 -> 83 us per call, profiles/r04_smc_large.txt);
 // KABC_SMC_SELECT_BLOCKS overrides
+static unsigned select_capacity();
 static unsigned select_blocks(int64_t N) {
     long g = (long)((N + 2047) / 2048);
     const long cap = N >= (1 << 21) ? 128 : N >= (1 << 19) ? 64 : N >= (1 << 17) ? 32 : 16;
@@ -221,19 +222,32 @@ static unsigned select_blocks(int64_t N) {
     const long ntile = (long)((N + kSelBlock - 1) / kSelBlock);
     if (g > ntile) g = ntile;
     if (g > kSelMaxBlocks) g = kSelMaxBlocks;
+    if (g > (long)select_capacity()) g = (long)select_capacity();  // (a partitioned or masked device)
     return g < 1 ? 1u : (unsigned)g;
 }
-// The kernel's device-wide barrier needs its G <= 128 workgroups resident at the same time:
-// for G > 1 it is launched with hipLaunchCooperativeKernel, which guarantees co-residency or
-// fails with an error (another process / stream holding the CUs cannot leave the grid half
-// resident and spinning).  The guarantee costs ~20 us per launch (measured: C4 on this path
-// 14.2 -> 16.1 ms); KABC_SMC_COOPERATIVE=0 selects an ordinary launch for timing experiments
-// -- the barrier's spin is bounded either way (sel_grid_barrier).
-static hipError_t launch_select(const SmcSelectArgs& sa, unsigned G, hipStream_t s) {
-    static const bool coop = [] {
-        const char* e = std::getenv("KABC_SMC_COOPERATIVE");
-        return !(e && e[0] == '0');
+// The kernel's device-wide barrier needs its G <= 128 workgroups resident at the same time.
+// They are launched as an ORDINARY grid that is known to fit: G is clamped to what the device
+// holds of this kernel (occupancy x CUs), the stream is in order (nothing of this run is on the
+// CUs when the kernel starts), and a tenant of another process delays the last workgroups but
+// cannot starve them -- its kernels end; the barrier's spin is bounded all the same (5 s, then
+// KABC_ERR_DEVICE; sel_grid_barrier).  hipLaunchCooperativeKernel gives the guarantee by
+// construction and costs ~21 us per launch, host and device side (131 072 particles x 16: 88 -> 67 us
+// per iteration without it, profiles/r04_smc_large.txt); KABC_SMC_COOPERATIVE=1 selects it.
+static unsigned select_capacity() {
+    static const unsigned cap = [] {
+        int dev = 0, per_cu = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 1u;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)smc_select_kernel, kSelBlock, 0) != hipSuccess)
+            return 1u;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1u;
+        const long c = (long)per_cu * cus;
+        return c < 1 ? 1u : (unsigned)c;
     }();
+    return cap;
+}
+static hipError_t launch_select(const SmcSelectArgs& sa, unsigned G, hipStream_t s) {
+    const char* e = std::getenv("KABC_SMC_COOPERATIVE");  // (read per launch: a test switches it)
+    const bool coop = e && e[0] == '1';
     if (G <= 1u || !coop) {
         hipLaunchKernelGGL(smc_select_kernel, dim3(G), dim3(kSelBlock), 0, s, sa);
         return hipGetLastError();

@@ -270,10 +270,10 @@ __device__ __forceinline__ void for_each_alive(const uint8_t* __restrict__ alive
 // them are resident).  Sense-reversing: one atomic per workgroup, thread 0 spins on the
 // generation word; 2.4 us at 32 x 1024 threads, about a kernel boundary (cooperative
 // groups' grid.sync() is 5.1 us; tools/gridsync_probe.hip).  G == 1: __syncthreads.
-// Residency: launch_select (capi_smc.hip) uses hipLaunchCooperativeKernel whenever G > 1, so
-// all G workgroups are co-resident or the launch fails with an error.  The spin is bounded all
-// the same (5 s of s_memrealtime): on time-out the abort word is set, every workgroup leaves
-// the kernel, and kabc_smc_run / kabc_pfilter_run return KABC_ERR_DEVICE instead of hanging.
+// Residency: launch_select (capi_smc.hip) launches a grid that fits the device (G clamped to
+// occupancy x CUs) on an in-order stream, or cooperatively under KABC_SMC_COOPERATIVE=1.  The spin
+// is bounded either way (5 s of s_memrealtime): on time-out the abort word is set, every workgroup
+// leaves the kernel, and kabc_smc_run / kabc_pfilter_run return KABC_ERR_DEVICE instead of hanging.
 __device__ __forceinline__ bool sel_grid_barrier(SmcSelScratch* g, unsigned G) {
     __shared__ int s_ok;
     // every wavefront's own stores are in the L2 before thread 0 releases for the workgroup

@@ -87,14 +87,16 @@ def test_smc_argument_errors_match_reference(k, gpu_ctx):
 
 
 @pytest.mark.parametrize("path,blocks", [("loop", None), ("kernels", None), ("kernels", "1"),
-                                         ("kernels", "32")])
+                                         ("kernels", "32"), ("kernels-cooperative", "32")])
 def test_c4_full_size_bit_exact(k, orc, gpu_ctx, monkeypatch, path, blocks):
     """BASELINE.json configs[3] at full size (32 768 particles, D = 16, hierarchical
     Gaussian simulator, ~190 ε-iterations): θ of every particle, ε and the iteration
     log equal the oracle's bit for bit -- on the persistent loop kernel, and on the
     kernel-per-phase path with the select kernel on its default 16 workgroups, on one,
-    and on 32."""
+    on 32, and on 32 launched cooperatively."""
     monkeypatch.setenv("KABC_SMC_LOOP", "1" if path == "loop" else "0")
+    # (the select kernel's grid: an ordinary launch that fits the device, or a cooperative one)
+    monkeypatch.setenv("KABC_SMC_COOPERATIVE", "1" if path.endswith("cooperative") else "0")
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
