@@ -22,9 +22,10 @@ for N in (1000, 16384, 65536):
     t1 = time.perf_counter()
     ro = orc.abcde(N2, cost, 0.01, **kw) if N <= 16384 else None
     t2 = time.perf_counter()
-    out[f"abcde_N{N}"] = {"device_s": t1 - t0, "oracle_s": t2 - t1,
+    # (the oracle's donor draw is O(N^2) per generation: not run at 65 536 -- null, not false)
+    out[f"abcde_N{N}"] = {"device_s": t1 - t0, "oracle_s": (t2 - t1) if ro is not None else None,
                           "generations": r.info["generations_run"],
-                          "bit_exact": bool(ro is not None and np.array_equal(r.P, ro["P"]))}
+                          "bit_exact": bool(np.array_equal(r.P, ro["P"])) if ro is not None else None}
 for N in (1000, 16384):
     kw = dict(q=0.7, eff_tol=0.1, epstol=0.02, seed=3)
     k.pfilter(N2, cost, N, return_array=True, **kw)
