@@ -1202,6 +1202,8 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     double eps = 0.0, eff = 0.0;
     SmcCtrl hsel;
     PfCtrl hp;
+    const char* pf_env = std::getenv("KABC_PF_PASSES");  // =1: one launch per attempt (the former scheme)
+    const bool pf_loop = !(pf_env && pf_env[0] == '1');
     std::memset(&hp, 0, sizeof hp);
     while (true) {
         ++iters;
@@ -1211,9 +1213,19 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         pa.iteration = (uint64_t)iters;
         uint32_t attempt = 0;
         while (true) {
-            for (int g = 0; g < 8; ++g) {
-                pa.attempt = attempt++;
+            if (pf_loop) {
+                // one launch: every bad particle runs its rejection loop to the end (a launch and
+                // a host round trip per group of attempts was most of an iteration's 88 us)
+                pa.attempt = 0u;
+                pa.loop_attempts = 1;
                 f_att(pa, s);
+                attempt = 1u << 24;
+            } else {
+                pa.loop_attempts = 0;
+                for (int g = 0; g < 8; ++g) {
+                    pa.attempt = attempt++;
+                    f_att(pa, s);
+                }
             }
             KABC_HIP_CHECK(hipGetLastError());
             KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));

@@ -34,6 +34,10 @@ struct PfArgs {
     uint64_t seed;
     uint64_t iteration;
     uint32_t attempt;
+    // 1: every pending particle repeats its attempts inside ONE launch until it is replaced
+    // (attempt = 0, 1, 2, ... -- the numbering the pass-per-attempt scheme gives it, so the same
+    // draws); 0: this launch is attempt `attempt` for all of them (KABC_PF_PASSES=1)
+    int32_t loop_attempts;
     int32_t cost_id;
     double proposal_width;
     PriorSet prior;
@@ -66,46 +70,53 @@ __global__ void __launch_bounds__(kPfBlock) pf_attempt_kernel(const PfArgs A) {
     if (i < A.N && A.pending[i]) {
         const uint64_t nok = (uint64_t)A.sel->ess;
         const double eps = A.sel->eps;
-        const uint64_t t = (A.iteration << 24) | (uint64_t)A.attempt;
         const uint32_t w = (uint32_t)i;
-        const kabc_u128_t B0 = kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_PF_MOVE);
-        const kabc_u128_t B1 = kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_PF_MOVE);
-        const kabc_u128_t B2 = kabc_stream_block(A.seed, w, t, 2u, KABC_DOM_PF_MOVE);
-        // b=c=d=rand(idxok); while c==b ...; while d==b || d==c ...  (:309-311)
-        const int64_t pb = (int64_t)kabc_index(kabc_lo64(B0), nok);
-        int64_t pc = (int64_t)kabc_index(kabc_hi64(B0), nok - 1u);
-        pc += (pc >= pb);
-        const int64_t lo = pb < pc ? pb : pc, hi = pb < pc ? pc : pb;
-        int64_t pd = (int64_t)kabc_index(kabc_lo64(B1), nok - 2u);
-        pd += (pd >= lo);
-        pd += (pd >= hi);
-        const int64_t b = A.idxok[pb], c = A.idxok[pc], d = A.idxok[pd];
-        double z0, z1;
-        kabc_normal_pair(kabc_lo64(B2), kabc_hi64(B2), &z0, &z1);
-        const double sc = z0 * A.proposal_width;  // randn(trng)*proposal_width
-        double tb[CAP], tc[CAP], td[CAP], p[CAP], xp[CAP];
-        load_row_n<DT>(A.theta + b * D, tb, D);
-        load_row_n<DT>(A.theta + c * D, tc, D);
-        load_row_n<DT>(A.theta + d * D, td, D);
+        const double lpi_i = A.lpi[i];
+        // the rejection loop of one bad particle (:306-325).  Its proposals are built from
+        // survivors only, which nobody writes during the iteration, so the loop needs nothing
+        // from the other bad particles: it runs to its end inside the launch.
+        const uint32_t a_end = A.loop_attempts ? (1u << 24) : A.attempt + 1u;
+        for (uint32_t attempt = A.attempt; attempt < a_end && !done; ++attempt) {
+            const uint64_t t = (A.iteration << 24) | (uint64_t)attempt;
+            const kabc_u128_t B0 = kabc_stream_block(A.seed, w, t, 0u, KABC_DOM_PF_MOVE);
+            const kabc_u128_t B1 = kabc_stream_block(A.seed, w, t, 1u, KABC_DOM_PF_MOVE);
+            const kabc_u128_t B2 = kabc_stream_block(A.seed, w, t, 2u, KABC_DOM_PF_MOVE);
+            // b=c=d=rand(idxok); while c==b ...; while d==b || d==c ...  (:309-311)
+            const int64_t pb = (int64_t)kabc_index(kabc_lo64(B0), nok);
+            int64_t pc = (int64_t)kabc_index(kabc_hi64(B0), nok - 1u);
+            pc += (pc >= pb);
+            const int64_t lo = pb < pc ? pb : pc, hi = pb < pc ? pc : pb;
+            int64_t pd = (int64_t)kabc_index(kabc_lo64(B1), nok - 2u);
+            pd += (pd >= lo);
+            pd += (pd >= hi);
+            const int64_t b = A.idxok[pb], c = A.idxok[pc], d = A.idxok[pd];
+            double z0, z1;
+            kabc_normal_pair(kabc_lo64(B2), kabc_hi64(B2), &z0, &z1);
+            const double sc = z0 * A.proposal_width;  // randn(trng)*proposal_width
+            double tb[CAP], tc[CAP], td[CAP], p[CAP], xp[CAP];
+            load_row_n<DT>(A.theta + b * D, tb, D);
+            load_row_n<DT>(A.theta + c * D, tc, D);
+            load_row_n<DT>(A.theta + d * D, td, D);
 #pragma unroll
-        for (int k = 0; k < D; ++k) p[k] = tb[k] + (td[k] - tc[k]) * sc;  // :312
-        reps = 1;
-        const double ll = logpdf_push_n<DT>(A.prior, A.dprior, D, p, xp);
-        const double wp = ll - A.lpi[i];
-        double mn = wp;
-        if (!(wp < 0.0)) mn = (wp != wp) ? wp : 0.0;  // min(0.0, ll - logπ[i])
-        const double lu = kabc_log_pn(kabc_u01(kabc_hi64(B1)));
-        if (!(lu > mn)) {  // :316-318
-            kabc_cost_rng_t rng = {A.seed, t, w, KABC_DOM_PF_COST, 0u};
-            const double Cp = kabc_cost_eval(A.cost_id, p, D, A.cost_params, A.cost_data,
-                                             A.cost_ndata, &rng);  // cost(p.x): NOT push_p'ed
-            evals = 1;
-            if (!(Cp > eps)) {  // :320-322
-                store_row_n<DT>(A.theta + i * D, p, D);
-                A.C[i] = Cp;
-                A.lpi[i] = ll;
-                A.pending[i] = 0;
-                done = 1;
+            for (int k = 0; k < D; ++k) p[k] = tb[k] + (td[k] - tc[k]) * sc;  // :312
+            reps += 1;
+            const double ll = logpdf_push_n<DT>(A.prior, A.dprior, D, p, xp);
+            const double wp = ll - lpi_i;
+            double mn = wp;
+            if (!(wp < 0.0)) mn = (wp != wp) ? wp : 0.0;  // min(0.0, ll - logπ[i])
+            const double lu = kabc_log_pn(kabc_u01(kabc_hi64(B1)));
+            if (!(lu > mn)) {  // :316-318
+                kabc_cost_rng_t rng = {A.seed, t, w, KABC_DOM_PF_COST, 0u};
+                const double Cp = kabc_cost_eval(A.cost_id, p, D, A.cost_params, A.cost_data,
+                                                 A.cost_ndata, &rng);  // cost(p.x): NOT push_p'ed
+                evals += 1;
+                if (!(Cp > eps)) {  // :320-322
+                    store_row_n<DT>(A.theta + i * D, p, D);
+                    A.C[i] = Cp;
+                    A.lpi[i] = ll;
+                    A.pending[i] = 0;
+                    done = 1;
+                }
             }
         }
     }

@@ -28,8 +28,12 @@ def test_pfilter_oracle(orc, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("passes", ["0", "1"], ids=["loop-in-kernel", "launch-per-attempt"])
 @pytest.mark.parametrize("name", ["gauss", "gauss_q9", "banana_noisy", "tiny_N_is_raised", "discrete"])
-def test_pfilter_bit_exact(k, orc, gpu_ctx, name):
+def test_pfilter_bit_exact(k, orc, gpu_ctx, name, passes, monkeypatch):
+    """(every bad particle's rejection loop inside one launch -- the default -- or one launch per
+    attempt, KABC_PF_PASSES=1: the same draws, the same particles)"""
+    monkeypatch.setenv("KABC_PF_PASSES", passes)
     pri, cost, N, kw = _cases(k)[name]
     got = k.pfilter(pri, cost, N, seed=4, return_array=True, **kw)
     ref = orc.pfilter(pri, cost, N, seed=4, **kw)
