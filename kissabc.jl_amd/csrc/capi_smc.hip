@@ -881,8 +881,9 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
             set_error("quantiles are undefined in presence of NaNs");
             rc = KABC_ERR_NAN_COST;
         } else if (hc.error == 3) {
-            set_error("smc: a device-wide barrier timed out (the cooperative grid lost residency "
-                      "or the device is wedged)");
+            set_error("smc: a device-wide barrier timed out after 5 s (the grid did not become "
+                      "resident -- another tenant holds the CUs; KABC_SMC_COOPERATIVE=1 launches the "
+                      "select kernel cooperatively -- or the device is wedged)");
             rc = KABC_ERR_DEVICE;
         } else if (hc.error == 4) {
             // more particles share one histogram bin of the costs than the loop kernel's candidate
@@ -1232,8 +1233,9 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
             KABC_HIP_CHECK(hipMemcpyAsync(&hsel, sel, sizeof hsel, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipStreamSynchronize(s));
             if (hsel.error == 3) {
-                set_error("pfilter: a device-wide barrier timed out (the cooperative grid lost "
-                          "residency or the device is wedged)");
+                set_error("pfilter: a device-wide barrier timed out after 5 s (the select grid did not "
+                          "become resident -- KABC_SMC_COOPERATIVE=1 launches it cooperatively -- or "
+                          "the device is wedged)");
                 return KABC_ERR_DEVICE;
             }
             if (hsel.error) {
