@@ -222,7 +222,10 @@ static unsigned select_blocks(int64_t N) {
     const long ntile = (long)((N + kSelBlock - 1) / kSelBlock);
     if (g > ntile) g = ntile;
     if (g > kSelMaxBlocks) g = kSelMaxBlocks;
-    if (g > (long)select_capacity()) g = (long)select_capacity();  // (a partitioned or masked device)
+    // at most a quarter of what the device holds of this kernel (128 of 512 on a whole MI355X): four
+    // concurrent runs are always co-resident; a partitioned or masked device gets smaller grids
+    const long quarter = (long)select_capacity() / 4 > 0 ? (long)select_capacity() / 4 : 1;
+    if (g > quarter) g = quarter;
     return g < 1 ? 1u : (unsigned)g;
 }
 // The kernel's device-wide barrier needs its G <= 128 workgroups resident at the same time.
