@@ -24,9 +24,10 @@ Prints ONE JSON line (rank 0).  `roofline` is for the half-generation kernel:
 algorithmic bytes per launch = rows * ntransitions * 8(3D+4) over the
 kernel's average duration measured with hipEvents on its stream over the timed
 region; `roofline.valu` is the second, binding resource: VALU wave-instructions per
-launch (committed PMC summary, profiles/) x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel
-time).  `smc_c4` times BASELINE.json configs[3] (smc, 32 768 particles, D = 16) the
-same way.  `cpu_baseline` times the CPU oracle's faithful serial restatement of the
+launch (committed PMC summary, profiles/) x the kernel's mix-weighted issue cycles
+(profiles/r*_valu_mix.json) / (1024 SIMDs x 2.4 GHz x kernel time).  `smc_c4` times BASELINE.json configs[3] (smc, 32 768 particles, D = 16) the
+same way.  `next_rows` are wall-clock legs of SURVEY 8's f3 / f4 rows (ABCDE, pfilter) beside the
+oracle on the same runs.  `cpu_baseline` times the CPU oracle's faithful serial restatement of the
 reference on a bounded sample of the same workloads.
 """
 import argparse
@@ -190,6 +191,20 @@ def cpu_baseline(k, budget_s, with_smc):
                                f"ntransitions=100 in {w:.1f}s"}
     except Exception as e:
         out["readme_c1"] = {"error": repr(e)}
+    try:  # the "next" rows (ABCDE, pfilter): the oracle on the same runs as the device legs
+        from oracle import oracle as orc
+        n2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+        gd = k.costs.GaussDist([1.0, -0.5])
+        t0 = time.perf_counter()
+        orc.abcde(n2, gd, 0.01, nparticles=2000, generations=50, seed=3)
+        out["abcde"] = {"wall_s": time.perf_counter() - t0, "cores": 1, "kind": "port",
+                        "sample": "oracle ABCDE (src/smc.jl:347-430), 2000 particles, 50 generations"}
+        t0 = time.perf_counter()
+        orc.pfilter(n2, gd, 16384, q=0.7, eff_tol=0.1, epstol=0.02, seed=3)
+        out["pfilter"] = {"wall_s": time.perf_counter() - t0, "cores": 1, "kind": "port",
+                          "sample": "oracle pfilter (src/smc.jl:275-340), 16384 particles"}
+    except Exception as e:
+        out["abcde"] = {"error": repr(e)}
     if with_smc:
         try:
             from oracle import oracle as orc
@@ -409,6 +424,35 @@ def main():
         if cpu and isinstance(cpu.get("readme_smc"), dict) and "wall_s" in cpu["readme_smc"]:
             extra["readme_smc"]["cpu_baseline"] = cpu["readme_smc"]
             extra["readme_smc"]["vs_cpu_port_1core"] = cpu["readme_smc"]["wall_s"] / w
+        # the "next" rows of SURVEY 8 (f3, f4): ABCDE and pfilter, wall clock against the oracle
+        try:
+            n2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+            gd = k.costs.GaussDist([1.0, -0.5])
+            nr = {}
+            for name, fn, kw_n in (
+                    ("abcde", lambda **kw: k.ABCDE(n2, gd, 0.01, ctx=ctx, return_array=True, **kw),
+                     dict(nparticles=2000, generations=50, seed=3)),
+                    ("pfilter", lambda **kw: k.pfilter(n2, gd, 16384, ctx=ctx, return_array=True, **kw),
+                     dict(q=0.7, eff_tol=0.1, epstol=0.02, seed=3))):
+                fn(**kw_n)
+                ws = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    rr = fn(**kw_n)
+                    ws.append(time.perf_counter() - t0)
+                w = sorted(ws)[2]
+                nr[name] = {"wall_ms": w * 1e3,
+                            "workload": ("ABCDE(prior, cost, 0.01; nparticles=2000, generations=50), Normal(0,5)^2 + gauss_dist "
+                                         "(src/smc.jl:347-430)" if name == "abcde" else
+                                         "pfilter(prior, cost, 16384; q=0.7, eff_tol=0.1, epstol=0.02), Normal(0,5)^2 + gauss_dist "
+                                         "(src/smc.jl:275-340)"),
+                            "iterations": int(rr.info["generations_run"] if name == "abcde" else rr.info["iterations"])}
+                if cpu and isinstance(cpu.get(name), dict) and "wall_s" in cpu[name]:
+                    nr[name]["cpu_baseline"] = cpu[name]
+                    nr[name]["vs_cpu_port_1core"] = cpu[name]["wall_s"] / w
+            extra["next_rows"] = nr
+        except Exception as e:  # informational legs: never fail the bench on them
+            extra["next_rows"] = {"error": repr(e)}
         # BASELINE.json configs[1]
         extra["c2"] = dict(kernel_leg(c2_problem(k), 4096, 2, nts=(NT_HEADLINE, 16)),
                            workload="C2: AIS 4096 walkers, D=2, Normal(0,5)^2, gauss_dist, scale 0.1 "
