@@ -51,6 +51,9 @@ struct AbcdeArgs {
     const unsigned* wm_nz;               // [levels]: zeros of the level
     int32_t wm_levels;
     int64_t wm_words;
+    // donor index of every particle, drawn by abcde_donor_kernel (256 <= N < 4096: sixteen lanes
+    // share one particle's scans); NULL = the generation kernel scans itself
+    const int32_t* donor;
     // length(prior) > KABC_MAX_DIM (kernels instantiated with D = 0): the dimension and the
     // prior as device arrays; rows and proposals then live in per-thread arrays of
     // KABC_MAX_DIM_DYN doubles (scratch memory) -- a fallback, several times slower per particle
@@ -197,6 +200,76 @@ __global__ void __launch_bounds__(1024) abcde_extrema_kernel(const AbcdeArgs A) 
     }
 }
 
+// s = rand(trng, (1:N)[Δs .<= Δs[i]])  (:392) for every particle that needs one, by TEAMS of
+// sixteen lanes: each lane counts the hits of its sixteenth of the costs (LDS, eight per step), a
+// team-wide prefix locates the lane holding the m-th hit, that lane finds it.  The generation
+// kernel's own scans are one lane per particle: 2 N dependent steps (N = 2000: 90 us per
+// generation on 32 wavefronts; with teams ~5 us).  Same draw, same index.
+constexpr int kDonorTeam = 16, kDonorBlock = 256;
+__global__ void __launch_bounds__(kDonorBlock) abcde_donor_kernel(const AbcdeArgs A, int32_t* donor) {
+    __shared__ double s_dl[kAbcdeScanMax];
+    if (A.ctrl->done) return;
+    const int64_t N = A.N;
+    const uint64_t g = (uint64_t)A.ctrl->iters;
+    const double* __restrict__ DL = A.delta[A.ctrl->cur];
+    for (int64_t j = threadIdx.x; j < N; j += kDonorBlock) s_dl[j] = DL[j];
+    __syncthreads();
+    const int t = threadIdx.x % kDonorTeam;
+    const int64_t i = (int64_t)blockIdx.x * (kDonorBlock / kDonorTeam) + threadIdx.x / kDonorTeam;
+    bool need = false;  // (the same in the sixteen lanes of a team)
+    double di = 0.0;
+    if (i < N) {
+        di = s_dl[i];
+        const bool skip = A.earlystop && di <= A.eps_target;                        // :384-386
+        const double eps = (di <= A.eps_target) ? A.eps_target : A.ctrl->eps_pop;   // :390
+        need = !skip && di > eps;
+    }
+    const int64_t per = (N + kDonorTeam - 1) / kDonorTeam;
+    const int64_t lo = (int64_t)t * per < N ? (int64_t)t * per : N;
+    const int64_t hi = lo + per < N ? lo + per : N;
+    constexpr int U = 8;
+    int c = 0;
+    if (need) {
+        int64_t j = lo;
+        for (; j + U <= hi; j += U) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = s_dl[j + u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) c += (v[u] <= di) ? 1 : 0;
+        }
+        for (; j < hi; ++j) c += (s_dl[j] <= di) ? 1 : 0;
+    }
+    int incl = c;  // inclusive prefix over the team
+#pragma unroll
+    for (int off = 1; off < kDonorTeam; off <<= 1) {
+        const int o = __shfl_up(incl, off, kDonorTeam);
+        if (t >= off) incl += o;
+    }
+    const int total = __shfl(incl, kDonorTeam - 1, kDonorTeam);
+    int found = -1;
+    if (need) {  // total >= 1: the particle's own cost counts
+        const kabc_u128_t B0 = kabc_stream_block(A.seed, (uint32_t)i, g, 0u, KABC_DOM_ABCDE_MOVE);
+        int64_t m = (int64_t)kabc_index(kabc_lo64(B0), (uint64_t)total);
+        const int excl = incl - c;
+        if (m >= excl && m < incl) {  // this lane's range holds the m-th hit
+            m -= excl;
+            for (int64_t j = lo; j < hi && found < 0; ++j) {
+                if (s_dl[j] <= di) {
+                    if (m == 0) found = (int)j;
+                    --m;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = kDonorTeam / 2; off > 0; off >>= 1) {
+        const int o = __shfl_xor(found, off, kDonorTeam);
+        found = o > found ? o : found;
+    }
+    if (t == 0 && i < N) donor[i] = need ? found : (int32_t)i;
+}
+
 #endif  // KABC_ABCDE_SINGLE_UNIT
 
 // one generation (:383-412); reads buffer cur, writes buffer 1-cur
@@ -216,7 +289,7 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_gen_kernel(const AbcdeArgs 
     // walks all of them twice for its donor draw; from global memory those were two dependent
     // chains of N loads per thread (1000 particles: 167 us per generation, 16 us from LDS)
     __shared__ double s_dl[kAbcdeScanMax];
-    const bool lds_scan = !A.sorted_delta && A.N <= (int64_t)kAbcdeScanMax;  // uniform
+    const bool lds_scan = !A.sorted_delta && !A.donor && A.N <= (int64_t)kAbcdeScanMax;  // uniform
     if (lds_scan) {
         for (int64_t j = threadIdx.x; j < A.N; j += kAbcdeBlock) s_dl[j] = DL[j];
         __syncthreads();
@@ -245,6 +318,8 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_gen_kernel(const AbcdeArgs 
                 }
                 const int64_t m = (int64_t)kabc_index(kabc_lo64(B0), (uint64_t)lo);
                 s = (int64_t)wm_quantile(A, (unsigned)lo, (unsigned)m);
+            } else if (di > eps && A.donor) {
+                s = (int64_t)A.donor[i];  // (abcde_donor_kernel: the same draw, scanned by a team)
             } else if (di > eps) {
                 // the same by two scans (small N): the m-th index, in ascending order, whose
                 // cost does not exceed ours

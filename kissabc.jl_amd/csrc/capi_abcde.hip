@@ -34,6 +34,7 @@ static AbcdeLaunchFn pick_gen(int D, std::integer_sequence<int, Ds...>) {
 
 // ---- rank structure (the donor draw was O(N) per particle) ------------------------
 constexpr int64_t kRankMinN = 4096;  // below this the two scans are cheaper than building it
+constexpr int64_t kDonorMinN = 256;  // below this one lane per particle scans inside the generation kernel
 
 // bit b of every element of the sequence entering level b, packed 64 per word
 __global__ void __launch_bounds__(256) wm_bits_kernel(const unsigned* seq, int64_t n, int b,
@@ -433,8 +434,22 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         A.wm_levels = R.levels;
         A.wm_words = R.words;
     }
+    // in between (256 <= N < 4096): the donor draws by teams of sixteen lanes, one launch per
+    // generation in front of the generation kernel (KABC_ABCDE_DONOR=0: the kernel's own scans)
+    int32_t* d_donor = nullptr;
+    {
+        const char* e = std::getenv("KABC_ABCDE_DONOR");
+        if (!R.sorted && N >= kDonorMinN && N <= (int64_t)kAbcdeScanMax && !(e && e[0] == '0')) {
+            KABC_HIP_CHECK(alloc((void**)&d_donor, sizeof(int32_t) * N));
+            A.donor = d_donor;
+        }
+    }
     for (int64_t g = 0; g < o->generations; ++g) {  // while iters < generations (:372)
         hipLaunchKernelGGL(abcde_extrema_kernel, dim3(1), dim3(1024), 0, s, A);
+        if (d_donor)
+            hipLaunchKernelGGL(abcde_donor_kernel,
+                               dim3((unsigned)((N + kDonorBlock / kDonorTeam - 1) / (kDonorBlock / kDonorTeam))),
+                               dim3(kDonorBlock), 0, s, A, d_donor);
         // the buffer set flips once per generation until the earlystop break, after which every
         // kernel is a no-op: the host knows which one is current
         if (R.sorted) KABC_HIP_CHECK(build_rank(R, A.delta[g & 1], N, s));

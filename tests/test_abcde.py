@@ -81,3 +81,22 @@ def test_abcde_beyond_16_parameters_bit_exact(k, orc, gpu_ctx, D):
     assert got.P.shape == (400, D)
     assert np.array_equal(got.P, ref["P"]) and np.array_equal(got.C, ref["C"])
     assert got.info["generations_run"] == ref["generations_run"] and got.info["nsims"] == ref["nsims"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,kw", [(2000, dict(generations=30)),
+                                  (4095, dict(generations=8, alpha=0.3, earlystop=True)),
+                                  (257, dict(generations=40, proposal_width=0.7))])
+def test_abcde_team_donor_draw_bit_exact(k, orc, gpu_ctx, monkeypatch, N, kw):
+    """256 <= N < 4096: the donor draw rand((1:N)[Δs .<= Δs[i]]) by teams of sixteen lanes
+    (abcde_donor_kernel; ragged last ranges at 4095 and 257, ties from a discrete prior) equals
+    the oracle's, and the generation kernel's own scans (KABC_ABCDE_DONOR=0) give the same run."""
+    pri = k.Factored(k.DiscreteUniform(-10, 10), k.Normal(0, 3))
+    cost = k.costs.GaussDist([3.0, -2.0])
+    got = k.ABCDE(pri, cost, 0.5, nparticles=N, seed=11, return_array=True, **kw)
+    monkeypatch.setenv("KABC_ABCDE_DONOR", "0")
+    own = k.ABCDE(pri, cost, 0.5, nparticles=N, seed=11, return_array=True, **kw)
+    ref = orc.abcde(pri, cost, 0.5, nparticles=N, seed=11, **kw)
+    for r in (got, own):
+        assert np.array_equal(r.P, ref["P"]) and np.array_equal(r.C, ref["C"])
+        assert r.info["generations_run"] == ref["generations_run"] and r.info["nsims"] == ref["nsims"]
