@@ -22,9 +22,27 @@ static void launch_half(const AisArgs& a, hipStream_t s, unsigned nchains) {
     hipLaunchKernelGGL((ais_half_kernel<D, COST, PC, PK>), dim3(grid, nchains), dim3(kAisBlock), 0, s, a);
 }
 
+// (one translation unit instantiates the dimensions KABC_INST_DLO .. KABC_INST_DHI of some prior
+// classes: the Makefile builds three per cost, one of them scheduled differently -- AIS_SCHED there)
+#ifndef KABC_INST_DLO
+#define KABC_INST_DLO 1
+#endif
+#ifndef KABC_INST_DHI
+#define KABC_INST_DHI KABC_MAX_DIM
+#endif
+#ifndef KABC_INST_SUFFIX
+#define KABC_INST_SUFFIX
+#endif
+// KABC_INST_PCSEL: 0 every prior class, 1 the NORMAL class only, 2 every class but NORMAL
+#ifndef KABC_INST_PCSEL
+#define KABC_INST_PCSEL 0
+#endif
 template <int COST, int D, int PCX>
 static AisLaunchFn pick() {
-    if constexpr (cost_dim_ok_c(COST, D)) return &launch_half<D, COST, PCX % kPriorClasses, PCX / kPriorClasses + 1>;
+    constexpr bool is_normal = (PCX % kPriorClasses) == kPriorNormal;
+    constexpr bool pc_ok = KABC_INST_PCSEL == 0 || (KABC_INST_PCSEL == 1) == is_normal;
+    if constexpr (pc_ok && D >= KABC_INST_DLO && D <= KABC_INST_DHI && cost_dim_ok_c(COST, D))
+        return &launch_half<D, COST, PCX % kPriorClasses, PCX / kPriorClasses + 1>;
     else return nullptr;
 }
 
@@ -44,7 +62,7 @@ static AisLaunchFn table(int D, int pcx, std::integer_sequence<int, PCXs...>) {
 
 #define KABC_CAT2(a, b) a##b
 #define KABC_CAT(a, b) KABC_CAT2(a, b)
-AisLaunchFn KABC_CAT(find_ais_kernel_cost_, KABC_INST_COST)(int D, int pcx) {
+AisLaunchFn KABC_CAT(KABC_CAT(find_ais_kernel_cost_, KABC_INST_COST), KABC_INST_SUFFIX)(int D, int pcx) {
     return table<KABC_INST_COST>(D, pcx, std::make_integer_sequence<int, kAisVariants>{});
 }
 

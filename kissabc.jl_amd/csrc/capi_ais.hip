@@ -15,7 +15,12 @@
 
 namespace kabc {
 
-#define KABC_DECL_COST(id) AisLaunchFn find_ais_kernel_cost_##id(int D, int pc);
+// (three translation units per cost, csrc/Makefile: dimensions 1..7 of the NORMAL prior class,
+// 1..7 of the other classes, 8..KABC_MAX_DIM)
+#define KABC_DECL_COST(id)                                     \
+    AisLaunchFn find_ais_kernel_cost_##id(int D, int pc);      \
+    AisLaunchFn find_ais_kernel_cost_##id##_nrm(int D, int pc); \
+    AisLaunchFn find_ais_kernel_cost_##id##_hi(int D, int pc);
 KABC_DECL_COST(1)
 KABC_DECL_COST(2)
 KABC_DECL_COST(3)
@@ -29,20 +34,26 @@ KABC_DECL_COST(10)
 KABC_DECL_COST(11)
 
 AisDynLaunchFn find_ais_dyn_kernel();
+constexpr int kAisInstSplit = 7;  // = KABC_INST_DHI of the low translation units (csrc/Makefile)
+static AisLaunchFn ais_inst_pick(int D, int pc, AisLaunchFn (*lo)(int, int), AisLaunchFn (*nrm)(int, int),
+                                 AisLaunchFn (*hi)(int, int)) {
+    if (D > kAisInstSplit) return hi(D, pc);
+    return (pc % kPriorClasses) == kPriorNormal ? nrm(D, pc) : lo(D, pc);
+}
 
 AisLaunch find_ais_kernel(int cost_id, int D, int pc) {
     switch (cost_id) {
-        case 1: return find_ais_kernel_cost_1(D, pc);
-        case 2: return find_ais_kernel_cost_2(D, pc);
-        case 3: return find_ais_kernel_cost_3(D, pc);
-        case 4: return find_ais_kernel_cost_4(D, pc);
-        case 5: return find_ais_kernel_cost_5(D, pc);
-        case 6: return find_ais_kernel_cost_6(D, pc);
-        case 7: return find_ais_kernel_cost_7(D, pc);
-        case 8: return find_ais_kernel_cost_8(D, pc);
-        case 9: return find_ais_kernel_cost_9(D, pc);
-        case 10: return find_ais_kernel_cost_10(D, pc);
-        case 11: return find_ais_kernel_cost_11(D, pc);
+        case 1: return ais_inst_pick(D, pc, find_ais_kernel_cost_1, find_ais_kernel_cost_1_nrm, find_ais_kernel_cost_1_hi);
+        case 2: return ais_inst_pick(D, pc, find_ais_kernel_cost_2, find_ais_kernel_cost_2_nrm, find_ais_kernel_cost_2_hi);
+        case 3: return ais_inst_pick(D, pc, find_ais_kernel_cost_3, find_ais_kernel_cost_3_nrm, find_ais_kernel_cost_3_hi);
+        case 4: return ais_inst_pick(D, pc, find_ais_kernel_cost_4, find_ais_kernel_cost_4_nrm, find_ais_kernel_cost_4_hi);
+        case 5: return ais_inst_pick(D, pc, find_ais_kernel_cost_5, find_ais_kernel_cost_5_nrm, find_ais_kernel_cost_5_hi);
+        case 6: return ais_inst_pick(D, pc, find_ais_kernel_cost_6, find_ais_kernel_cost_6_nrm, find_ais_kernel_cost_6_hi);
+        case 7: return ais_inst_pick(D, pc, find_ais_kernel_cost_7, find_ais_kernel_cost_7_nrm, find_ais_kernel_cost_7_hi);
+        case 8: return ais_inst_pick(D, pc, find_ais_kernel_cost_8, find_ais_kernel_cost_8_nrm, find_ais_kernel_cost_8_hi);
+        case 9: return ais_inst_pick(D, pc, find_ais_kernel_cost_9, find_ais_kernel_cost_9_nrm, find_ais_kernel_cost_9_hi);
+        case 10: return ais_inst_pick(D, pc, find_ais_kernel_cost_10, find_ais_kernel_cost_10_nrm, find_ais_kernel_cost_10_hi);
+        case 11: return ais_inst_pick(D, pc, find_ais_kernel_cost_11, find_ais_kernel_cost_11_nrm, find_ais_kernel_cost_11_hi);
         default: {
             const PluginKernel k = plugin_kernel(find_plugin(cost_id), kPfAis, D, pc);
             if (k.host) return AisLaunch((AisLaunchFn)k.host);

@@ -1,5 +1,5 @@
 """Mix-weighted VALU issue time of one kernel of the shipped library:
-   python tools/valu_mix.py kissabc.jl_amd/csrc/build/ais_inst_2.o "ais_half_kernel<8, 2, 0, 1>" > profiles/r04_valu_mix.json
+   python tools/valu_mix.py kissabc.jl_amd/csrc/build/ais_insthi_2.o "ais_half_kernel<8, 2, 0, 1>" > profiles/r04_valu_mix.json
 Every static VALU instruction of the kernel is priced with this chip's MEASURED issue time for its
 opcode (profiles/r01m_valu_rate_8waves.json: ns per wave-instruction per SIMD with 8 waves sharing
 the SIMD, tools/valu_rate.hip); opcodes that were not measured take their class's figure (f64 and
