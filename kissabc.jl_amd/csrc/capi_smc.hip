@@ -1209,7 +1209,52 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     const char* pf_env = std::getenv("KABC_PF_PASSES");  // =1: one launch per attempt (the former scheme)
     const bool pf_loop = !(pf_env && pf_env[0] == '1');
     std::memset(&hp, 0, sizeof hp);
-    while (true) {
+    // Default: every bad particle's rejection loop inside one launch, the stop tests on the device,
+    // FOUR iterations enqueued per host round trip (kernels of iterations after the last are
+    // no-ops); verbose runs look after every iteration, to print it.
+    bool batched_done = false;
+    while (pf_loop) {
+        const int kIterBatch = o->verbose ? 1 : 4;
+        for (int b = 0; b < kIterBatch; ++b) {
+            ++iters;
+            KABC_HIP_CHECK(launch_select(sa, selG, s));
+            hipLaunchKernelGGL(pf_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
+                               pending, ok, pctrl, sel, N);
+            pa.iteration = (uint64_t)iters;
+            pa.attempt = 0u;
+            pa.loop_attempts = 1;
+            f_att(pa, s);
+            hipLaunchKernelGGL(pf_iter_end_kernel, dim3(1), dim3(1), 0, s, pctrl, sel, N, o->eff_tol,
+                               o->epstol, o->max_iters);
+        }
+        KABC_HIP_CHECK(hipGetLastError());
+        KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));
+        KABC_HIP_CHECK(hipStreamSynchronize(s));
+        if (hp.error == 3) {
+            set_error("pfilter: a device-wide barrier timed out after 5 s (the select grid did not "
+                      "become resident -- KABC_SMC_COOPERATIVE=1 launches it cooperatively -- or "
+                      "the device is wedged)");
+            return KABC_ERR_DEVICE;
+        }
+        if (hp.error == 9) {
+            set_error("pfilter: a particle was not replaced after 2^24 proposals");
+            return KABC_ERR_RETRY_EXHAUSTED;
+        }
+        if (hp.error) {
+            set_error("pfilter: quantile of the costs is undefined (NaN or empty)");
+            return KABC_ERR_NAN_COST;
+        }
+        if (o->verbose)
+            fprintf(stderr, "(iters, ϵ, eff) = (%lld, %.17g, %.17g)\n", (long long)hp.iters, hp.eps, hp.eff);
+        if (hp.done) {
+            iters = hp.iters;
+            eps = hp.eps;
+            eff = hp.eff;
+            batched_done = true;
+            break;
+        }
+    }
+    while (!batched_done) {
         ++iters;
         KABC_HIP_CHECK(launch_select(sa, selG, s));
         hipLaunchKernelGGL(pf_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
@@ -1217,19 +1262,10 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         pa.iteration = (uint64_t)iters;
         uint32_t attempt = 0;
         while (true) {
-            if (pf_loop) {
-                // one launch: every bad particle runs its rejection loop to the end (a launch and
-                // a host round trip per group of attempts was most of an iteration's 88 us)
-                pa.attempt = 0u;
-                pa.loop_attempts = 1;
+            pa.loop_attempts = 0;  // (KABC_PF_PASSES=1: a launch per attempt, eight per host round trip)
+            for (int g = 0; g < 8; ++g) {
+                pa.attempt = attempt++;
                 f_att(pa, s);
-                attempt = 1u << 24;
-            } else {
-                pa.loop_attempts = 0;
-                for (int g = 0; g < 8; ++g) {
-                    pa.attempt = attempt++;
-                    f_att(pa, s);
-                }
             }
             KABC_HIP_CHECK(hipGetLastError());
             KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));

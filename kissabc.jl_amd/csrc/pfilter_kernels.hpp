@@ -17,6 +17,12 @@ struct PfCtrl {
     unsigned long long remaining;   // bad particles not yet replaced
     unsigned long long cost_evals;  // cumulative
     unsigned long long total_reps;  // cumulative
+    // the loop's own state, kept on the device so that several iterations are enqueued per host
+    // round trip (pf_iter_end_kernel): iterations finished, ϵ and eff of the last one, the stop
+    // decision of :328-333, an error (the select kernel's code, or 9 = a particle left unreplaced)
+    long long iters;
+    double eps, eff;
+    int32_t done, error;
 };
 
 struct PfArgs {
@@ -52,10 +58,41 @@ constexpr int kPfBlock = 64;
 __global__ void __launch_bounds__(256) pf_mark_kernel(uint8_t* pending, const uint8_t* ok,
                                                       PfCtrl* ctrl, const SmcCtrl* sel, int64_t N) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (ctrl->done) return;  // uniform: the loop ended in an earlier iteration of this batch
     if (i < N) pending[i] = ok[i] ? 0 : 1;
     if (i == 0) {
         ctrl->nreps = 0;
         ctrl->remaining = (unsigned long long)(N - sel->ess);
+    }
+}
+
+// end of an iteration (:326-333): eff, the stop tests -- on the device, so that the host looks
+// once per batch of iterations instead of once per iteration
+__global__ void pf_iter_end_kernel(PfCtrl* ctrl, SmcCtrl* sel, int64_t N, double eff_tol, double epstol,
+                                   int64_t max_iters) {
+    if (ctrl->done) return;
+    if (sel->error) {
+        ctrl->error = sel->error;
+        ctrl->done = 1;
+        sel->done = 1;
+        return;
+    }
+    if (ctrl->remaining != 0ull) {  // (2^24 proposals did not replace some particle)
+        ctrl->error = 9;
+        ctrl->done = 1;
+        sel->done = 1;
+        return;
+    }
+    const long long iters = ctrl->iters + 1;
+    const double eps = sel->eps;
+    const double nbad = (double)(N - sel->ess);
+    const double eff = nbad / (double)ctrl->nreps;  // :327 (0/0 = NaN when nothing was bad, as in Julia)
+    ctrl->iters = iters;
+    ctrl->eps = eps;
+    ctrl->eff = eff;
+    if (eff < eff_tol || eps < epstol || (max_iters >= 0 && iters > max_iters) || !(ctrl->nreps > 0ull)) {
+        ctrl->done = 1;
+        sel->done = 1;  // (the select kernels still enqueued become no-ops)
     }
 }
 
@@ -67,6 +104,7 @@ __global__ void __launch_bounds__(kPfBlock) pf_attempt_kernel(const PfArgs A) {
     constexpr int CAP = DimOf<DT>::cap;
     const int D = DimOf<DT>::get(A.D_rt);
     unsigned long long reps = 0, evals = 0, done = 0;
+    if (A.ctrl->done) return;  // uniform
     if (i < A.N && A.pending[i]) {
         const uint64_t nok = (uint64_t)A.sel->ess;
         const double eps = A.sel->eps;
