@@ -54,6 +54,9 @@ struct AbcdeArgs {
     // donor index of every particle, drawn by abcde_donor_kernel (256 <= N < 4096: sixteen lanes
     // share one particle's scans); NULL = the generation kernel scans itself
     const int32_t* donor;
+    // 1: abcde_extrema_kernel first flips the buffer set (θs = nθs of the generation before,
+    // :413-415) -- one launch per generation less than a flip kernel of its own
+    int32_t flip_first;
     // length(prior) > KABC_MAX_DIM (kernels instantiated with D = 0): the dimension and the
     // prior as device arrays; rows and proposals then live in per-thread arrays of
     // KABC_MAX_DIM_DYN doubles (scratch memory) -- a fallback, several times slower per particle
@@ -166,7 +169,8 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_init_kernel(const AbcdeArgs
 __global__ void __launch_bounds__(1024) abcde_extrema_kernel(const AbcdeArgs A) {
     __shared__ double smin[16], smax[16];
     if (A.ctrl->done) return;
-    const double* dl = A.delta[A.ctrl->cur];
+    const int cur = A.ctrl->cur ^ (A.flip_first ? 1 : 0);  // (every thread: nobody writes ctrl before the end)
+    const double* dl = A.delta[cur];
     double mn = KABC_INF, mx = -KABC_INF;
     for (int64_t i = threadIdx.x; i < A.N; i += 1024) {
         const double v = dl[i];
@@ -188,6 +192,7 @@ __global__ void __launch_bounds__(1024) abcde_extrema_kernel(const AbcdeArgs A) 
             mn = smin[w] < mn ? smin[w] : mn;
             mx = smax[w] > mx ? smax[w] : mx;
         }
+        A.ctrl->cur = cur;
         A.ctrl->eps_l = mn;
         A.ctrl->eps_h = mx;
         if (A.earlystop && mx <= A.eps_target) {

@@ -445,6 +445,7 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         }
     }
     for (int64_t g = 0; g < o->generations; ++g) {  // while iters < generations (:372)
+        A.flip_first = g > 0 ? 1 : 0;  // (the flip after generation g - 1 rides on this launch)
         hipLaunchKernelGGL(abcde_extrema_kernel, dim3(1), dim3(1024), 0, s, A);
         if (d_donor)
             hipLaunchKernelGGL(abcde_donor_kernel,
@@ -454,8 +455,8 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         // kernel is a no-op: the host knows which one is current
         if (R.sorted) KABC_HIP_CHECK(build_rank(R, A.delta[g & 1], N, s));
         f_gen(A, s);
-        hipLaunchKernelGGL(abcde_flip_kernel, dim3(1), dim3(1), 0, s, A.ctrl);
     }
+    if (o->generations > 0) hipLaunchKernelGGL(abcde_flip_kernel, dim3(1), dim3(1), 0, s, A.ctrl);  // the last one
     KABC_HIP_CHECK(hipGetLastError());
     AbcdeFinalArgs F;
     for (int b = 0; b < 2; ++b) {
