@@ -250,7 +250,149 @@ def _pmc_table():
         return None, {}
 
 
+def spawn_ranks(n, argv, stub=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per
+    GPU, BEFORE this process has made any GPU call (the children are fresh interpreters; nothing
+    is exec'ed after a GPU initialisation).  The ranks get the variables a launcher would set
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT); their stderr passes through,
+    rank 0's stdout is relayed with its JSON line LAST, and the exit code is non-zero when any
+    rank failed (the others are ended: a rank that lost its peers would wait in a collective).
+    Returns (exit code, the JSON line or None)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:   # a free rendezvous port (it names the unique-id file, comm.py)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    out_f = tempfile.TemporaryFile(mode="w+")   # (a pipe would fill up: the line is tens of KB)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if stub is not None:
+            env["KABC_BENCH_STUB_RANK"] = stub
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=out_f if r == 0 else subprocess.DEVNULL))
+    t0, rc = time.time(), 0
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is not None:
+                live.discard(r)
+                if c != 0:
+                    rc = rc or c
+                    print(f"[bench] rank {r} exited with code {c}", file=sys.stderr, flush=True)
+        if (rc or (timeout and time.time() - t0 > timeout)) and live:
+            rc = rc or 124
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            live.clear()
+        if live:
+            time.sleep(0.05)
+    out_f.seek(0)
+    out0 = out_f.read()
+    out_f.close()
+    line = None
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    for ln in lines:
+        if ln.lstrip().startswith("{"):
+            try:
+                json.loads(ln)
+                line = ln
+            except ValueError:
+                pass
+    for ln in lines:
+        if ln is not line:
+            print(ln, flush=True)
+    if line is None and rc == 0:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc, line
+
+
+def stub_rank(mode, rank, world, args):
+    """tests/test_bench_spawn.py: a rank that stands in for the GPU work (no library call)"""
+    toks = mode.split(",")   # "ok" | "fail<r>" | "hang<r>", comma-separated
+    if f"hang{rank}" in toks:
+        time.sleep(600)
+    if f"fail{rank}" in toks:
+        time.sleep(0.5)
+        print(f"stub rank {rank} fails", file=sys.stderr, flush=True)
+        raise SystemExit(7)
+    time.sleep(0.2 * rank)
+    if rank == 0:
+        print("stub: a line that is not the result")
+        print(json.dumps({"metric": "stub", "value": 1.0, "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ranks_env": [os.environ.get(v) for v in
+                                                               ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR")]}),
+              flush=True)
+    raise SystemExit(0)
+
+
+def cold_spec_child():
+    """`bench.py --cold-spec`: the default (non-blocking) specialisation with an EMPTY code-object
+    cache, in a process of its own: first-call latency of k.AisEnsemble(...) against the same call
+    with KABC_SPECIALIZE=0, the time until the handle switched to the model's own kernels, and the
+    launches that ran before.  One JSON line."""
+    import tempfile
+    d = tempfile.mkdtemp(prefix="kabc_cold_rtc_")
+    os.environ["KABC_RTC_CACHE_DIR"] = d
+    os.environ["KABC_RTC_WORKERS"] = "4"
+    os.environ.pop("KABC_SPECIALIZE", None)
+    import kissabc_jl_amd as k
+    ctx = k.Context(int(os.environ.get("KABC_BENCH_DEVICE", "0")))
+    probs = prior_class_problems(k)
+    k.AisEnsemble(build_model(k), 4096, seed=SEED, ctx=ctx).init().advance(1, 4)   # context, module load
+    ctx.synchronize()
+    res, live = {}, {}
+
+    def first_call(m, Nm):
+        t0 = time.perf_counter()
+        e = k.AisEnsemble(m, Nm, seed=SEED, ctx=ctx).init()
+        e.advance(1, NT_HEADLINE)
+        ctx.synchronize()
+        return e, (time.perf_counter() - t0) * 1e3
+    for name, m, Nm, Dm in probs:
+        os.environ["KABC_SPECIALIZE"] = "0"
+        e0, ms0 = first_call(m, Nm)
+        e0.close()
+        os.environ.pop("KABC_SPECIALIZE")
+        t_create = time.perf_counter()
+        e, ms1 = first_call(m, Nm)
+        res[name] = {"first_call_ms_prebuilt_only": ms0, "first_call_ms_default": ms1,
+                     "state_after_first_call": e.spec_state()[0]}
+        live[name] = (e, t_create)
+    t0 = time.perf_counter()
+    while live and time.perf_counter() - t0 < 300:
+        for name in list(live):
+            e, t_create = live[name]
+            e.advance(1, NT_HEADLINE)
+            st, before = e.spec_state()
+            if st != "pending":
+                ctx.synchronize()
+                res[name].update(cold_compile_s=time.perf_counter() - t_create, state=st,
+                                 switched_after_launches=before)
+                e.close()
+                del live[name]
+        time.sleep(0.01)
+    for name in live:
+        res[name].update(state="pending after 300 s")
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
+    print(json.dumps({"cold_spec": res}), flush=True)
+
+
 def main():
+    if "--cold-spec" in sys.argv:
+        return cold_spec_child()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -266,16 +408,25 @@ def main():
     ap.add_argument("--no-alt", action="store_true",
                     help="time the headline ntransitions only (clean rocprof summaries)")
     ap.add_argument("--no-smc", action="store_true", help="skip the C4 smc leg")
+    ap.add_argument("--no-cold-spec", action="store_true",
+                    help="skip the cold-cache measurement of the default specialisation path (a child process)")
     args = ap.parse_args()
     nt_head = args.ntransitions
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with `python -m torch.distributed.run --nproc-per-node N "
-                         "bench.py --gpus N` (one process per GPU; the ranks find each other "
-                         "through RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)")
+    emulate = int(os.environ.get("KABC_BENCH_EMULATE_RANKS", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not emulate:
+        # no launcher: this process becomes the launcher (it has made no GPU call)
+        rc, _ = spawn_ranks(args.gpus, sys.argv[1:], stub=os.environ.get("KABC_BENCH_STUB_RANK"))
+        raise SystemExit(rc)
+    if os.environ.get("KABC_BENCH_STUB_RANK"):
+        stub_rank(os.environ["KABC_BENCH_STUB_RANK"], rank, world, args)
+    if world != args.gpus and not emulate:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with `python bench.py --gpus N` "
+                         "(the ranks are started here) or `python -m torch.distributed.run "
+                         "--nproc-per-node N bench.py --gpus N`")
 
     # The CPU baseline runs FIRST, before this process touches the GPU: its all-core
     # leg spawns worker processes, and a process that has initialised HIP must not
@@ -285,17 +436,71 @@ def main():
         import kissabc_jl_amd as k0
         cpu = cpu_baseline(k0, args.cpu_seconds, with_smc=not args.no_smc)
 
+    # ... and so does the cold-cache leg of the default specialisation path (its own process: the
+    # code-object cache must be empty and no unit loaded)
+    cold_spec = None
+    if world == 1 and not emulate and not args.no_alt and not args.no_cold_spec:
+        import subprocess
+        try:
+            cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-spec"],
+                                capture_output=True, text=True, timeout=420)
+            for ln in cp.stdout.splitlines():
+                if ln.startswith("{"):
+                    cold_spec = json.loads(ln).get("cold_spec")
+            if cold_spec is None:
+                cold_spec = {"error": (cp.stderr or "no output")[-500:]}
+        except Exception as e:   # informational: never fail the bench on it
+            cold_spec = {"error": repr(e)}
+
     import kissabc_jl_amd as k
-    from kissabc_jl_amd.comm import Comm
+    from kissabc_jl_amd.comm import Comm, EnsembleGroup
 
     dev = int(os.environ.get("KABC_BENCH_DEVICE", local_rank))
-    use_comm = world > 1 or os.environ.get("KABC_FORCE_COLLECTIVE") == "1"
+    use_comm = (world > 1 or os.environ.get("KABC_FORCE_COLLECTIVE") == "1") and not emulate
     comm = Comm.from_env(device=dev) if use_comm else None
-    ctx = comm.ctx if comm else k.Context(dev)
 
     model = build_model(k)
+    if emulate:
+        # Rehearsal of the world-N line on ONE GPU: N emulated ranks on device `dev` in this process,
+        # a real exchange between their shards through the P2P communicator (kabc_comm_init_all with
+        # a repeated device id).  Says so in the line; no scaling figure can be read from it.
+        world = emulate
+
+        class _Group:
+            def __init__(self):
+                self.g = EnsembleGroup(model, WALKERS_PER_GPU * emulate, seed=SEED, devices=[dev] * emulate,
+                                       backend="p2p").init()
+
+            def advance(self, gens, nt):
+                self.g.advance(gens, nt)
+
+            def stats(self):
+                return self.g.stats()
+
+            def set_timing(self, n, stride=1):
+                for sh in self.g.shards:
+                    sh.set_timing(n, stride=stride)
+
+            def kernel_ms(self):
+                v = [sh.kernel_ms() for sh in self.g.shards]
+                return sum(a for a, _ in v) / len(v), sum(b for _, b in v)
+
+            def exchange_us(self):
+                xs = [sh.exchange_us() for sh in self.g.shards]
+                return {kk: max(x[kk] for x in xs) for kk in xs[0]}
+
+            def synchronize(self):
+                self.g.synchronize()
+
+            def close(self):
+                self.g.close()
+        ens = _Group()
+        ctx = ens
+    else:
+        ctx = comm.ctx if comm else k.Context(dev)
     n_total = WALKERS_PER_GPU * world
-    ens = k.AisEnsemble(model, n_total, seed=SEED, ctx=ctx, comm=comm).init()
+    if not emulate:
+        ens = k.AisEnsemble(model, n_total, seed=SEED, ctx=ctx, comm=comm).init()
 
     def sync():
         ctx.synchronize()
@@ -323,7 +528,7 @@ def main():
         # hipEvent pairs on the kernel's stream, one pair per 8 consecutive half-generation
         # launches (a pair per launch adds ~3 us of marker overhead to every figure); with
         # collectives between the launches each launch gets its own pair instead
-        ens.set_timing(min(2 * steps * blocks, 8192), stride=1 if comm else 8)
+        ens.set_timing(min(2 * steps * blocks, 8192), stride=1 if (comm or emulate) else 8)
         el_r = 0.0
         for _ in range(blocks):
             sync()
@@ -335,9 +540,11 @@ def main():
         # exchange diagnostics (kabc_ais_exchange_us: hipEvent pairs on the stream the all-gather
         # runs on, over the first 128 timed half-generations): max over the ranks
         xch = None
-        if comm:
+        if comm or emulate:
             x = ens.exchange_us()
-            v = comm.allreduce_max([x["compute_us_per_half"], x["exchange_us_per_half"], x["exposed_us_per_half"]])
+            v = [x["compute_us_per_half"], x["exchange_us_per_half"], x["exposed_us_per_half"]]
+            if comm:
+                v = comm.allreduce_max(v)
             xch = {"compute_us_per_half": v[0], "exchange_us_per_half": v[1], "exposed_us_per_half": v[2],
                    "chunks": x["chunks"],
                    "note": "per half-generation, max over ranks: kernels / all-gather(s) on their stream / "
@@ -383,12 +590,13 @@ def main():
                               "evals_per_s_wall": N * nt_r * gens / el, "bytes_per_eval": Bm,
                               "roofline_frac": (N // 2) * nt_r * Bm / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         st = e.stats()
+        res["spec_state"], res["switched_after_launches"] = e.spec_state()
         e.close()
         res["accept_rate"] = st["accepted"] / max(1, st["proposals"])
         return res
 
     extra = {}
-    if world == 1 and not args.no_alt:
+    if world == 1 and not args.no_alt and isinstance(ctx, k.Context):
         # BASELINE.json configs[0]: the README example end to end through sample()
         rm = readme_problem(k)
         k.sample(rm, k.AIS(10), 1000, ntransitions=NT_HEADLINE, seed=1, ctx=ctx, return_array=True)
@@ -407,6 +615,27 @@ def main():
         if cpu and isinstance(cpu.get("readme_c1"), dict) and "wall_s" in cpu["readme_c1"]:
             extra["readme_c1"]["cpu_baseline"] = cpu["readme_c1"]
             extra["readme_c1"]["vs_cpu_port_1core"] = cpu["readme_c1"]["wall_s"] / w
+        # the same model as 50 chains at once (sample(model, AIS(10), MCMCThreads(), 1000, 50):
+        # test/runtests.jl:88-104 runs 50 chains of AIS(12)): chains are a grid dimension of every
+        # launch, so a single chain's latency is shared by all of them
+        try:
+            k.sample(rm, k.AIS(10), k.MCMCThreads(), 1000, 50, ntransitions=NT_HEADLINE, seed=1, ctx=ctx,
+                     return_array=True)
+            walls = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                rc50 = k.sample(rm, k.AIS(10), k.MCMCThreads(), 1000, 50, ntransitions=NT_HEADLINE, seed=1,
+                                ctx=ctx, return_array=True)
+                walls.append(time.perf_counter() - t0)
+            w50 = sorted(walls)[1]
+            extra["readme_c1"]["chains_50"] = {
+                "workload": "sample(model, AIS(10), MCMCThreads(), 1000, 50; ntransitions=100): 50 independent "
+                            "chains in one handle (kabc_ais_create_batch)",
+                "wall_ms": w50 * 1e3, "transitions_per_s": 50 * 1000 * NT_HEADLINE / w50,
+                "vs_single_chain_throughput": (50 * 1000 * NT_HEADLINE / w50) / (1000 * NT_HEADLINE / w),
+                "posterior_mean": rc50.reshape(-1, 2).mean(0).tolist()}
+        except Exception as e:   # informational
+            extra["readme_c1"]["chains_50"] = {"error": repr(e)}
         # README.md:80-84: `smc(prior, cost)` with its defaults on the same simulator
         for _ in range(2):
             k.smc(rm.prior, rm.cost, nparticles=100, seed=1, ctx=ctx, return_array=True)
@@ -454,7 +683,12 @@ def main():
         except Exception as e:  # informational legs: never fail the bench on them
             extra["next_rows"] = {"error": repr(e)}
         # BASELINE.json configs[1]
-        extra["c2"] = dict(kernel_leg(c2_problem(k), 4096, 2, nts=(NT_HEADLINE, 16)),
+        os.environ["KABC_SPECIALIZE"] = "0"
+        try:
+            c2_pre = kernel_leg(c2_problem(k), 4096, 2, nts=(NT_HEADLINE,))
+        finally:
+            os.environ.pop("KABC_SPECIALIZE", None)
+        extra["c2"] = dict(kernel_leg(c2_problem(k), 4096, 2, nts=(NT_HEADLINE, 16)), prebuilt=c2_pre,
                            workload="C2: AIS 4096 walkers, D=2, Normal(0,5)^2, gauss_dist, scale 0.1 "
                                     "(BASELINE.json configs[1]); 32 workgroups: bound by the latency of "
                                     "one wavefront's chain of dependent transitions, not by throughput")
@@ -470,31 +704,35 @@ def main():
                 v["latency_floor_frac"] = floor_us / v["kernel_avg_us"]
         if cpu and isinstance(cpu.get("c2"), dict) and "value" in cpu["c2"]:
             extra["c2"]["cpu_baseline"] = cpu["c2"]
-        # Each class on the prebuilt kernels and on the kernels specialised for the model
-        # (kabc_compile_model: the prior tuple's families and parameters as compile-time constants
-        # of a translation unit compiled by hipRTC at run time, cached on disk; same bits).
-        # `roofline_frac` etc. at the top level of a class are the specialised kernel's -- the path
-        # a user of compile_model(model) gets; `prebuilt` holds the other one.
+        # The prior classes the reference's own tests use beside boxes, on the DEFAULT path: nothing
+        # but k.AisEnsemble(model, N) -- the library specialises the model on its own without ever
+        # waiting for the compiler (include/kabc.h "THE DEFAULT"; here the unit comes from the
+        # on-disk cache build() warmed: switched_after_launches = 0).  `prebuilt` = the same call
+        # under KABC_SPECIALIZE=0; `cold` = the same call in a fresh process with an EMPTY cache:
+        # first-call latency against the prebuilt-only call, seconds until the handle switched to
+        # its own kernels, launches that ran before.  Same bits on every path.
         bpc = {}
         for name, m, Nm, Dm in prior_class_problems(k):
-            pre = kernel_leg(m, Nm, Dm)
-            entry = dict(pre, N=Nm, D=Dm, kernel="prebuilt")
+            os.environ["KABC_SPECIALIZE"] = "0"
             try:
-                t0 = time.perf_counter()
-                hdl = k.compile_model(m, families=1)
-                t_compile = time.perf_counter() - t0
-                if hdl:
-                    spec = kernel_leg(m, Nm, Dm)
-                    k._lib.check(k._lib.load().kabc_model_release(hdl))
-                    entry = dict(spec, N=Nm, D=Dm, kernel="specialised (kabc_compile_model)",
-                                 compile_or_cache_load_s=t_compile, prebuilt=pre)
-            except Exception as e:   # hipRTC missing: the prebuilt kernels remain the path
-                entry["specialise_error"] = repr(e)
+                pre = kernel_leg(m, Nm, Dm)
+            finally:
+                os.environ.pop("KABC_SPECIALIZE", None)
+            cur = kernel_leg(m, Nm, Dm)
+            entry = dict(cur, N=Nm, D=Dm, prebuilt=pre,
+                         kernel={"active": "the model's own (default path, k.AisEnsemble only)",
+                                 "pending": "prebuilt while the worker compiles (cold cache)"}.get(
+                                     cur["spec_state"], "prebuilt (" + cur["spec_state"] + ")"))
+            if isinstance(cold_spec, dict) and name in cold_spec:
+                entry["cold"] = cold_spec[name]
+                entry["cold_compile_s"] = cold_spec[name].get("cold_compile_s")
+            elif isinstance(cold_spec, dict) and "error" in cold_spec:
+                entry["cold"] = cold_spec
             bpc[name] = entry
         extra["by_prior_class"] = bpc
 
     smc = None
-    if world == 1 and not args.no_smc:
+    if world == 1 and not args.no_smc and isinstance(ctx, k.Context):
         prior, cost, kw = c4_problem(k)
         # warm-up: module load, allocations, and a one-off ~25 ms hiccup on the fourth call that
         # returns the 4 MiB particle array (host-side; steady state afterwards)
@@ -601,9 +839,10 @@ def main():
         # HBM bytes per launch from PMC counters are collected in separate rocprofv3
         # passes (FETCH_SIZE / WRITE_SIZE cannot share a pass); the committed summary
         # of that run is reported here when it was taken on this very workload.
-        traffic = None
+        traffic, traffic_file = None, None
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic_nt{nt_head}.json"))):
             traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            traffic_file = os.path.basename(tf)
         out = {
             "metric": "walker proposal+cost evals/sec at N=65536 walkers, D=8",
             "value": h["value"], "unit": "evals/s", "n_gpus": world, "steps": args.steps,
@@ -619,13 +858,22 @@ def main():
                                             "under by_ntransitions",
                        "evals_per_step": n_total * nt_head, "seed": SEED,
                        "timed_blocks": h["blocks"], "timed_seconds": h["timed_s"],
-                       "parallelism": f"walker-sharded x{world}, 1 RCCL all-gather per "
-                                      f"half-generation issued by libkabc_hip (no torch.distributed)"
-                       if world > 1 else "single GPU"},
+                       "parallelism": (f"REHEARSAL: {emulate} emulated ranks on ONE GPU, P2P exchange "
+                                       f"(KABC_BENCH_EMULATE_RANKS); not a scaling figure" if emulate else
+                                       f"walker-sharded x{world}, 1 RCCL all-gather per "
+                                       f"half-generation issued by libkabc_hip (no torch.distributed)"
+                                       if world > 1 else "single GPU"),
+                       **({"emulated_ranks": emulate} if emulate else {})},
             "cost_evals_per_s": h["cost_evals_per_s"], "accept_rate": h["accept_rate"],
             "roofline": {"bound": "hbm", "achieved": h["roofline_achieved_GBps"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h["roofline_frac"],
                          "traffic": traffic,
+                         "replayed_from": {"traffic": traffic_file, "valu.wave_insts_per_launch": pmc_file,
+                                           "valu.issue_cycles_per_inst": VALU_MIX_FILE,
+                                           "note": "PMC counters cannot be read inside this run (separate "
+                                                   "rocprofv3 --pmc passes): these fields replay the committed "
+                                                   "summaries of the builder's passes over this same command; "
+                                                   "achieved / frac / kernel_avg_ms are measured live"},
                          "kernel": "ais_half_kernel<8, rosenbrock, BOX, kernelized>",
                          "kernel_avg_ms": h["kernel_avg_us"] / 1e3,
                          "kernel_launches_timed": h["kernel_launches_timed"],

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KABC_VERSION 300 /* 0.3.0 */
+#define KABC_VERSION 310 /* 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
 /* AIS and smc accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM run-time-dimension
  * kernels keep the walker / particle rows in memory (several times slower per evaluation, same
@@ -254,6 +254,31 @@ kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32
 #define KABC_FAMILY_PFILTER 8
 kabc_status_t kabc_compile_model(const kabc_model_t* model, int32_t families, int32_t* out_handle);
 kabc_status_t kabc_model_release(int32_t handle);
+/* THE DEFAULT (KABC_SPECIALIZE unset): kabc_ais_create* / kabc_smc_run / kabc_abcde_run /
+ * kabc_pfilter_run specialise an eligible model ON THEIR OWN and never wait for the compiler --
+ * the reference gets the same from Julia's per-type compilation of logpdf(::Factored)
+ * (src/priors.jl:11,30-36).  The call starts on the prebuilt kernels; the model's unit is
+ * compiled by a detached worker process (<library directory>/kabc_rtc_worker, KABC_RTC_WORKER)
+ * into the on-disk cache of code objects (KABC_RTC_CACHE_DIR); an AIS handle looks for it at its
+ * launch boundaries and switches kernels when it is there, the run-to-completion entry points
+ * take it from their next call on.  The switch cannot be seen in the results (same bits).  A
+ * unit found in the cache is loaded at once (~1 ms).  Without hipRTC, the worker or a writable
+ * cache directory, and after a failed compilation, the prebuilt kernels stay, silently.
+ * KABC_SPECIALIZE=1: compile at first sight, blocking; =0: never specialise. */
+/* The same ahead of the first use, still without waiting: hands the units of `families` (as in
+ * kabc_compile_model) to the worker unless they are in the cache already.  A no-op for models
+ * that are not eligible. */
+kabc_status_t kabc_prefetch_model(const kabc_model_t* model, int32_t families);
+#define KABC_SPEC_NONE 0    /* prebuilt kernels: model not eligible, specialisation off or unavailable */
+#define KABC_SPEC_PENDING 1 /* prebuilt (or generic) kernels while the worker compiles              */
+#define KABC_SPEC_ACTIVE 2  /* the model's own kernels                                              */
+#define KABC_SPEC_FAILED 3  /* the compilation failed: prebuilt (or generic) kernels for good       */
+/* process-wide counters of the above: out[0] compilations handed to the worker, out[1] code
+ * objects it delivered that were loaded, out[2] failures, out[3] units found in the cache at
+ * first sight */
+void kabc_spec_counters(uint64_t out[4]);
+/* entry point of the worker process (csrc/rtc_worker.c); not for callers */
+int32_t kabc_rtc_worker_main(const char* jobfile);
 
 /* ---- AIS: sample(model, AIS(N), Ns; ntransitions, discard_initial, retry_sampling)
  *
@@ -333,6 +358,10 @@ kabc_status_t kabc_ais_set_state(kabc_ais_t* h, const double* x, const double* l
                                  const double* loglik, uint64_t t);
 /* cumulative counters since create (device-side counters, read synchronously) */
 kabc_status_t kabc_ais_get_stats(kabc_ais_t* h, kabc_stats_t* stats);
+/* which kernels the handle's half-generation launches run on: *state = KABC_SPEC_*;
+ * *launches_before_switch = launches that ran on the prebuilt kernels before the model's own
+ * took over (0: specialised from the first launch; -1: not switched) */
+kabc_status_t kabc_ais_spec_state(kabc_ais_t* h, int32_t* state, int64_t* launches_before_switch);
 /* number of walkers this handle owns, and per half */
 int64_t kabc_ais_owned(const kabc_ais_t* h, int32_t half);
 /* Per-launch timing: bracket each of the next `max_launches` half-generation

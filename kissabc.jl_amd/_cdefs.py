@@ -7,7 +7,7 @@ import ctypes as C
 
 KABC_MAX_DIM = 16
 KABC_MAX_DIM_DYN = 256   # AIS only: run-time-dimension kernels beyond KABC_MAX_DIM
-KABC_VERSION = 300   # include/kabc.h
+KABC_VERSION = 310   # include/kabc.h
 KABC_COMM_ID_BYTES = 128
 KABC_MAX_EXCHANGE_CHUNKS = 16
 KABC_COMM_MAX_WORLD = 16
@@ -129,6 +129,10 @@ PROTOTYPES = {
     "kabc_compile_prior_plugin": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
     "kabc_compile_model": (C.c_int, [C.POINTER(Model), C.c_int32, C.POINTER(C.c_int32)]),
     "kabc_model_release": (C.c_int, [C.c_int32]),
+    "kabc_prefetch_model": (C.c_int, [C.POINTER(Model), C.c_int32]),
+    "kabc_spec_counters": (None, [C.POINTER(C.c_uint64)]),
+    "kabc_rtc_worker_main": (C.c_int32, [C.c_char_p]),
+    "kabc_ais_spec_state": (C.c_int, [VP, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "kabc_ais_create": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_uint64, C.POINTER(VP)]),
     "kabc_ais_create_batch": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_int32,
                                         C.POINTER(C.c_uint64), C.POINTER(VP)]),

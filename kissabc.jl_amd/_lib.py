@@ -122,7 +122,7 @@ def default_context(device=0):
 # 268 MB (an smc result at 2 M particles x 16) costs as much as copying into it ten times.
 _pinned_free = {}            # nbytes -> [address, ...]
 _pinned_free_bytes = 0
-_pinned_lock = threading.Lock()
+_pinned_lock = threading.RLock()   # (re-entrant: a GC pass inside the locked region may finalise another block)
 
 
 def _pinned_cache_cap():

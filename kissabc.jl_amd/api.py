@@ -253,6 +253,16 @@ class AisEnsemble:
         _lib.check(_lib.load().kabc_ais_get_stats(self._h, C.byref(st)))
         return {"proposals": st.proposals, "cost_evals": st.cost_evals, "accepted": st.accepted}
 
+    SPEC_STATES = ("none", "pending", "active", "failed")   # KABC_SPEC_* of include/kabc.h
+
+    def spec_state(self):
+        """(state, launches_before_switch): which kernels the half-generation launches run on --
+        the prebuilt ones ("none" / "pending" / "failed") or the model's own ("active", the default
+        non-blocking specialisation of include/kabc.h); launches that ran before the switch, -1."""
+        st, n = C.c_int32(0), C.c_int64(-1)
+        _lib.check(_lib.load().kabc_ais_spec_state(self._h, C.byref(st), C.byref(n)))
+        return self.SPEC_STATES[st.value], n.value
+
     def ensemble(self):
         """[N][D] unrounded positions of ALL walkers in walker-id order (for a sharded
         handle: this rank's copy after the last all-gather)."""

@@ -1079,7 +1079,7 @@ inline dim3 ais_init_geom(const InitArgs& a, unsigned nchains) {
 AisLaunch find_ais_kernel(int cost_id, int D, int pcx);
 constexpr int kAisVariants = 3 * kPriorClasses;
 struct ModelUnit;
-void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains, ModelUnit* unit);
+bool launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains, ModelUnit* unit);
 
 #endif
 

@@ -322,32 +322,32 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
     if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
         const PluginKernel ki = unit_kernel(unit, kPfAbcdeInit, D, 0), kg = unit_kernel(unit, kPfAbcdeGen, D, 0);
-        if (ki.mod && kg.mod) {
-            f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
-            f_gen = AbcdeLaunch(kg.mod, &abcde_geom, (unsigned)kAbcdeBlock);
-        } else if (!unit_is_spec(unit)) {
-            return KABC_ERR_DEVICE;
-        } else {
-            unit = nullptr;
-        }
+        if (ki.mod) f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
+        if (kg.mod) f_gen = AbcdeLaunch(kg.mod, &abcde_geom, (unsigned)kAbcdeBlock);
+        if ((!f_init || !f_gen) && unit_required(unit)) return KABC_ERR_DEVICE;
+        // (a specialisation that is not there (yet): what is missing comes from below, same bits)
     }
-    if (unit) {
-    } else if (dyn) {
-        f_init = AbcdeLaunch(&l_init<0>);
-        f_gen = AbcdeLaunch(&l_gen<0>);
-    } else if (const CostPlugin* p = find_plugin(cost->id)) {
-        const PluginKernel ki = plugin_kernel(p, kPfAbcdeInit, D, 0), kg = plugin_kernel(p, kPfAbcdeGen, D, 0);
-        f_init = ki.host ? AbcdeLaunch((AbcdeLaunchFn)ki.host)
-                         : ki.mod ? AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
-        f_gen = kg.host ? AbcdeLaunch((AbcdeLaunchFn)kg.host)
-                        : kg.mod ? AbcdeLaunch(kg.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
-        if (!f_init || !f_gen) {
-            set_error("cost plugin has no ABCDE kernels for D = %d", D);
-            return KABC_ERR_UNSUPPORTED;
+    if (!f_init || !f_gen) {
+        AbcdeLaunch b_init, b_gen;
+        if (dyn) {
+            b_init = AbcdeLaunch(&l_init<0>);
+            b_gen = AbcdeLaunch(&l_gen<0>);
+        } else if (const CostPlugin* p = find_plugin(cost->id)) {
+            const PluginKernel ki = plugin_kernel(p, kPfAbcdeInit, D, 0), kg = plugin_kernel(p, kPfAbcdeGen, D, 0);
+            b_init = ki.host ? AbcdeLaunch((AbcdeLaunchFn)ki.host)
+                             : ki.mod ? AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
+            b_gen = kg.host ? AbcdeLaunch((AbcdeLaunchFn)kg.host)
+                            : kg.mod ? AbcdeLaunch(kg.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
+            if (!b_init || !b_gen) {
+                set_error("cost plugin has no ABCDE kernels for D = %d", D);
+                return KABC_ERR_UNSUPPORTED;
+            }
+        } else {
+            b_init = pick_init(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+            b_gen = pick_gen(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
         }
-    } else {
-        f_init = pick_init(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
-        f_gen = pick_gen(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+        if (!f_init) f_init = b_init;
+        if (!f_gen) f_gen = b_gen;
     }
     if (!dyn) std::memcpy(A.raw, prior, sizeof(kabc_prior_t) * D);
     KABC_HIP_CHECK(hipSetDevice(ctx->device));

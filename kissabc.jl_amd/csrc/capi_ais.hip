@@ -1,6 +1,7 @@
 // capi_ais.hip -- the AIS entry points of the C ABI (include/kabc.h):
 // AIS(N) + AISState + step(init) + step(advance) of src/KissABC.jl:21-80,
 // executed by the gfx950 kernels in ais_kernels.hpp.
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -78,20 +79,25 @@ static void launch_init_table(int D, const InitArgs& a, hipStream_t s, unsigned 
     fns[D - 1](a, s, nchains);
 }
 
-void launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains, ModelUnit* unit) {
-    if (unit) {  // user prior families / a specialised model: the unit's own init kernel
+bool launch_ais_init(int D, const InitArgs& a, hipStream_t s, unsigned nchains, ModelUnit* unit) {
+    if (unit) {  // user prior families / a specialisation compiled ahead: the unit's own init kernel
         const PluginKernel k = unit_kernel(unit, kPfAisInit, D, 0);
-        if (k.mod) AisInitLaunch(k.mod, &ais_init_geom, (unsigned)kInitBlock)(a, s, nchains);
-        return;
+        if (k.mod) {
+            AisInitLaunch(k.mod, &ais_init_geom, (unsigned)kInitBlock)(a, s, nchains);
+            return true;
+        }
+        if (unit_required(unit)) return false;  // (message set by the compilation / load)
     }
     if (const CostPlugin* p = find_plugin(a.cost_id)) {
         const PluginKernel k = plugin_kernel(p, kPfAisInit, D, 0);
         using Fn = void (*)(const InitArgs&, hipStream_t, unsigned);
         if (k.host) AisInitLaunch((Fn)k.host)(a, s, nchains);
         else if (k.mod) AisInitLaunch(k.mod, &ais_init_geom, (unsigned)kInitBlock)(a, s, nchains);
-        return;
+        else return false;
+        return true;
     }
     launch_init_table(D, a, s, nchains, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+    return true;
 }
 
 }  // namespace kabc
@@ -144,6 +150,12 @@ struct kabc_ais {
     int32_t rank, world;
     AisLaunch launch;
     ModelUnit* unit;       // run-time compiled unit (user prior families / specialised model), else NULL
+    // the model's own kernels (the default, non-blocking specialisation: plugin_registry.hpp)
+    int32_t spec_state;    // KABC_SPEC_*
+    int32_t spec_variant;  // the AIS variant asked of the unit while KABC_SPEC_PENDING
+    int64_t launches;      // half-generation launches so far
+    int64_t spec_switch_at;  // launches that ran before the switch, -1
+    std::chrono::steady_clock::time_point spec_next_poll;
     double box_lp;
     bool initialised;
     // sample-trace streaming: device chunks filled in rotation by the kernels and
@@ -355,13 +367,15 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
             }
     }
     AisLaunch fn;
+    int spec_state = KABC_SPEC_NONE;
+    const int spec_variant = kPriorGeneral + kPriorClasses * (m->posterior - 1);
     if (unit) {
-        const PluginKernel uk = unit_kernel(unit, kPfAis, m->D, kPriorGeneral + kPriorClasses * (m->posterior - 1));
+        const PluginKernel uk = unit_kernel(unit, kPfAis, m->D, spec_variant, &spec_state);
         if (uk.mod) fn = AisLaunch(uk.mod, &ais_half_geom, (unsigned)kAisBlock);
-        if (!fn && unit_is_spec(unit)) unit = nullptr;  // (a specialisation that cannot be built: the prebuilt kernels)
-        else if (!fn) return KABC_ERR_DEVICE;            // (message set by the compilation / load)
+        // user families: there are no other kernels (message set by the compilation / load)
+        if (!fn && unit_required(unit)) return KABC_ERR_DEVICE;
     }
-    if (!unit) {
+    if (!fn) {  // (no unit, or a specialisation that is not there (yet): the prebuilt kernels)
         fn = dyn ? AisLaunch() : find_ais_kernel(m->cost.id, m->D, pc + kPriorClasses * (m->posterior - 1));
         if (!fn && !dyn && pc == kPriorNormal)  // plugins instantiate SIMPLE only
             fn = find_ais_kernel(m->cost.id, m->D, kPriorSimple + kPriorClasses * (m->posterior - 1));
@@ -398,6 +412,10 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     }
     h->launch = fn;
     h->unit = unit;
+    h->spec_state = spec_state;
+    h->spec_variant = spec_variant;
+    h->launches = 0;
+    h->spec_switch_at = spec_state == KABC_SPEC_ACTIVE ? 0 : -1;
     // BOX class: logpdf inside the box = c0_1 + ... + c0_D, summed left to right
     // exactly as logpdf(d::Factored, x) does (src/priors.jl:30-36)
     h->box_lp = h->prior.c[0].c0;
@@ -621,7 +639,10 @@ static kabc_status_t ais_init_enqueue(kabc_ais_t* h, int32_t retry_sampling) {
             a.chain_retries = h->d_chain_retries;
             a.stride_act = h->rows[hf] * h->D;
             a.stride_own = h->rows_owned[hf];
-            launch_ais_init(h->D, a, s, (unsigned)h->nchains, h->unit);
+            if (!launch_ais_init(h->D, a, s, (unsigned)h->nchains, h->unit)) {
+                if (!get_error()[0]) set_error("no init kernel for cost id %d, D = %d", h->cost_id, h->D);
+                return KABC_ERR_DEVICE;
+            }
             KABC_HIP_CHECK(hipGetLastError());
         }
     }
@@ -756,11 +777,30 @@ static kabc_status_t timing_close_pair(kabc_ais_t* h) {
     return KABC_OK;
 }
 
+// A handle that started on the prebuilt kernels while the worker compiles the model's own: look
+// for them (a map lookup; a stat() at most every 2 ms) and switch.  Same bits either way.
+static void ais_poll_spec(kabc_ais_t* h) {
+    const auto now = std::chrono::steady_clock::now();
+    if (now < h->spec_next_poll) return;
+    h->spec_next_poll = now + std::chrono::milliseconds(2);
+    int st = KABC_SPEC_NONE;
+    const PluginKernel k = unit_kernel(h->unit, kPfAis, h->D, h->spec_variant, &st);
+    if (st == KABC_SPEC_ACTIVE && k.mod) {
+        h->launch = AisLaunch(k.mod, &ais_half_geom, (unsigned)kAisBlock);
+        h->spec_state = KABC_SPEC_ACTIVE;
+        h->spec_switch_at = h->launches;
+    } else if (st == KABC_SPEC_FAILED) {
+        h->spec_state = KABC_SPEC_FAILED;
+    }
+}
+
 // one launch: `ntransitions` transitions for the owned rows of segment `sg` of `half`
 static kabc_status_t launch_half_seg(kabc_ais_t* h, int32_t half, const kabc_ais::Seg& sg,
                                      int32_t ntransitions, double* dev_trace_rows) {
     if (sg.count == 0) return KABC_OK;
     hipStream_t s = h->ctx->stream;
+    if (h->spec_state == KABC_SPEC_PENDING) ais_poll_spec(h);
+    h->launches++;
     // debug records: layout [N_owned][nt][6] in the order of the owned rows (half 0 first)
     int32_t* dbg = nullptr;
     if (h->d_dbg) {
@@ -1304,6 +1344,13 @@ int32_t kabc_ais_owned_segments(const kabc_ais_t* h, int32_t half, int64_t* firs
         if (count) count[i] = h->seg[half][i].count;
     }
     return n;
+}
+
+kabc_status_t kabc_ais_spec_state(kabc_ais_t* h, int32_t* state, int64_t* launches_before_switch) {
+    if (check_handle(h)) return KABC_ERR_INVALID_ARG;
+    if (state) *state = h->spec_state;
+    if (launches_before_switch) *launches_before_switch = h->spec_switch_at;
+    return KABC_OK;
 }
 
 kabc_status_t kabc_ais_set_timing_stride(kabc_ais_t* h, int32_t stride) {

@@ -21,9 +21,15 @@
 //       that carries the run-time-dimension kernels for length(prior) > KABC_MAX_DIM).
 #include <dirent.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hiprtc.h>
+#include <spawn.h>
 #include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
+
+#include <atomic>
+#include <chrono>
 
 #include <algorithm>
 #include <map>
@@ -34,6 +40,8 @@
 #include "host_common.hpp"
 #include "launcher.hpp"
 #include "plugin_registry.hpp"
+
+extern "C" char** environ;
 
 namespace kabc {
 
@@ -132,10 +140,18 @@ static std::vector<std::string> rtc_include_dirs() {
 
 // ---- what gets compiled ---------------------------------------------------------------------
 // kernels compiled so far from one translation-unit recipe, per device
+// a compilation handed to the worker process (rtc_kernel_try)
+struct RtcAsyncJob {
+    enum State { kDeferred, kPending, kFailed } state = kPending;  // deferred: the workers are busy, ask again
+    std::string cpath;
+    std::chrono::steady_clock::time_point t_spawn, t_poll;
+    std::string why;  // (failed)
+};
 struct RtcCache {
     std::mutex mu;
     std::map<std::string, void*> fns;  // "<device>|<name expression>" -> hipFunction_t
     std::vector<hipModule_t> mods;
+    std::map<std::string, RtcAsyncJob> jobs;  // by the wanted name expression (process-wide, not per device)
 };
 
 struct RtcPlugin : RtcCache {
@@ -276,19 +292,40 @@ static uint64_t toolchain_fingerprint() {
     return fp;
 }
 
-// KABC_RTC_CACHE_DIR, else <library directory>/rtc_cache; "" or "0" disables
+static std::string lib_dir() {
+    Dl_info info;
+    if (dladdr((const void*)&find_plugin, &info) && info.dli_fname) {
+        std::string lib(info.dli_fname);
+        const size_t sl = lib.rfind('/');
+        return sl == std::string::npos ? std::string(".") : lib.substr(0, sl);
+    }
+    return std::string();
+}
+
+// KABC_RTC_CACHE_DIR, else <library directory>/rtc_cache, else (a read-only install)
+// /tmp/kabc_rtc_cache_<uid>; "" or "0" disables
 static std::string rtc_cache_dir() {
     if (const char* e = std::getenv("KABC_RTC_CACHE_DIR")) {
         const std::string v(e);
         return (v.empty() || v == "0") ? std::string() : v;
     }
-    Dl_info info;
-    if (dladdr((const void*)&find_plugin, &info) && info.dli_fname) {
-        std::string lib(info.dli_fname);
-        const size_t sl = lib.rfind('/');
-        return (sl == std::string::npos ? std::string(".") : lib.substr(0, sl)) + "/rtc_cache";
-    }
-    return std::string();
+    static std::string dir;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const std::string ld = lib_dir();
+        if (!ld.empty()) {
+            const std::string d = ld + "/rtc_cache";
+            (void)mkdir(d.c_str(), 0777);
+            if (access(d.c_str(), W_OK | X_OK) == 0) {
+                dir = d;
+                return;
+            }
+        }
+        const std::string t = "/tmp/kabc_rtc_cache_" + std::to_string((long long)getuid());
+        (void)mkdir(t.c_str(), 0700);
+        if (access(t.c_str(), W_OK | X_OK) == 0) dir = t;
+    });
+    return dir;
 }
 
 static bool cache_load(const std::string& path, size_t nnames, std::vector<char>* code,
@@ -341,38 +378,46 @@ static void cache_store(const std::string& dir, const std::string& path, const s
     if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
 }
 
-// compile `names` (kernel name expressions) from `head` (snippets, model constants) + `header`
-// (the kernel templates) into one code object
-static kabc_status_t rtc_compile(const std::string& head, const char* header, bool fma_c_vgpr,
-                                 const std::vector<std::string>& names, std::vector<char>* code,
-                                 std::vector<std::string>* lowered) {
+// everything that determines a code object: the unit's text, the compiler options, the cache path
+struct RtcJob {
+    std::string text;
+    std::vector<std::string> opt;
+    std::string cdir, cpath;  // on-disk cache (empty: disabled)
+};
+
+static void rtc_prepare(const std::string& head, const char* header, bool fma_c_vgpr,
+                        const std::vector<std::string>& names, bool want_cache, RtcJob* J) {
+    J->text = "// generated by libkabc_hip (capi_plugin.hip)\n" + head;
+    if (fma_c_vgpr) J->text += "#define KABC_FMA_C_VGPR\n";
+    if (header) J->text += std::string("#include \"") + header + "\"\n";
+    // the flags of csrc/Makefile: the arithmetic contract needs -ffp-contract=off
+    J->opt = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+    // the on-disk cache: keyed by everything that determines the code object
+    J->cdir = want_cache ? rtc_cache_dir() : std::string();
+    J->cpath.clear();
+    if (!J->cdir.empty()) {
+        uint64_t h = fnv1a(J->text.data(), J->text.size(), toolchain_fingerprint());
+        uint64_t h2 = fnv1a(J->text.data(), J->text.size(), 0x9e3779b97f4a7c15ull ^ toolchain_fingerprint());
+        for (const std::string& n : names) {
+            h = fnv1a(n.data(), n.size() + 1, h);
+            h2 = fnv1a(n.data(), n.size() + 1, h2);
+        }
+        for (const std::string& o : J->opt) h = fnv1a(o.data(), o.size() + 1, h);
+        char nm[64];
+        std::snprintf(nm, sizeof nm, "/kabc_%016llx%016llx.co", (unsigned long long)h, (unsigned long long)h2);
+        J->cpath = J->cdir + nm;
+    }
+}
+
+// hipRTC proper: `text` -> one gfx950 code object + the lowered names of `names`
+static kabc_status_t rtc_compile_text(const std::string& text, std::vector<std::string> opt,
+                                      const std::vector<std::string>& names, std::vector<char>* code,
+                                      std::vector<std::string>* lowered) {
     Hiprtc* H = hiprtc();
     if (!H) {
         set_error("hipRTC is not available: %s(set KABC_HIPRTC_LIB, or register a plugin .so built "
                   "by hipcc with kabc_register_cost_plugin)", g_rtc.why.c_str());
         return KABC_ERR_DEVICE;
-    }
-    std::string text = "// generated by libkabc_hip (capi_plugin.hip)\n" + head;
-    if (fma_c_vgpr) text += "#define KABC_FMA_C_VGPR\n";
-    if (header) text += std::string("#include \"") + header + "\"\n";
-    // the flags of csrc/Makefile: the arithmetic contract needs -ffp-contract=off
-    std::vector<std::string> opt = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                                    "-fno-fast-math"};
-    // the on-disk cache: keyed by everything that determines the code object
-    std::string cpath;
-    const std::string cdir = code ? rtc_cache_dir() : std::string();
-    if (!cdir.empty()) {
-        uint64_t h = fnv1a(text.data(), text.size(), toolchain_fingerprint());
-        uint64_t h2 = fnv1a(text.data(), text.size(), 0x9e3779b97f4a7c15ull ^ toolchain_fingerprint());
-        for (const std::string& n : names) {
-            h = fnv1a(n.data(), n.size() + 1, h);
-            h2 = fnv1a(n.data(), n.size() + 1, h2);
-        }
-        for (const std::string& o : opt) h = fnv1a(o.data(), o.size() + 1, h);
-        char nm[64];
-        std::snprintf(nm, sizeof nm, "/kabc_%016llx%016llx.co", (unsigned long long)h, (unsigned long long)h2);
-        cpath = cdir + nm;
-        if (cache_load(cpath, names.size(), code, lowered)) return KABC_OK;
     }
     hiprtcProgram prog = nullptr;
     if (H->CreateProgram(&prog, text.c_str(), "kabc_rtc_unit.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) {
@@ -404,25 +449,28 @@ static kabc_status_t rtc_compile(const std::string& head, const char* header, bo
             (void)H->GetLoweredName(prog, n.c_str(), &low);
             lowered->push_back(low ? low : "");
         }
-        if (!cpath.empty()) cache_store(cdir, cpath, *code, *lowered);
     }
     (void)H->DestroyProgram(&prog);
     return KABC_OK;
 }
 
-// the kernel `want` of a family on the CURRENT device (every entry point selects its context's
-// device before it looks kernels up); the whole batch `names` is compiled together on a miss
-static void* rtc_kernel(RtcCache* R, const std::string& head, const char* header, bool fma_c_vgpr,
-                        const std::vector<std::string>& names, const std::string& want) {
-    int dev = -1;
-    if (hipGetDevice(&dev) != hipSuccess) dev = -1;  // (no device: the compilation still runs, the load fails)
+// compile `names` (kernel name expressions) from `head` (snippets, model constants) + `header`
+// (the kernel templates) into one code object
+static kabc_status_t rtc_compile(const std::string& head, const char* header, bool fma_c_vgpr,
+                                 const std::vector<std::string>& names, std::vector<char>* code,
+                                 std::vector<std::string>* lowered) {
+    RtcJob J;
+    rtc_prepare(head, header, fma_c_vgpr, names, code != nullptr, &J);
+    if (!J.cpath.empty() && cache_load(J.cpath, names.size(), code, lowered)) return KABC_OK;
+    if (kabc_status_t st = rtc_compile_text(J.text, J.opt, names, code, lowered)) return st;
+    if (code && !J.cpath.empty()) cache_store(J.cdir, J.cpath, *code, *lowered);
+    return KABC_OK;
+}
+
+// loads a code object on the current device and records its kernels (R->mu held)
+static void* rtc_load(RtcCache* R, int dev, const std::vector<char>& code, const std::vector<std::string>& names,
+                      const std::vector<std::string>& lowered, const std::string& want) {
     const std::string pre = std::to_string(dev) + "|";
-    std::lock_guard<std::mutex> lk(R->mu);
-    auto it = R->fns.find(pre + want);
-    if (it != R->fns.end()) return it->second;
-    std::vector<char> code;
-    std::vector<std::string> lowered;
-    if (rtc_compile(head, header, fma_c_vgpr, names, &code, &lowered) != KABC_OK) return nullptr;
     hipModule_t mod = nullptr;
     const hipError_t e = dev < 0 ? hipErrorNoDevice : hipModuleLoadData(&mod, code.data());
     if (e != hipSuccess) {
@@ -436,12 +484,264 @@ static void* rtc_kernel(RtcCache* R, const std::string& head, const char* header
         if (!lowered[i].empty() && hipModuleGetFunction(&f, mod, lowered[i].c_str()) == hipSuccess)
             R->fns[pre + names[i]] = (void*)f;
     }
-    it = R->fns.find(pre + want);
+    auto it = R->fns.find(pre + want);
     if (it == R->fns.end()) {
         set_error("kernel %s is missing from the compiled unit", want.c_str());
         return nullptr;
     }
     return it->second;
+}
+
+// the kernel `want` of a family on the CURRENT device (every entry point selects its context's
+// device before it looks kernels up); the whole batch `names` is compiled together on a miss
+static void* rtc_kernel(RtcCache* R, const std::string& head, const char* header, bool fma_c_vgpr,
+                        const std::vector<std::string>& names, const std::string& want) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;  // (no device: the compilation still runs, the load fails)
+    std::lock_guard<std::mutex> lk(R->mu);
+    auto it = R->fns.find(std::to_string(dev) + "|" + want);
+    if (it != R->fns.end()) return it->second;
+    std::vector<char> code;
+    std::vector<std::string> lowered;
+    if (rtc_compile(head, header, fma_c_vgpr, names, &code, &lowered) != KABC_OK) return nullptr;
+    return rtc_load(R, dev, code, names, lowered, want);
+}
+
+// ---- compilation off the caller's thread: a worker PROCESS ----------------------------------
+// The default path of a model that can be specialised must never wait for the compiler (2-20 s
+// per AIS kernel): the caller starts on the prebuilt kernels, the unit's text goes to
+// <library directory>/kabc_rtc_worker (csrc/rtc_worker.c: a detached process that loads this
+// library and calls kabc_rtc_worker_main -- no GPU, no thread inside the host application, nothing
+// to join at exit; it finishes and fills the on-disk cache even when its parent has gone), and the
+// caller looks for the code object in the cache at its next launch boundaries.
+struct SpecCounters {
+    std::atomic<uint64_t> spawned{0}, loaded{0}, failed{0}, cache_hits{0};
+};
+static SpecCounters g_spec_counters;
+
+static std::string worker_path() {
+    if (const char* e = std::getenv("KABC_RTC_WORKER")) return e;
+    const std::string ld = lib_dir();
+    return ld.empty() ? std::string() : ld + "/kabc_rtc_worker";
+}
+
+static std::string self_lib_path() {
+    Dl_info info;
+    return (dladdr((const void*)&find_plugin, &info) && info.dli_fname) ? std::string(info.dli_fname) : std::string();
+}
+
+static bool async_compile_available() {
+    const std::string w = worker_path();
+    return !w.empty() && access(w.c_str(), X_OK) == 0 && !rtc_cache_dir().empty() && !self_lib_path().empty();
+}
+
+static bool file_exists(const std::string& p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0;
+}
+
+static std::string read_small_file(const std::string& p) {
+    std::string out;
+    if (FILE* f = std::fopen(p.c_str(), "rb")) {
+        char buf[2048];
+        const size_t n = std::fread(buf, 1, sizeof buf - 1, f);
+        out.assign(buf, n);
+        std::fclose(f);
+    }
+    return out;
+}
+
+// compilations in flight in this cache directory, whoever started them (fresh lock files): the
+// worker processes of ALL processes sharing the cache are bounded by KABC_RTC_WORKERS (default 2)
+// -- a test-suite or a service creating a hundred models in a minute must not start a hundred
+// compilers
+static int workers_in_flight(const std::string& cdir) {
+    int n = 0;
+    if (DIR* dir = opendir(cdir.c_str())) {
+        const time_t now = time(nullptr);
+        while (const dirent* e = readdir(dir)) {
+            const size_t len = std::strlen(e->d_name);
+            if (len < 5 || std::strcmp(e->d_name + len - 5, ".lock") != 0) continue;
+            struct stat st;
+            if (stat((cdir + "/" + e->d_name).c_str(), &st) == 0 && now - st.st_mtime < 600) ++n;
+        }
+        closedir(dir);
+    }
+    return n;
+}
+static int max_workers() {
+    const char* e = std::getenv("KABC_RTC_WORKERS");
+    const int v = e ? std::atoi(e) : 2;
+    return v < 1 ? 1 : v;
+}
+
+// writes the job file and starts the worker; false: could not (message in *why)
+static bool spawn_worker(const RtcJob& J, const std::vector<std::string>& names, std::string* why) {
+    const std::string lock = J.cpath + ".lock";
+    const int lfd = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY | O_CLOEXEC, 0666);
+    if (lfd < 0) {
+        struct stat st;
+        if (errno == EEXIST && stat(lock.c_str(), &st) == 0 && time(nullptr) - st.st_mtime < 600)
+            return true;  // another process (or handle) is compiling exactly this unit: wait for its result
+        (void)unlink(lock.c_str());  // (a worker that died)
+        const int l2 = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY | O_CLOEXEC, 0666);
+        if (l2 < 0) {
+            *why = "cannot create " + lock + ": " + std::strerror(errno);
+            return false;
+        }
+        close(l2);
+    } else {
+        close(lfd);
+    }
+    const std::string job = J.cpath + ".job";
+    FILE* f = std::fopen(job.c_str(), "wb");
+    bool ok = f != nullptr;
+    if (ok) {
+        std::string hd = "KABCJOB1\n" + J.cpath + "\n" + std::to_string(J.opt.size()) + "\n";
+        for (const std::string& o : J.opt) hd += o + "\n";
+        hd += std::to_string(names.size()) + "\n";
+        for (const std::string& n : names) hd += n + "\n";
+        hd += std::to_string(J.text.size()) + "\n";
+        ok = std::fwrite(hd.data(), 1, hd.size(), f) == hd.size() &&
+             std::fwrite(J.text.data(), 1, J.text.size(), f) == J.text.size();
+        ok = (std::fclose(f) == 0) && ok;
+    }
+    if (!ok) {
+        *why = "cannot write " + job;
+        (void)unlink(lock.c_str());
+        return false;
+    }
+    // the worker's environment: ours without the variables that would make a tool (profiler,
+    // preload) initialise the GPU inside it
+    std::vector<char*> envp;
+    for (char** e = ::environ; e && *e; ++e) {
+        static const char* drop[] = {"LD_PRELOAD=", "HSA_TOOLS_LIB=", "ROCP_", "ROCPROF", "ROCTRACER_", "HIP_PROFILE"};
+        bool skip = false;
+        for (const char* d : drop) skip = skip || std::strncmp(*e, d, std::strlen(d)) == 0;
+        if (!skip) envp.push_back(*e);
+    }
+    envp.push_back(nullptr);
+    const std::string w = worker_path(), lib = self_lib_path();
+    char* argv[] = {const_cast<char*>(w.c_str()), const_cast<char*>(lib.c_str()), const_cast<char*>(job.c_str()), nullptr};
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+    posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+    posix_spawn_file_actions_addopen(&fa, 2, "/dev/null", O_WRONLY, 0);
+    pid_t pid = 0;
+    const int rc = posix_spawn(&pid, w.c_str(), &fa, nullptr, argv, envp.data());
+    posix_spawn_file_actions_destroy(&fa);
+    if (rc != 0) {
+        *why = "cannot start " + w + ": " + std::strerror(rc);
+        (void)unlink(job.c_str());
+        (void)unlink(lock.c_str());
+        return false;
+    }
+    // (the worker detaches at once -- it forks and its first process exits: nothing of ours stays
+    // a zombie, and the host application's own child handling never sees it)
+    int wst = 0;
+    while (waitpid(pid, &wst, 0) < 0 && errno == EINTR) {
+    }
+    g_spec_counters.spawned++;
+    return true;
+}
+
+// The non-blocking form of rtc_kernel: the kernel when it is loaded already or its code object
+// lies in the on-disk cache (loaded now, ~1 ms); otherwise nullptr -- the first such call hands
+// the compilation to the worker, later ones look for its result at most every 2 ms.
+// *failed: the compilation cannot or did not succeed (never ask again).
+static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* header, bool fma_c_vgpr,
+                            const std::vector<std::string>& names, const std::string& want, bool* failed) {
+    *failed = false;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    std::lock_guard<std::mutex> lk(R->mu);
+    auto it = R->fns.find(std::to_string(dev) + "|" + want);
+    if (it != R->fns.end()) return it->second;
+    const auto now = std::chrono::steady_clock::now();
+    auto jt = R->jobs.find(want);
+    if (jt != R->jobs.end()) {
+        RtcAsyncJob& job = jt->second;
+        if (job.state == RtcAsyncJob::kFailed) {
+            *failed = true;
+            return nullptr;
+        }
+        if (now - job.t_poll < std::chrono::milliseconds(job.state == RtcAsyncJob::kDeferred ? 50 : 2)) return nullptr;
+        job.t_poll = now;
+        if (job.state == RtcAsyncJob::kDeferred) {  // the workers were busy: look again, start it if there is room
+            RtcJob J;
+            rtc_prepare(head, header, fma_c_vgpr, names, true, &J);
+            if (file_exists(J.cpath) || file_exists(J.cpath + ".err") || file_exists(J.cpath + ".lock")) {
+                job.state = RtcAsyncJob::kPending;  // (somebody else took it meanwhile)
+            } else if (workers_in_flight(J.cdir) < max_workers()) {
+                job.t_spawn = now;
+                if (spawn_worker(J, names, &job.why)) {
+                    job.state = RtcAsyncJob::kPending;
+                } else {
+                    job.state = RtcAsyncJob::kFailed;
+                    g_spec_counters.failed++;
+                    *failed = true;
+                }
+            }
+            return nullptr;
+        }
+        std::vector<char> code;
+        std::vector<std::string> lowered;
+        if (file_exists(job.cpath) && cache_load(job.cpath, names.size(), &code, &lowered)) {
+            void* fn = rtc_load(R, dev, code, names, lowered, want);
+            if (fn) {
+                g_spec_counters.loaded++;
+                return fn;  // (the job entry stays: other devices load from the cache the same way)
+            }
+            job.state = RtcAsyncJob::kFailed;
+            job.why = get_error();
+        } else if (file_exists(job.cpath + ".err")) {
+            job.state = RtcAsyncJob::kFailed;
+            job.why = read_small_file(job.cpath + ".err");
+        } else if (now - job.t_spawn > std::chrono::seconds(900)) {
+            job.state = RtcAsyncJob::kFailed;
+            job.why = "the compilation worker did not deliver within 900 s";
+        }
+        if (job.state == RtcAsyncJob::kFailed) {
+            g_spec_counters.failed++;
+            *failed = true;
+        }
+        return nullptr;
+    }
+    // first request
+    RtcJob J;
+    rtc_prepare(head, header, fma_c_vgpr, names, true, &J);
+    RtcAsyncJob job;
+    job.cpath = J.cpath;
+    job.t_spawn = job.t_poll = now;
+    if (J.cpath.empty()) {
+        job.state = RtcAsyncJob::kFailed;
+        job.why = "no code-object cache directory";
+    } else {
+        std::vector<char> code;
+        std::vector<std::string> lowered;
+        if (cache_load(J.cpath, names.size(), &code, &lowered)) {
+            if (void* fn = rtc_load(R, dev, code, names, lowered, want)) {
+                g_spec_counters.cache_hits++;
+                return fn;
+            }
+            job.state = RtcAsyncJob::kFailed;
+            job.why = get_error();
+        } else if (file_exists(J.cpath + ".err")) {
+            job.state = RtcAsyncJob::kFailed;
+            job.why = read_small_file(J.cpath + ".err");
+        } else if (!file_exists(J.cpath + ".lock") && workers_in_flight(J.cdir) >= max_workers()) {
+            job.state = RtcAsyncJob::kDeferred;
+        } else if (!spawn_worker(J, names, &job.why)) {
+            job.state = RtcAsyncJob::kFailed;
+        }
+    }
+    if (job.state == RtcAsyncJob::kFailed) {
+        g_spec_counters.failed++;
+        *failed = true;
+    }
+    R->jobs.emplace(want, job);
+    return nullptr;
 }
 
 static constexpr int kPriorClassesRt = 4;  // kPriorClasses of ais_kernels.hpp (static_assert there)
@@ -450,8 +750,14 @@ static constexpr int kPriorClassesRt = 4;  // kPriorClasses of ais_kernels.hpp (
 // (a built-in DeviceCost id, or KABC_COST_USER when `head` carries a user cost), pk_mask the
 // posterior kinds the AIS kernel may be asked for
 static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int cost, int pk_mask,
-                                      int family, int D, int variant) {
+                                      int family, int D, int variant, bool* try_failed = nullptr) {
     PluginKernel k;
+    // try_failed != nullptr: the non-blocking form (rtc_kernel_try)
+    auto rtc_kernel = [try_failed](RtcCache* R_, const std::string& head_, const char* header, bool fma,
+                                   const std::vector<std::string>& names, const std::string& want) -> void* {
+        if (try_failed) return rtc_kernel_try(R_, head_, header, fma, names, want, try_failed);
+        return kabc::rtc_kernel(R_, head_, header, fma, names, want);
+    };
     const std::string d = std::to_string(D), u = std::to_string(cost);
     const std::string ais_init = "kabc::ais_init_kernel<" + d + ">";
     auto smc_names = [&](int simple) {
@@ -545,13 +851,20 @@ struct ModelUnit : RtcCache {
     // a specialisation is found again by exactly its components, D and cost id
     int cost_id = 0;
     std::vector<kabc_prior_t> prior;
-    int handle = 0;      // kabc_compile_model registration (0: created by KABC_SPECIALIZE=1)
+    int handle = 0;      // kabc_compile_model registration (0: created by an entry point on its own)
     bool released = false;
+    // created by an entry point at first sight of the model (the default): its kernels are compiled
+    // by the worker process and taken when they are there (unit_kernel never waits for them)
+    bool async = false;
+    // the unit the model's kernels MUST come from while / when this one cannot serve (a prior with
+    // user families has no prebuilt kernels: their generic unit); nullptr: the prebuilt kernels
+    ModelUnit* fallback = nullptr;
 };
 static std::map<std::string, ModelUnit*> g_units;  // generic units by key (g_mu)
 static std::vector<ModelUnit*> g_specs;            // specialised units (g_mu)
 
 bool unit_is_spec(const ModelUnit* u) { return u && u->spec; }
+bool unit_required(const ModelUnit* u) { return u && (!u->spec || u->fallback != nullptr); }
 
 static std::vector<int> user_kinds_of(const kabc_prior_t* prior, int D) {
     std::vector<int> ks;
@@ -613,6 +926,9 @@ static kabc_status_t unit_head(const kabc_prior_t* prior, int D, int cost_id, bo
     return KABC_OK;
 }
 
+// KABC_SPECIALIZE: unset -- every entry point specialises on its own WITHOUT waiting (worker
+// process, see rtc_kernel_try); 1 -- the same, compiling at first sight (blocking: tests, warm-up
+// scripts); 0 -- never (registered kabc_compile_model units are ignored too)
 static bool specialize_env() {
     const char* e = std::getenv("KABC_SPECIALIZE");
     return e && *e && *e != '0';
@@ -622,52 +938,36 @@ static bool specialize_off() {
     return e && *e == '0';
 }
 
-static kabc_status_t make_spec_unit(const kabc_prior_t* prior, int D, int cost_id, int handle, ModelUnit** out) {
+static kabc_status_t make_spec_unit(const kabc_prior_t* prior, int D, int cost_id, int handle, bool async,
+                                    ModelUnit** out) {
     ModelUnit* u = new ModelUnit();
     if (kabc_status_t st = unit_head(prior, D, cost_id, true, &u->head, &u->cost_tmpl, &u->pk_mask)) {
         delete u;
         return st;
     }
+    if (std::getenv("KABC_SPEC_INJECT_ERROR"))  // (tests: a specialisation whose compilation fails)
+        u->head += "#error \"KABC_SPEC_INJECT_ERROR\"\n";
     u->spec = true;
+    u->async = async;
     u->cost_id = cost_id;
     u->prior.assign(prior, prior + D);
     u->handle = handle;
     std::lock_guard<std::mutex> lk(g_mu);
+    // (two threads at the first sight of one model: one unit)
+    for (ModelUnit* v : g_specs)
+        if (!v->released && v->cost_id == cost_id && same_prior(v->prior, prior, D)) {
+            delete u;
+            *out = v;
+            return KABC_OK;
+        }
     g_specs.push_back(u);
     *out = u;
     return KABC_OK;
 }
 
-kabc_status_t model_unit_for(const kabc_prior_t* prior, int D, int cost_id, ModelUnit** out, bool allow_spec) {
-    *out = nullptr;
-    if (!prior || D < 1) return KABC_OK;
-    const std::vector<int> uk = user_kinds_of(prior, D);
-    for (int k : uk)
-        if (!find_prior_plugin(k)) {
-            set_error("prior kind %d is not a registered user family (kabc_compile_prior_plugin)", k);
-            return KABC_ERR_INVALID_ARG;
-        }
-    if (!uk.empty() && D > KABC_MAX_DIM) {
-        set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
-        return KABC_ERR_UNSUPPORTED;
-    }
-    // 1. a specialisation of exactly this model
-    if (allow_spec && !specialize_off() && spec_eligible(prior, D)) {
-        {
-            std::lock_guard<std::mutex> lk(g_mu);
-            for (ModelUnit* u : g_specs)
-                if (!u->released && u->cost_id == cost_id && same_prior(u->prior, prior, D)) {
-                    *out = u;
-                    return KABC_OK;
-                }
-        }
-        if (specialize_env() && hiprtc()) {
-            if (make_spec_unit(prior, D, cost_id, 0, out) == KABC_OK) return KABC_OK;
-            if (uk.empty()) return KABC_OK;  // (the prebuilt kernels serve)
-        }
-    }
-    if (uk.empty()) return KABC_OK;
-    // 2. the generic unit of these user families and this cost
+// the generic unit of the user families among `prior` (there are no prebuilt kernels for them)
+static kabc_status_t generic_unit_for(const kabc_prior_t* prior, int D, int cost_id, const std::vector<int>& uk,
+                                      ModelUnit** out) {
     std::string key = "c" + std::to_string(cost_id) + "|";
     for (int k : uk) key += std::to_string(k) + ",";
     {
@@ -695,9 +995,74 @@ kabc_status_t model_unit_for(const kabc_prior_t* prior, int D, int cost_id, Mode
     return KABC_OK;
 }
 
-PluginKernel unit_kernel(ModelUnit* u, int family, int D, int variant) {
+kabc_status_t model_unit_for(const kabc_prior_t* prior, int D, int cost_id, ModelUnit** out, bool allow_spec) {
+    *out = nullptr;
+    if (!prior || D < 1) return KABC_OK;
+    const std::vector<int> uk = user_kinds_of(prior, D);
+    for (int k : uk)
+        if (!find_prior_plugin(k)) {
+            set_error("prior kind %d is not a registered user family (kabc_compile_prior_plugin)", k);
+            return KABC_ERR_INVALID_ARG;
+        }
+    if (!uk.empty() && D > KABC_MAX_DIM) {
+        set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    // 1. the unit the kernels must come from when no specialisation serves
+    ModelUnit* generic = nullptr;
+    if (!uk.empty())
+        if (kabc_status_t st = generic_unit_for(prior, D, cost_id, uk, &generic)) return st;
+    *out = generic;
+    // 2. a specialisation of exactly this model: registered (kabc_compile_model), or made here
+    if (allow_spec && !specialize_off() && spec_eligible(prior, D)) {
+        ModelUnit* spec = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            for (ModelUnit* u : g_specs)
+                if (!u->released && u->cost_id == cost_id && same_prior(u->prior, prior, D)) spec = u;
+        }
+        if (!spec && hiprtc()) {
+            // (a user cost built by hipcc has no text to specialise: unit_head refuses, the other kernels serve)
+            const bool sync = specialize_env();
+            if (sync || async_compile_available()) {
+                const std::string keep = get_error();
+                if (make_spec_unit(prior, D, cost_id, 0, !sync, &spec) != KABC_OK) {
+                    spec = nullptr;
+                    set_error("%s", keep.c_str());
+                }
+            }
+        }
+        if (spec) {
+            spec->fallback = generic;  // (the same generic unit every time: its key is (cost, kinds))
+            *out = spec;
+        }
+    }
+    return KABC_OK;
+}
+
+static bool is_init_family(int family) {
+    return family == kPfAisInit || family == kPfSmcInit || family == kPfAbcdeInit;
+}
+
+PluginKernel unit_kernel(ModelUnit* u, int family, int D, int variant, int* spec_state) {
+    if (spec_state) *spec_state = KABC_SPEC_NONE;
     if (!u || D < 1 || D > KABC_MAX_DIM) return PluginKernel();
-    return rtc_family_kernel(u, u->head, u->cost_tmpl, u->pk_mask, family, D, variant);
+    if (!u->spec) return rtc_family_kernel(u, u->head, u->cost_tmpl, u->pk_mask, family, D, variant);
+    PluginKernel k;
+    if (!u->async) {
+        k = rtc_family_kernel(u, u->head, u->cost_tmpl, u->pk_mask, family, D, variant);
+        if (spec_state) *spec_state = k.mod ? KABC_SPEC_ACTIVE : KABC_SPEC_FAILED;
+    } else if (!is_init_family(family)) {
+        // (the one-off init kernels are not worth a compilation: they stay generic / prebuilt)
+        bool failed = false;
+        const std::string keep = get_error();
+        k = rtc_family_kernel(u, u->head, u->cost_tmpl, u->pk_mask, family, D, variant, &failed);
+        if (!k.mod) set_error("%s", keep.c_str());  // (a pending or failed background job is not the caller's error)
+        if (spec_state) *spec_state = k.mod ? KABC_SPEC_ACTIVE : failed ? KABC_SPEC_FAILED : KABC_SPEC_PENDING;
+    }
+    if (k.mod || !u->fallback) return k;
+    return rtc_family_kernel(u->fallback, u->fallback->head, u->fallback->cost_tmpl, u->fallback->pk_mask, family,
+                             D, variant);
 }
 
 bool cost_dim_ok_rt(int cost_id, int D) {
@@ -863,6 +1228,29 @@ extern "C" kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t disc
     return KABC_OK;
 }
 
+// the kernel families (and their variants) a model's entry points will ask its specialised unit for
+struct SpecReq { int family, variant; };
+static std::vector<SpecReq> spec_requests(const kabc_model_t* model, int families, int pk_mask) {
+    const int D = model->D;
+    if (families == 0) families = KABC_FAMILY_AIS | KABC_FAMILY_SMC;
+    bool simple = true;
+    for (int k = 0; k < D; ++k) simple = simple && prior_is_simple(model->prior[k].kind);
+    std::vector<SpecReq> reqs;
+    if (families & KABC_FAMILY_AIS) {
+        const int pk_lo = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 1;
+        const int pk_hi = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 3;
+        for (int pk = pk_lo; pk <= pk_hi; ++pk)
+            if ((pk_mask >> (pk - 1)) & 1) reqs.push_back({kPfAis, 2 + kPriorClassesRt * (pk - 1)});
+    }
+    if (families & KABC_FAMILY_SMC) reqs.push_back({kPfSmcLoop, simple ? 1 : 0});
+    if (families & KABC_FAMILY_ABCDE) reqs.push_back({kPfAbcdeGen, 0});
+    if (families & KABC_FAMILY_PFILTER) {
+        reqs.push_back({kPfAbcdeInit, 0});
+        reqs.push_back({kPfAttempt, 0});
+    }
+    return reqs;
+}
+
 extern "C" kabc_status_t kabc_compile_model(const kabc_model_t* model, int32_t families, int32_t* out_handle) {
     if (!model || !model->prior) {
         set_error("kabc_compile_model: NULL argument");
@@ -897,30 +1285,24 @@ extern "C" kabc_status_t kabc_compile_model(const kabc_model_t* model, int32_t f
             std::lock_guard<std::mutex> lk(g_mu);
             h = ++next_handle;
         }
-        if (kabc_status_t st = make_spec_unit(model->prior, D, model->cost.id, h, &u)) return st;
+        if (kabc_status_t st = make_spec_unit(model->prior, D, model->cost.id, h, false, &u)) return st;
+    }
+    {
+        // (a unit an entry point made on its own: from now on it is this registration's, and its
+        // kernels are compiled here and now)
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (u->handle == 0) {
+            static int next_auto = 1 << 20;
+            u->handle = ++next_auto;
+        }
+        u->async = false;
     }
     if (out_handle) *out_handle = u->handle;
     // compile (and, with a device, load) the requested families now
-    if (families == 0) families = KABC_FAMILY_AIS | KABC_FAMILY_SMC;
     int dev = -1;
     const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0;
-    bool simple = true;
-    for (int k = 0; k < D; ++k) simple = simple && prior_is_simple(model->prior[k].kind);
-    struct Req { int family, variant; };
-    std::vector<Req> reqs;
-    if (families & KABC_FAMILY_AIS) {
-        const int pk_lo = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 1;
-        const int pk_hi = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 3;
-        for (int pk = pk_lo; pk <= pk_hi; ++pk)
-            if ((u->pk_mask >> (pk - 1)) & 1) reqs.push_back({kPfAis, 2 + kPriorClassesRt * (pk - 1)});
-    }
-    if (families & KABC_FAMILY_SMC) reqs.push_back({kPfSmcLoop, simple ? 1 : 0});
-    if (families & KABC_FAMILY_ABCDE) reqs.push_back({kPfAbcdeGen, 0});
-    if (families & KABC_FAMILY_PFILTER) {
-        reqs.push_back({kPfAbcdeInit, 0});
-        reqs.push_back({kPfAttempt, 0});
-    }
-    for (const Req& r : reqs) {
+    const std::vector<SpecReq> reqs = spec_requests(model, families, u->pk_mask);
+    for (const SpecReq& r : reqs) {
         set_error("%s", "");
         const PluginKernel k = unit_kernel(u, r.family, D, r.variant);
         if (k.mod) continue;
@@ -933,6 +1315,19 @@ extern "C" kabc_status_t kabc_compile_model(const kabc_model_t* model, int32_t f
     return KABC_OK;
 }
 
+extern "C" kabc_status_t kabc_prefetch_model(const kabc_model_t* model, int32_t families) {
+    if (!model || !model->prior) {
+        set_error("kabc_prefetch_model: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    ModelUnit* u = nullptr;
+    if (kabc_status_t st = model_unit_for(model->prior, model->D, model->cost.id, &u)) return st;
+    if (!u || !u->spec || !u->async) return KABC_OK;  // (nothing to do ahead: prebuilt, generic or compiled already)
+    for (const SpecReq& r : spec_requests(model, families, u->pk_mask))
+        if (!is_init_family(r.family)) (void)unit_kernel(u, r.family, model->D, r.variant);
+    return KABC_OK;
+}
+
 extern "C" kabc_status_t kabc_model_release(int32_t handle) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (ModelUnit* u : g_specs)
@@ -942,4 +1337,72 @@ extern "C" kabc_status_t kabc_model_release(int32_t handle) {
         }
     set_error("kabc_model_release: %d is not a registered model", handle);
     return KABC_ERR_INVALID_ARG;
+}
+
+extern "C" void kabc_spec_counters(uint64_t out[4]) {
+    if (!out) return;
+    out[0] = g_spec_counters.spawned.load();
+    out[1] = g_spec_counters.loaded.load();
+    out[2] = g_spec_counters.failed.load();
+    out[3] = g_spec_counters.cache_hits.load();
+}
+
+// The worker process's whole job (csrc/rtc_worker.c calls this after it has detached): read the
+// job file spawn_worker wrote, compile, store the code object under the cache path the parent
+// polls -- or <cache path>.err with the compiler's message.  No HIP call is made.
+extern "C" int32_t kabc_rtc_worker_main(const char* jobfile) {
+    if (!jobfile) return 2;
+    FILE* f = std::fopen(jobfile, "rb");
+    if (!f) return 2;
+    auto line = [f](std::string* out) {
+        out->clear();
+        int c;
+        while ((c = std::fgetc(f)) != EOF && c != '\n') out->push_back((char)c);
+        return c != EOF || !out->empty();
+    };
+    std::string magic, cpath, n;
+    std::vector<std::string> opt, names;
+    std::string text;
+    bool ok = line(&magic) && magic == "KABCJOB1" && line(&cpath) && line(&n);
+    for (long i = 0, m = ok ? std::atol(n.c_str()) : 0; i < m && ok; ++i) {
+        std::string o;
+        ok = line(&o);
+        opt.push_back(o);
+    }
+    ok = ok && line(&n);
+    for (long i = 0, m = ok ? std::atol(n.c_str()) : 0; i < m && ok; ++i) {
+        std::string o;
+        ok = line(&o);
+        names.push_back(o);
+    }
+    ok = ok && line(&n);
+    if (ok) {
+        text.resize((size_t)std::atoll(n.c_str()));
+        ok = text.empty() || std::fread(&text[0], 1, text.size(), f) == text.size();
+    }
+    std::fclose(f);
+    int rc = 0;
+    if (!ok) {
+        rc = 2;
+    } else {
+        std::vector<char> code;
+        std::vector<std::string> lowered;
+        const size_t sl = cpath.rfind('/');
+        const std::string cdir = sl == std::string::npos ? std::string(".") : cpath.substr(0, sl);
+        if (rtc_compile_text(text, opt, names, &code, &lowered) == KABC_OK && !code.empty()) {
+            cache_store(cdir, cpath, code, lowered);
+        } else {
+            rc = 1;
+            const std::string tmp = cpath + ".err.tmp";
+            if (FILE* e = std::fopen(tmp.c_str(), "wb")) {
+                const char* msg = get_error();
+                std::fwrite(msg, 1, std::strlen(msg), e);
+                std::fclose(e);
+                (void)std::rename(tmp.c_str(), (cpath + ".err").c_str());
+            }
+        }
+        (void)unlink((cpath + ".lock").c_str());
+    }
+    (void)unlink(jobfile);
+    return rc;
 }

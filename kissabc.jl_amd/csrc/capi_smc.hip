@@ -57,9 +57,11 @@ KABC_DECL_SMALL(10)
 KABC_DECL_SMALL(11)
 
 SmcSmallLaunch find_smc_small_kernel(int cost_id, int D, bool simple, ModelUnit* unit) {
-    if (unit) {
+    if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
         const PluginKernel k = unit_kernel(unit, kPfSmcSmall, D, simple ? 1 : 0);
-        return k.mod ? SmcSmallLaunch(k.mod, &smc_small_geom, (unsigned)kSmallBlock) : SmcSmallLaunch();
+        if (k.mod) return SmcSmallLaunch(k.mod, &smc_small_geom, (unsigned)kSmallBlock);
+        if (unit_required(unit)) return SmcSmallLaunch();
+        // (a specialisation that is not there (yet): the kernels below, same bits)
     }
     switch (cost_id) {
         case 1: return find_smc_small_kernel_cost_1(D, simple);
@@ -84,7 +86,8 @@ SmcSmallLaunch find_smc_small_kernel(int cost_id, int D, bool simple, ModelUnit*
 SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple, ModelUnit* unit) {
     if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
         const PluginKernel k = unit_kernel(unit, kPfSmcLoop, D, simple ? 1 : 0);
-        return k.mod ? SmcLoopLaunch(k.mod) : SmcLoopLaunch();
+        if (k.mod) return SmcLoopLaunch(k.mod);
+        if (unit_required(unit)) return SmcLoopLaunch();
     }
     switch (cost_id) {
         case 1: return find_smc_loop_kernel_cost_1(D, simple);
@@ -110,7 +113,8 @@ SmcLoopLaunch find_smc_loop_kernel(int cost_id, int D, bool simple, ModelUnit* u
 SmcLaunch find_smc_kernel(int cost_id, int D, bool simple, ModelUnit* unit) {
     if (unit) {
         const PluginKernel k = unit_kernel(unit, kPfSmc, D, simple ? 1 : 0);
-        return k.mod ? SmcLaunch(k.mod, &smc_mcmc_geom, (unsigned)kSmcBlock) : SmcLaunch();
+        if (k.mod) return SmcLaunch(k.mod, &smc_mcmc_geom, (unsigned)kSmcBlock);
+        if (unit_required(unit)) return SmcLaunch();
     }
     switch (cost_id) {
         case 1: return find_smc_kernel_cost_1(D, simple);
@@ -373,12 +377,11 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                 return KABC_ERR_UNSUPPORTED;
             }
     }
-    SmcLaunch mcmc = dyn ? SmcLaunch() : find_smc_kernel(cost->id, D, simple, unit);
-    if (!mcmc && unit) {
-        if (!unit_is_spec(unit)) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
-        unit = nullptr;                                    // a specialisation that cannot be built
-        mcmc = find_smc_kernel(cost->id, D, simple);
-    }
+    // (a specialisation an entry point made on its own is asked for the kernels of the driver that
+    // actually runs, below; here: does a propose / accept kernel exist at all)
+    SmcLaunch mcmc = dyn ? SmcLaunch() : find_smc_kernel(cost->id, D, simple, unit_required(unit) ? unit : nullptr);
+    bool mcmc_final = !unit || unit_required(unit);
+    if (!mcmc && unit_required(unit)) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
     SmcDynLaunchFn dyn_fn = nullptr;
     if (dyn) {
         if (cost->id >= KABC_COST_USER) {
@@ -543,10 +546,11 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
             KABC_HIP_CHECK(hipStreamSynchronize(s));  // (c0 is on this stack frame)
         }
         std::memcpy(a.raw, prior, sizeof(kabc_prior_t) * D);
-        if (unit) {
-            const PluginKernel k = unit_kernel(unit, kPfSmcInit, D, simple ? 1 : 0);
-            if (!k.mod) return KABC_ERR_DEVICE;
-            SmcInitLaunch(k.mod, &smc_init_geom, (unsigned)kSmcBlock)(a, s);
+        const PluginKernel uk = unit ? unit_kernel(unit, kPfSmcInit, D, simple ? 1 : 0) : PluginKernel();
+        if (uk.mod) {
+            SmcInitLaunch(uk.mod, &smc_init_geom, (unsigned)kSmcBlock)(a, s);
+        } else if (unit_required(unit)) {
+            return KABC_ERR_DEVICE;
         } else if (const CostPlugin* pl = find_plugin(cost->id)) {
             using Fn = void (*)(const SmcInitArgs&, hipStream_t);
             const PluginKernel k = plugin_kernel(pl, kPfSmcInit, D, simple ? 1 : 0);
@@ -640,6 +644,10 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         ma.aux_ring = aux_ring;
     }
     auto run_pass = [&](hipStream_t st) {  // one propose / accept pass (+ its pre-pass)
+        if (!mcmc_final) {  // the kernel-per-phase driver runs: the model's own kernel if it is there
+            if (SmcLaunch m2 = find_smc_kernel(cost->id, D, simple, unit)) mcmc = m2;
+            mcmc_final = true;
+        }
         if (auxW && aux_ring == 1) launch_aux_prepass(cost->id, xa, st, 1);
         mcmc(ma, st);
     };
@@ -1062,32 +1070,33 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
     if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
         const PluginKernel ki = unit_kernel(unit, kPfAbcdeInit, D, 0), ka = unit_kernel(unit, kPfAttempt, D, 0);
-        if (ki.mod && ka.mod) {
-            f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
-            f_att = PfLaunch(ka.mod, &pf_geom, (unsigned)kPfBlock);
-        } else if (!unit_is_spec(unit)) {
-            return KABC_ERR_DEVICE;
-        } else {
-            unit = nullptr;
-        }
+        if (ki.mod) f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
+        if (ka.mod) f_att = PfLaunch(ka.mod, &pf_geom, (unsigned)kPfBlock);
+        if ((!f_init || !f_att) && unit_required(unit)) return KABC_ERR_DEVICE;
+        // (a specialisation that is not there (yet): what is missing comes from below, same bits)
     }
-    if (unit) {
-    } else if (dyn) {
-        f_init = AbcdeLaunch(&pf_l_init<0>);
-        f_att = PfLaunch(&pf_l_attempt<0>);
-    } else if (const CostPlugin* p = find_plugin(cost->id)) {
-        const PluginKernel ki = plugin_kernel(p, kPfAbcdeInit, D, 0), ka = plugin_kernel(p, kPfAttempt, D, 0);
-        f_init = ki.host ? AbcdeLaunch((AbcdeLaunchFn)ki.host)
-                         : ki.mod ? AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
-        f_att = ka.host ? PfLaunch((PfLaunchFn)ka.host)
-                        : ka.mod ? PfLaunch(ka.mod, &pf_geom, (unsigned)kPfBlock) : PfLaunch();
-        if (!f_init || !f_att) {
-            set_error("cost plugin has no pfilter kernels for D = %d", D);
-            return KABC_ERR_UNSUPPORTED;
+    if (!f_init || !f_att) {
+        AbcdeLaunch b_init;
+        PfLaunch b_att;
+        if (dyn) {
+            b_init = AbcdeLaunch(&pf_l_init<0>);
+            b_att = PfLaunch(&pf_l_attempt<0>);
+        } else if (const CostPlugin* p = find_plugin(cost->id)) {
+            const PluginKernel ki = plugin_kernel(p, kPfAbcdeInit, D, 0), ka = plugin_kernel(p, kPfAttempt, D, 0);
+            b_init = ki.host ? AbcdeLaunch((AbcdeLaunchFn)ki.host)
+                             : ki.mod ? AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock) : AbcdeLaunch();
+            b_att = ka.host ? PfLaunch((PfLaunchFn)ka.host)
+                            : ka.mod ? PfLaunch(ka.mod, &pf_geom, (unsigned)kPfBlock) : PfLaunch();
+            if (!b_init || !b_att) {
+                set_error("cost plugin has no pfilter kernels for D = %d", D);
+                return KABC_ERR_UNSUPPORTED;
+            }
+        } else {
+            b_init = pf_pick_init(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+            b_att = pf_pick_attempt(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
         }
-    } else {
-        f_init = pf_pick_init(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
-        f_att = pf_pick_attempt(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+        if (!f_init) f_init = b_init;
+        if (!f_att) f_att = b_att;
     }
     const int64_t N = kabc_pfilter_nparticles(o->nparticles, o->q, D);
     KABC_HIP_CHECK(hipSetDevice(ctx->device));

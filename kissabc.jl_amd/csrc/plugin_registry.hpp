@@ -63,8 +63,16 @@ namespace kabc {
 kabc_status_t model_unit_for(const kabc_prior_t* prior, int D, int cost_id, ModelUnit** out,
                              bool allow_spec = true);
 bool unit_is_spec(const ModelUnit* u);
+// must the model's kernels come from run-time compiled code (user families among the components:
+// there are no prebuilt kernels)?  false: a miss of unit_kernel means "take the prebuilt kernel"
+bool unit_required(const ModelUnit* u);
 // AIS variant (pcx): a unit instantiates the GENERAL prior class only (user families are not
-// "simple"; a specialised unit routes that class to the model's own constants)
-PluginKernel unit_kernel(ModelUnit* u, int family, int D, int variant);
+// "simple"; a specialised unit routes that class to the model's own constants).
+// A specialised unit an entry point made on its own (the default, KABC_SPECIALIZE unset) NEVER
+// blocks here: its kernels are compiled by a worker process; until they are there the call
+// returns the kernel of the unit's fallback (the generic unit of the prior's user families) or
+// nothing (= the prebuilt kernel), and *spec_state says KABC_SPEC_PENDING -- ask again at the next
+// launch boundary.  Everything returned computes the same bits.
+PluginKernel unit_kernel(ModelUnit* u, int family, int D, int variant, int* spec_state = nullptr);
 
 }  // namespace kabc

@@ -283,9 +283,18 @@ def _gamma_p(a, x):
 class TruncatedGamma(UserPrior):
     """Truncated(Gamma(alpha, theta), lower, upper): the Gamma log-density minus the log-mass of
     [lower, upper] inside it, -Inf outside; p = (alpha, theta, lower, upper), the normaliser
-    lgamma(alpha) + alpha log(theta) + logtp is a literal of the snippet.  rand: rejection from the
-    parent Gamma over the component's window (Distributions.jl's generic truncated sampler does
-    the same for a window of this mass)."""
+    lgamma(alpha) + alpha log(theta) + logtp is a literal of the snippet.
+
+    rand is a rejection sampler over the component's window of the counter stream, with the
+    envelope chosen HERE, once, by acceptance rate (a literal of the snippet):
+      * the parent Gamma (Marsaglia-Tsang; for alpha < 1 with the boost U^(1/alpha) -- a FRESH U
+        per proposal, so that (U, G) are rejected jointly), accepted when inside [lower, upper]:
+        rate ~ 0.95 x the window's mass;
+      * a uniform on [lower, upper] against the density's maximum there: rate = mass / ((upper -
+        lower) max pdf) -- what serves the narrow windows of little mass.
+    A window neither envelope fills with probability 1 - 1e-12 within the slots is refused at
+    construction (Distributions.jl switches to quantile inversion there; the incomplete-gamma
+    inverse is not part of the arithmetic contract)."""
     TEMPLATE = """
 KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab) {
     if (!(x >= p[2] && x <= p[3]) || !(x >= 0.0)) return -KABC_INF;
@@ -293,35 +302,52 @@ KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* t
     return t1 - kabc_div_rc(x, p[1], %(rtheta)s) - %(norm)s;
 }
 KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
-    /* Marsaglia-Tsang proposals of the parent, two per pair of blocks, until one lands in
-     * [lower, upper]; beyond the window's slots: the nearer end of the interval to the mode */
     const double a0 = p[0];
-    double boost = 1.0, a = a0;
-    if (a < 1.0) {
-        boost = kabc_exp(kabc_log(kabc_u01(kabc_lo64(kabc_slot(w, KABC_SLOTS_PER_DIM - 1u)))) / a);
-        a += 1.0;
+#if %(uniform_envelope)d
+    /* uniform proposals on [lo, upper] against the (unnormalised) log-density's maximum there */
+    const double lo = %(lo)s, width = p[3] - lo;
+    for (uint32_t j = 0; j < KABC_SLOTS_PER_DIM; ++j) {
+        const kabc_u128_t b = kabc_slot(w, j);
+        const double x = lo + width * kabc_u01(kabc_lo64(b));
+        if (!(x >= lo && x <= p[3]) || !(x > 0.0)) continue;
+        const double lf = ((a0 == 1.0) ? 0.0 : (a0 - 1.0) * kabc_log(x)) - kabc_div_rc(x, p[1], %(rtheta)s);
+        if (kabc_log(kabc_u01(kabc_hi64(b))) < lf - %(logfmax)s) return x;
     }
+    return %(xmax)s;
+#else
+    /* Marsaglia-Tsang proposals of the parent, two per group of blocks (normals, accept uniforms,
+     * and for alpha < 1 the boost uniforms), until one lands in [lower, upper] */
+    const int small = a0 < 1.0;
+    const double a = small ? a0 + 1.0 : a0;
     const double d = a - 1.0 / 3.0, c = 1.0 / kabc_sqrt(9.0 * d);
-    for (uint32_t j = 0; j + 1u < KABC_SLOTS_PER_DIM - 1u; j += 2u) {
+    const uint32_t step = small ? 3u : 2u;
+    for (uint32_t j = 0; j + step <= KABC_SLOTS_PER_DIM; j += step) {
         const kabc_u128_t bn = kabc_slot(w, j), bu = kabc_slot(w, j + 1u);
         double z0, z1;
         kabc_normal_pair(kabc_lo64(bn), kabc_hi64(bn), &z0, &z1);
         const double us[2] = {kabc_u01(kabc_lo64(bu)), kabc_u01(kabc_hi64(bu))};
         const double zs[2] = {z0, z1};
+        double boost[2] = {1.0, 1.0};
+        if (small) {
+            const kabc_u128_t bb = kabc_slot(w, j + 2u);
+            boost[0] = kabc_exp(kabc_log(kabc_u01(kabc_lo64(bb))) / a0);
+            boost[1] = kabc_exp(kabc_log(kabc_u01(kabc_hi64(bb))) / a0);
+        }
         for (int i = 0; i < 2; ++i) {
             double v = 1.0 + c * zs[i];
             if (v <= 0.0) continue;
             v = v * v * v;
             if (kabc_log(us[i]) < 0.5 * zs[i] * zs[i] + d - d * v + d * kabc_log(v)) {
-                const double x = d * v * boost * p[1];
+                const double x = d * v * boost[i] * p[1];
                 if (x >= p[2] && x <= p[3]) return x;
             }
         }
     }
-    const double mode = (a0 > 1.0 ? (a0 - 1.0) : 0.0) * p[1];
-    return (kabc_fabs(p[2] - mode) < kabc_fabs(p[3] - mode)) ? p[2] : p[3];
+    return %(xmax)s;  /* (probability < 1e-12 by construction: the point of highest density) */
+#endif
 }
 """
+    SLOTS = 128   # KABC_SLOTS_PER_DIM (include/kabc_sampling_base.h)
 
     def __init__(self, alpha, theta, lower, upper):
         alpha, theta, lower, upper = map(float, (alpha, theta, lower, upper))
@@ -333,8 +359,29 @@ KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
             raise ValueError("Truncated(Gamma): the interval has no mass")
         self.alpha, self.theta, self.lower, self.upper = alpha, theta, lower, upper
         self.logtp = math.log(tp)
-        norm = math.lgamma(alpha) + alpha * math.log(theta) + self.logtp
-        super().__init__(self.TEMPLATE % {"rtheta": _hx(1.0 / theta), "norm": _hx(norm)},
+        lognorm0 = math.lgamma(alpha) + alpha * math.log(theta)
+        norm = lognorm0 + self.logtp
+        # the point of highest density inside the window, and log of the unnormalised density there
+        xmax = min(max((alpha - 1.0) * theta, lo), upper) if alpha >= 1.0 else lo
+        logf = lambda x: ((alpha - 1.0) * math.log(x) if alpha != 1.0 else 0.0) - x / theta   # noqa: E731
+        # acceptance rate per proposal and proposals per window of either envelope
+        rate_parent = 0.95 * tp
+        n_parent = 2 * (self.SLOTS // (3 if alpha < 1.0 else 2))
+        rate_unif, logfmax = 0.0, 0.0
+        if math.isfinite(upper) and xmax > 0.0:
+            logfmax = logf(xmax)
+            rate_unif = tp / ((upper - lo) * math.exp(logfmax - lognorm0))
+        fail_parent = (1.0 - min(rate_parent, 1.0)) ** n_parent
+        fail_unif = (1.0 - min(rate_unif, 1.0)) ** self.SLOTS if rate_unif > 0 else 1.0
+        self.envelope = "uniform" if fail_unif < fail_parent else "parent"
+        if min(fail_parent, fail_unif) > 1e-12:
+            raise ValueError(
+                f"Truncated(Gamma({alpha}, {theta}), {lower}, {upper}): the window holds {tp:.3g} of the mass and "
+                "neither rejection envelope of the device sampler fills it reliably (Distributions.jl "
+                "inverts the quantile there, which the arithmetic contract does not provide)")
+        super().__init__(self.TEMPLATE % {"rtheta": _hx(1.0 / theta), "norm": _hx(norm),
+                                          "uniform_envelope": int(self.envelope == "uniform"),
+                                          "lo": _hx(lo), "logfmax": _hx(logfmax), "xmax": _hx(xmax)},
                          (alpha, theta, lower, upper), name="TruncatedGamma")
 
     def __repr__(self):

@@ -261,10 +261,31 @@ KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
 }
 """
 lower(d::Laplace) = UserPrior(LAPLACE_SRC, (d.μ, d.θ, 1 / d.θ, log(2 * d.θ)))
-# Truncated(Gamma(α, θ), lo, hi): the normaliser lgamma(α) + α log θ + logtp is a literal of the snippet
+# Truncated(Gamma(α, θ), lo, hi): the normaliser lgamma(α) + α log θ + logtp is a literal of the snippet;
+# so is the rejection envelope of rand, chosen here by acceptance rate exactly as
+# kissabc.jl_amd/distributions.py (TruncatedGamma) chooses it: the parent Gamma (a fresh boost
+# uniform per proposal when α < 1) or a uniform on the window against the density's maximum there
 function lower(d::Truncated{<:Gamma})
     g = d.untruncated
-    norm = Distributions.loggamma(g.α) + g.α * log(g.θ) + d.logtp
+    lognorm0 = Distributions.loggamma(g.α) + g.α * log(g.θ)
+    norm = lognorm0 + d.logtp
+    lo = max(Float64(d.lower), 0.0)
+    hi = Float64(d.upper)
+    tp = exp(d.logtp)
+    xmax = g.α >= 1 ? min(max((g.α - 1) * g.θ, lo), hi) : lo
+    logf(x) = (g.α != 1 ? (g.α - 1) * log(x) : 0.0) - x / g.θ
+    slots = 128                                   # KABC_SLOTS_PER_DIM
+    n_parent = 2 * (slots ÷ (g.α < 1 ? 3 : 2))
+    rate_unif, logfmax = 0.0, 0.0
+    if isfinite(hi) && xmax > 0
+        logfmax = logf(xmax)
+        rate_unif = tp / ((hi - lo) * exp(logfmax - lognorm0))
+    end
+    fail_parent = (1 - min(0.95 * tp, 1.0))^n_parent
+    fail_unif = rate_unif > 0 ? (1 - min(rate_unif, 1.0))^slots : 1.0
+    uniform_envelope = fail_unif < fail_parent
+    min(fail_parent, fail_unif) > 1e-12 &&
+        error("Truncated(Gamma): neither rejection envelope of the device sampler fills this window reliably")
     src = """
 KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* tab) {
     if (!(x >= p[2] && x <= p[3]) || !(x >= 0.0)) return -KABC_INF;
@@ -272,33 +293,49 @@ KABC_HD double kabc_user_prior_logpdf(double x, const double* p, const double* t
     return t1 - kabc_div_rc(x, p[1], $(hexlit(1 / g.θ))) - $(hexlit(norm));
 }
 KABC_HD double kabc_user_prior_rand(const double* p, const kabc_slotwin_t* w) {
-    /* Marsaglia-Tsang proposals of the parent, two per pair of blocks, until one lands in
-     * [lower, upper]; beyond the window's slots: the nearer end of the interval to the mode */
     const double a0 = p[0];
-    double boost = 1.0, a = a0;
-    if (a < 1.0) {
-        boost = kabc_exp(kabc_log(kabc_u01(kabc_lo64(kabc_slot(w, KABC_SLOTS_PER_DIM - 1u)))) / a);
-        a += 1.0;
+#if $(Int(uniform_envelope))
+    /* uniform proposals on [lo, upper] against the (unnormalised) log-density's maximum there */
+    const double lo = $(hexlit(lo)), width = p[3] - lo;
+    for (uint32_t j = 0; j < KABC_SLOTS_PER_DIM; ++j) {
+        const kabc_u128_t b = kabc_slot(w, j);
+        const double x = lo + width * kabc_u01(kabc_lo64(b));
+        if (!(x >= lo && x <= p[3]) || !(x > 0.0)) continue;
+        const double lf = ((a0 == 1.0) ? 0.0 : (a0 - 1.0) * kabc_log(x)) - kabc_div_rc(x, p[1], $(hexlit(1 / g.θ)));
+        if (kabc_log(kabc_u01(kabc_hi64(b))) < lf - $(hexlit(logfmax))) return x;
     }
+    return $(hexlit(xmax));
+#else
+    /* Marsaglia-Tsang proposals of the parent, two per group of blocks (normals, accept uniforms,
+     * and for alpha < 1 the boost uniforms), until one lands in [lower, upper] */
+    const int small = a0 < 1.0;
+    const double a = small ? a0 + 1.0 : a0;
     const double d = a - 1.0 / 3.0, c = 1.0 / kabc_sqrt(9.0 * d);
-    for (uint32_t j = 0; j + 1u < KABC_SLOTS_PER_DIM - 1u; j += 2u) {
+    const uint32_t step = small ? 3u : 2u;
+    for (uint32_t j = 0; j + step <= KABC_SLOTS_PER_DIM; j += step) {
         const kabc_u128_t bn = kabc_slot(w, j), bu = kabc_slot(w, j + 1u);
         double z0, z1;
         kabc_normal_pair(kabc_lo64(bn), kabc_hi64(bn), &z0, &z1);
         const double us[2] = {kabc_u01(kabc_lo64(bu)), kabc_u01(kabc_hi64(bu))};
         const double zs[2] = {z0, z1};
+        double boost[2] = {1.0, 1.0};
+        if (small) {
+            const kabc_u128_t bb = kabc_slot(w, j + 2u);
+            boost[0] = kabc_exp(kabc_log(kabc_u01(kabc_lo64(bb))) / a0);
+            boost[1] = kabc_exp(kabc_log(kabc_u01(kabc_hi64(bb))) / a0);
+        }
         for (int i = 0; i < 2; ++i) {
             double v = 1.0 + c * zs[i];
             if (v <= 0.0) continue;
             v = v * v * v;
             if (kabc_log(us[i]) < 0.5 * zs[i] * zs[i] + d - d * v + d * kabc_log(v)) {
-                const double x = d * v * boost * p[1];
+                const double x = d * v * boost[i] * p[1];
                 if (x >= p[2] && x <= p[3]) return x;
             }
         }
     }
-    const double mode = (a0 > 1.0 ? (a0 - 1.0) : 0.0) * p[1];
-    return (kabc_fabs(p[2] - mode) < kabc_fabs(p[3] - mode)) ? p[2] : p[3];
+    return $(hexlit(xmax));  /* (probability < 1e-12 by construction: the point of highest density) */
+#endif
 }
 """
     UserPrior(src, (g.α, g.θ, Float64(d.lower), Float64(d.upper)))

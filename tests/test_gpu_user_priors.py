@@ -155,18 +155,22 @@ def _spec_models(k):
 
 @pytest.mark.parametrize("name", ["socks", "four_family_d4", "c4_prior_d16", "c2_normal_d2",
                                   "threshold_mixed_user"])
-def test_specialised_ais_kernels_bit_exact(k, orc, gpu_ctx, name):
+def test_specialised_ais_kernels_bit_exact(k, orc, gpu_ctx, monkeypatch, name):
     """the same model on the prebuilt kernels, on its specialised kernels and on the oracle"""
     model, N, nt = _spec_models(k)[name]
     has_user = any(c.kind >= 100 for c in model.prior.p)
+    monkeypatch.setenv("KABC_SPECIALIZE", "0")   # (the default would specialise on its own)
     base = None if has_user else k.AisEnsemble(model, N, seed=3).init().advance(3, nt, collect=True)
+    monkeypatch.delenv("KABC_SPECIALIZE")
     h = k.compile_model(model, families=1)
     assert h > 0
     try:
         ens = _ais_check(k, orc, model, N, nt=nt, gens=2, seed=3)
         ens.close()
         if base is not None:
-            assert np.array_equal(k.AisEnsemble(model, N, seed=3).init().advance(3, nt, collect=True), base)
+            e2 = k.AisEnsemble(model, N, seed=3).init()
+            assert e2.spec_state() == ("active", 0)
+            assert np.array_equal(e2.advance(3, nt, collect=True), base)
     finally:
         k._lib.check(k._lib.load().kabc_model_release(h))
 
@@ -181,7 +185,9 @@ def test_specialised_smc_kernels_bit_exact(k, orc, gpu_ctx, monkeypatch, path):
     socks = k.Factored(k.NegativeBinomial(900 / 195, (900 / 195) / (30 + 900 / 195)), k.Beta(15, 2))
     for prior, cost, kw in [(H16, k.costs.HierGaussSim(ybar), dict(nparticles=4096, alpha=0.95, epstol=0.05)),
                             (socks, k.costs.GaussDist([40.0, 0.8]), dict(nparticles=1000, alpha=0.9, epstol=0.5))]:
+        monkeypatch.setenv("KABC_SPECIALIZE", "0")
         base = k.smc(prior, cost, seed=5, return_array=True, **kw)
+        monkeypatch.delenv("KABC_SPECIALIZE")
         h = k.compile_model(prior, cost, families=2)
         assert h > 0
         try:

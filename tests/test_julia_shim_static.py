@@ -370,5 +370,9 @@ def test_shim_snippets_are_the_python_ones(k):
     m = re.search(r'const LAPLACE_SRC = """\n(.*?)"""', text, re.S)
     assert m and m.group(1).strip() == k.Laplace.SOURCE.strip()
     m = re.search(r'function lower\(d::Truncated\{<:Gamma\}\).*?src = """\n(.*?)"""', text, re.S)
-    jl = m.group(1).replace("$(hexlit(1 / g.θ))", "%(rtheta)s").replace("$(hexlit(norm))", "%(norm)s")
+    jl = m.group(1)
+    for a, b in (("$(hexlit(1 / g.θ))", "%(rtheta)s"), ("$(hexlit(norm))", "%(norm)s"),
+                 ("$(Int(uniform_envelope))", "%(uniform_envelope)d"), ("$(hexlit(lo))", "%(lo)s"),
+                 ("$(hexlit(logfmax))", "%(logfmax)s"), ("$(hexlit(xmax))", "%(xmax)s")):
+        jl = jl.replace(a, b)
     assert jl.strip() == k.TruncatedGamma.TEMPLATE.strip()

@@ -77,3 +77,26 @@ def test_specialised_model_compiles_without_a_gpu(k, tmp_path, monkeypatch):
     box = k.ApproxKernelizedPosterior(k.Factored(k.Uniform(0, 1), k.DiscreteUniform(1, 4)),
                                       k.costs.GaussDist([0.5, 2.0]), 1.0)
     assert k.compile_model(box) == 0
+
+
+def test_truncated_gamma_sampler_small_alpha_and_narrow_windows(orc, k):
+    """round-4 advisor finding: with alpha < 1 the Marsaglia-Tsang boost U^(1/alpha) must be drawn
+    afresh for every proposal (one U reused over the retries weights it by 1 / P(accept | U):
+    mean 0.951 against 0.872 for Truncated(Gamma(0.7, 2), 0, 3)); and a window of little mass must
+    not put a point mass on its boundary: narrow ones take the uniform envelope, the rest is refused."""
+    n = 200000
+    for a, th, lo, hi, env in ((0.7, 2.0, 0.0, 3.0, "parent"), (0.4, 1.0, 0.05, 2.5, "parent"),
+                               (2.0, 1.5, 7.0, 7.5, "uniform"), (0.6, 1.0, 2.0, 2.2, "uniform"),
+                               (3.0, 1.0, 0.1, 0.6, "uniform")):
+        d = k.Truncated(k.Gamma(a, th), lo, hi)
+        assert d.envelope == env
+        x = orc.factored_rand(d, n, seed=11)[:, 0]
+        g = stats.gamma(a, scale=th)
+        cdf = lambda v: (g.cdf(v) - g.cdf(lo)) / (g.cdf(hi) - g.cdf(lo))   # noqa: E731
+        assert x.min() >= lo and x.max() <= hi
+        assert stats.kstest(x, cdf).pvalue > 1e-3, (a, th, lo, hi)
+        exact = g.expect(lambda v: v, lb=lo, ub=hi, conditional=True)
+        assert abs(x.mean() - exact) < 5 * x.std() / np.sqrt(n), (a, th, lo, hi)
+        assert np.mean(x == lo) + np.mean(x == hi) == 0.0      # no point mass on the boundary
+    with pytest.raises(ValueError, match="neither rejection envelope"):
+        k.Truncated(k.Gamma(2.0, 1.0), 8.0, 40.0)              # mass 3e-3, wide: inversion territory
