@@ -243,7 +243,8 @@ kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32
  * receive the same prior components (bit for bit), D and cost id; model->posterior and ->eps do
  * not take part (the posterior kind is a template parameter of the AIS kernel, chosen at
  * kabc_ais_create).  Priors made of Uniform / DiscreteUniform components only are left to the
- * prebuilt kernels (their box test is already parameter-free); so are full-covariance
+ * prebuilt kernels (their box test is already parameter-free); so are priors of plain Normals
+ * up to seven parameters (the prebuilt class is the faster kernel there), full-covariance
  * MvNormal priors and length(prior) > KABC_MAX_DIM.  KABC_SPECIALIZE=1 in the environment makes
  * every entry point specialise on its own at first sight of a model.  Without hipRTC (or with
  * KABC_SPECIALIZE=0) the prebuilt kernels remain the path.  *out_handle (optional) identifies

@@ -195,10 +195,10 @@ __global__ void __launch_bounds__(1024) abcde_extrema_kernel(const AbcdeArgs A) 
         A.ctrl->cur = cur;
         A.ctrl->eps_l = mn;
         A.ctrl->eps_h = mx;
+        A.ctrl->iters += 1;  // iters += 1 (:373): counted before the earlystop break (:379-381), as the reference does
         if (A.earlystop && mx <= A.eps_target) {
             A.ctrl->done = 1;
         } else {
-            A.ctrl->iters += 1;  // iters += 1 (:373)
             const double pop = mn + A.alpha * (mx - mn);
             A.ctrl->eps_pop = (A.eps_target > pop) ? A.eps_target : pop;  // max(ϵ_target, ...)
         }

@@ -685,7 +685,13 @@ ais_half_kernel(const AisArgs A0) {
     slogtab[threadIdx.x + kAisBlock] = tab1;
     // NegativeBinomial components (GENERAL class, launches long enough to pay for it): slot j of
     // snb = lgamma(k + r_j); which components have a slot is recomputed below from the same scan
+#ifdef KABC_MODEL_SPEC
+    // (a unit generated for one model addresses the table slots as compile-time constants
+    // (kabc_device.hpp model_comp): its tables are always there)
+    [[maybe_unused]] const bool nb_on = kNbTabs > 0;
+#else
     [[maybe_unused]] const bool nb_on = kNbTabs > 0 && A.nt >= 8;
+#endif
     if constexpr (kNbTabs > 0) {
         static_assert(kNbEntries == kAisBlock, "one table entry per thread");
         int slot = 0;

@@ -202,6 +202,130 @@ __global__ void __launch_bounds__(256) wm_partition_kernel(const unsigned* sin, 
     sout[((v >> b) & 1u) ? (int64_t)*nz + ones : p - ones] = v;
 }
 
+// ---- the donor draw of medium ensembles (4096 .. 131 072 particles): TWO launches per generation
+// The rank structure above costs ~68 dependent launches per generation (an 8-pass radix sort of
+// 128-512 KB of keys, then a wavelet-matrix level per index bit): 242 us per generation at 16 384
+// particles, nearly all of it kernel boundaries.  The donor draw
+//     s = rand((1:N)[Δs .<= Δs[i]])          (src/smc.jl:392)
+// is "the m-th index, in ascending order, among the particles whose cost does not exceed mine, m
+// uniform below their count".  With the indices cut into BLOCKS of 256 consecutive particles and
+// every block's costs sorted (one workgroup each, a bitonic network in LDS -- no dependency
+// between workgroups), one WAVEFRONT answers a particle's draw: every lane bisects the sorted costs
+// of its share of the blocks (count of costs <= mine per block), a wavefront prefix over the block
+// counts gives the total and the block holding the m-th hit, and the 64 lanes scan that block's
+// 256 costs in index order with four ballots.  Same count, same m, same index as the scans and
+// the wavelet matrix.
+constexpr int kDbBlock = 256;                 // particles per sorted block
+constexpr int64_t kDbMaxN = 131072;           // beyond: the wavelet matrix (lanes would walk > 8 blocks each)
+constexpr int kDbMaxPerLane = (int)(kDbMaxN / kDbBlock / kWave);
+
+// sorted[b * 256 + r] = r-th smallest cost of particles [256 b, 256 b + 256) (+Inf past N)
+__global__ void __launch_bounds__(kDbBlock) abcde_blocksort_kernel(const AbcdeArgs A, double* sorted) {
+    __shared__ double s_v[kDbBlock];
+    if (A.ctrl->done) return;
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kDbBlock + tid;
+    s_v[tid] = i < A.N ? A.delta[A.ctrl->cur][i] : KABC_INF;
+    __syncthreads();
+    for (int k = 2; k <= kDbBlock; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int p = tid ^ j;
+            if (p > tid) {
+                const double a = s_v[tid], b = s_v[p];
+                const bool up = (tid & k) == 0;
+                if (up ? (b < a) : (a < b)) {
+                    s_v[tid] = b;
+                    s_v[p] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    sorted[i] = s_v[tid];  // (the array is padded to whole blocks)
+}
+
+// donor[i] for every particle that needs one: a wavefront per particle
+__global__ void __launch_bounds__(256) abcde_donor_blocks_kernel(const AbcdeArgs A, const double* sorted,
+                                                                 int32_t* donor) {
+    if (A.ctrl->done) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t i = (int64_t)blockIdx.x * (256 / kWave) + (threadIdx.x >> 6);
+    if (i >= A.N) return;  // (wave-uniform)
+    const int64_t N = A.N;
+    const double* __restrict__ DL = A.delta[A.ctrl->cur];
+    const double di = DL[i];
+    const bool skip = A.earlystop && di <= A.eps_target;                        // :384-386
+    const double eps = (di <= A.eps_target) ? A.eps_target : A.ctrl->eps_pop;   // :390
+    if (skip || !(di > eps)) {  // (wave-uniform: one particle per wavefront)
+        if (lane == 0) donor[i] = (int32_t)i;
+        return;
+    }
+    const int nblocks = (int)((N + kDbBlock - 1) / kDbBlock);
+    const int per = (nblocks + kWave - 1) / kWave;  // consecutive blocks per lane (<= kDbMaxPerLane)
+    // count of costs <= di in each of this lane's blocks: upper bound by bisection (8 steps of 256)
+    int cb[kDbMaxPerLane];
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < kDbMaxPerLane; ++q) {
+        cb[q] = 0;
+        const int b = lane * per + q;
+        if (q < per && b < nblocks) {
+            const double* __restrict__ sb = sorted + (size_t)b * kDbBlock;
+            int lo = 0, hi = kDbBlock;
+#pragma unroll
+            for (int step = 0; step < 8; ++step) {
+                const int mid = (lo + hi) >> 1;
+                if (sb[mid] <= di) lo = mid + 1;
+                else hi = mid;
+            }
+            cb[q] = lo;
+            c += lo;
+        }
+    }
+    int incl = c;
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int o = __shfl_up(incl, off, kWave);
+        if (lane >= off) incl += o;
+    }
+    const int total = __shfl(incl, kWave - 1, kWave);  // >= 1: the particle's own cost counts
+    const kabc_u128_t B0 = kabc_stream_block(A.seed, (uint32_t)i, (uint64_t)A.ctrl->iters, 0u, KABC_DOM_ABCDE_MOVE);
+    const int64_t m = (int64_t)kabc_index(kabc_lo64(B0), (uint64_t)total);
+    // the lane whose blocks hold the m-th hit names the block and the hit's rank inside it
+    const int excl = incl - c;
+    int tb = -1, tm = 0;
+    if (m >= excl && m < incl) {
+        int r = (int)m - excl;
+#pragma unroll
+        for (int q = 0; q < kDbMaxPerLane; ++q) {
+            if (tb < 0 && q < per) {
+                if (r < cb[q]) {
+                    tb = lane * per + q;
+                    tm = r;
+                }
+                r -= cb[q];
+            }
+        }
+    }
+    const unsigned long long owner = __ballot(tb >= 0);  // exactly one lane
+    const int src = __ffsll((long long)owner) - 1;
+    tb = __shfl(tb, src, kWave);
+    tm = __shfl(tm, src, kWave);
+    // the tm-th particle of block tb, in index order, whose cost does not exceed di
+    const unsigned long long below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int found = -1;
+#pragma unroll
+    for (int q = 0; q < kDbBlock / kWave; ++q) {
+        const int64_t j = (int64_t)tb * kDbBlock + q * kWave + lane;
+        const bool hit = j < N && DL[j] <= di;
+        const unsigned long long mk = __ballot(hit);
+        const int cnt = __popcll(mk);
+        if (found < 0 && tm >= 0 && tm < cnt && hit && __popcll(mk & below) == tm) found = (int)j;
+        tm -= cnt;  // (negative from the group after the hit on: no later group matches)
+    }
+    const unsigned long long fm = __ballot(found >= 0);
+    if (fm && lane == __ffsll((long long)fm) - 1) donor[i] = found;
+}
+
 struct RankStructure {
     double* sorted = nullptr;
     unsigned *seq[2] = {nullptr, nullptr}, *cnt = nullptr, *nz = nullptr;
@@ -411,7 +535,12 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     KABC_HIP_CHECK(hipGetLastError());
     // large ensembles: a rank structure per generation replaces the O(N) donor scans
     RankStructure R;
-    if (N >= kRankMinN) {
+    // (KABC_ABCDE_RANK=wavelet | blocks: force one of the two structures from kRankMinN particles on)
+    const char* rank_env = std::getenv("KABC_ABCDE_RANK");
+    const bool force_wm = rank_env && rank_env[0] == 'w';
+    const bool use_blocks = N >= kRankMinN && !force_wm && N <= kDbMaxN;
+    double* d_bsorted = nullptr;
+    if (N >= kRankMinN && !use_blocks) {
         R.levels = 1;
         while ((1ll << R.levels) < N) ++R.levels;
         R.words = (N + 64) / 64;  // one word past position N (rank queries at p = N)
@@ -439,15 +568,25 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     int32_t* d_donor = nullptr;
     {
         const char* e = std::getenv("KABC_ABCDE_DONOR");
-        if (!R.sorted && N >= kDonorMinN && N <= (int64_t)kAbcdeScanMax && !(e && e[0] == '0')) {
+        if (!R.sorted && !use_blocks && N >= kDonorMinN && N <= (int64_t)kAbcdeScanMax && !(e && e[0] == '0')) {
             KABC_HIP_CHECK(alloc((void**)&d_donor, sizeof(int32_t) * N));
             A.donor = d_donor;
         }
     }
+    const unsigned db_blocks = (unsigned)((N + kDbBlock - 1) / kDbBlock);
+    if (use_blocks) {
+        KABC_HIP_CHECK(alloc((void**)&d_donor, sizeof(int32_t) * N));
+        KABC_HIP_CHECK(alloc((void**)&d_bsorted, sizeof(double) * (size_t)db_blocks * kDbBlock));
+        A.donor = d_donor;
+    }
     for (int64_t g = 0; g < o->generations; ++g) {  // while iters < generations (:372)
         A.flip_first = g > 0 ? 1 : 0;  // (the flip after generation g - 1 rides on this launch)
         hipLaunchKernelGGL(abcde_extrema_kernel, dim3(1), dim3(1024), 0, s, A);
-        if (d_donor)
+        if (use_blocks) {
+            hipLaunchKernelGGL(abcde_blocksort_kernel, dim3(db_blocks), dim3(kDbBlock), 0, s, A, d_bsorted);
+            hipLaunchKernelGGL(abcde_donor_blocks_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, A,
+                               d_bsorted, d_donor);
+        } else if (d_donor)
             hipLaunchKernelGGL(abcde_donor_kernel,
                                dim3((unsigned)((N + kDonorBlock / kDonorTeam - 1) / (kDonorBlock / kDonorTeam))),
                                dim3(kDonorBlock), 0, s, A, d_donor);

@@ -152,6 +152,9 @@ struct RtcCache {
     std::map<std::string, void*> fns;  // "<device>|<name expression>" -> hipFunction_t
     std::vector<hipModule_t> mods;
     std::map<std::string, RtcAsyncJob> jobs;  // by the wanted name expression (process-wide, not per device)
+    // compiler options beyond the common ones for the AIS half-generation kernel of this unit
+    // (csrc/Makefile AIS_SCHED: the NORMAL prior class up to seven parameters is scheduled for ILP)
+    std::vector<std::string> ais_opt;
 };
 
 struct RtcPlugin : RtcCache {
@@ -386,12 +389,14 @@ struct RtcJob {
 };
 
 static void rtc_prepare(const std::string& head, const char* header, bool fma_c_vgpr,
-                        const std::vector<std::string>& names, bool want_cache, RtcJob* J) {
+                        const std::vector<std::string>& names, bool want_cache, RtcJob* J,
+                        const std::vector<std::string>* extra_opt = nullptr) {
     J->text = "// generated by libkabc_hip (capi_plugin.hip)\n" + head;
     if (fma_c_vgpr) J->text += "#define KABC_FMA_C_VGPR\n";
     if (header) J->text += std::string("#include \"") + header + "\"\n";
     // the flags of csrc/Makefile: the arithmetic contract needs -ffp-contract=off
     J->opt = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+    if (extra_opt) J->opt.insert(J->opt.end(), extra_opt->begin(), extra_opt->end());
     // the on-disk cache: keyed by everything that determines the code object
     J->cdir = want_cache ? rtc_cache_dir() : std::string();
     J->cpath.clear();
@@ -458,9 +463,9 @@ static kabc_status_t rtc_compile_text(const std::string& text, std::vector<std::
 // (the kernel templates) into one code object
 static kabc_status_t rtc_compile(const std::string& head, const char* header, bool fma_c_vgpr,
                                  const std::vector<std::string>& names, std::vector<char>* code,
-                                 std::vector<std::string>* lowered) {
+                                 std::vector<std::string>* lowered, const std::vector<std::string>* extra_opt = nullptr) {
     RtcJob J;
-    rtc_prepare(head, header, fma_c_vgpr, names, code != nullptr, &J);
+    rtc_prepare(head, header, fma_c_vgpr, names, code != nullptr, &J, extra_opt);
     if (!J.cpath.empty() && cache_load(J.cpath, names.size(), code, lowered)) return KABC_OK;
     if (kabc_status_t st = rtc_compile_text(J.text, J.opt, names, code, lowered)) return st;
     if (code && !J.cpath.empty()) cache_store(J.cdir, J.cpath, *code, *lowered);
@@ -503,7 +508,8 @@ static void* rtc_kernel(RtcCache* R, const std::string& head, const char* header
     if (it != R->fns.end()) return it->second;
     std::vector<char> code;
     std::vector<std::string> lowered;
-    if (rtc_compile(head, header, fma_c_vgpr, names, &code, &lowered) != KABC_OK) return nullptr;
+    const bool ais = header && std::strcmp(header, "ais_kernels.hpp") == 0 && !R->ais_opt.empty();
+    if (rtc_compile(head, header, fma_c_vgpr, names, &code, &lowered, ais ? &R->ais_opt : nullptr) != KABC_OK) return nullptr;
     return rtc_load(R, dev, code, names, lowered, want);
 }
 
@@ -658,6 +664,8 @@ static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* he
     std::lock_guard<std::mutex> lk(R->mu);
     auto it = R->fns.find(std::to_string(dev) + "|" + want);
     if (it != R->fns.end()) return it->second;
+    const std::vector<std::string>* ais_opt =
+        (header && std::strcmp(header, "ais_kernels.hpp") == 0 && !R->ais_opt.empty()) ? &R->ais_opt : nullptr;
     const auto now = std::chrono::steady_clock::now();
     auto jt = R->jobs.find(want);
     if (jt != R->jobs.end()) {
@@ -670,7 +678,7 @@ static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* he
         job.t_poll = now;
         if (job.state == RtcAsyncJob::kDeferred) {  // the workers were busy: look again, start it if there is room
             RtcJob J;
-            rtc_prepare(head, header, fma_c_vgpr, names, true, &J);
+            rtc_prepare(head, header, fma_c_vgpr, names, true, &J, ais_opt);
             if (file_exists(J.cpath) || file_exists(J.cpath + ".err") || file_exists(J.cpath + ".lock")) {
                 job.state = RtcAsyncJob::kPending;  // (somebody else took it meanwhile)
             } else if (workers_in_flight(J.cdir) < max_workers()) {
@@ -710,7 +718,7 @@ static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* he
     }
     // first request
     RtcJob J;
-    rtc_prepare(head, header, fma_c_vgpr, names, true, &J);
+    rtc_prepare(head, header, fma_c_vgpr, names, true, &J, ais_opt);
     RtcAsyncJob job;
     job.cpath = J.cpath;
     job.t_spawn = job.t_poll = now;
@@ -880,12 +888,19 @@ static std::vector<int> user_kinds_of(const kabc_prior_t* prior, int D) {
 // register-resident kernels
 static bool spec_eligible(const kabc_prior_t* prior, int D) {
     if (D < 1 || D > KABC_MAX_DIM) return false;
-    bool allbox = true;
+    bool allbox = true, allnormal = true;
     for (int k = 0; k < D; ++k) {
         const int kd = prior[k].kind;
         if (kd == KABC_PRIOR_MVNORMAL || kd == KABC_PRIOR_USER_INIT) return false;
         allbox = allbox && (kd == KABC_PRIOR_UNIFORM || kd == KABC_PRIOR_DISCRETE_UNIFORM);
+        allnormal = allnormal && kd == KABC_PRIOR_NORMAL;
     }
+    // plain Normals up to seven parameters: the prebuilt NORMAL class (no support tests, no
+    // rounding, scheduled for ILP: csrc/Makefile AIS_SCHED / AIS_SPLIT) is the faster kernel --
+    // C2 (4096 x 2): 51.6 us per launch against 54.8 for the model's own kernel with either
+    // scheduling strategy, 70.3 against 70.6 at 65 536 walkers (profiles/r05_c2_spec_ab.txt); from
+    // eight parameters on the model's own wins (0.72 -> 0.78 of the contract roofline)
+    if (allnormal && D <= 7) return false;
     return !allbox;
 }
 
@@ -947,6 +962,8 @@ static kabc_status_t make_spec_unit(const kabc_prior_t* prior, int D, int cost_i
     }
     if (std::getenv("KABC_SPEC_INJECT_ERROR"))  // (tests: a specialisation whose compilation fails)
         u->head += "#error \"KABC_SPEC_INJECT_ERROR\"\n";
+    if (const char* e = std::getenv("KABC_SPEC_SCHED"))  // (probe: the scheduling strategy of csrc/Makefile AIS_SCHED)
+        if (*e == '1') u->ais_opt = {"-mllvm", "-amdgpu-sched-strategy=max-ilp"};
     u->spec = true;
     u->async = async;
     u->cost_id = cost_id;

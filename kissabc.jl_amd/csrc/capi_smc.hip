@@ -11,6 +11,7 @@
 #include "plugin_registry.hpp"
 #include "smc_loop_kernel.hpp"
 #include "smc_small_kernel.hpp"
+#include "smc_select2_kernels.hpp"
 #include "smc_dyn_kernels.hpp"
 #include "abcde_kernels.hpp"
 #include "pfilter_kernels.hpp"
@@ -262,6 +263,47 @@ static hipError_t launch_select(const SmcSelectArgs& sa, unsigned G, hipStream_t
     SmcSelectArgs a = sa;
     void* args[] = {&a};
     return hipLaunchCooperativeKernel((void*)smc_select_kernel, dim3(G), dim3(kSelBlock), args, 0, s);
+}
+
+// set while a run is repeated with the one-kernel select after the barrier-free kernels gave up
+// (a candidate bin beyond their list: smc_select2_kernels.hpp)
+static thread_local bool tl_smc_no_sel2 = false;
+
+// From how many particles the selection runs as barrier-free kernels over all CUs
+// (smc_select2_kernels.hpp); below, the one-kernel select on at most 16 workgroups (co-resident
+// on any device that runs this library at all).  KABC_SMC_SELECT2_FROM overrides (0 = never).
+static int64_t select2_from() {
+    if (const char* e = std::getenv("KABC_SMC_SELECT2_FROM")) {
+        const long long v = std::atoll(e);
+        return v <= 0 ? INT64_MAX : (int64_t)v;
+    }
+    return (int64_t)1 << 17;
+}
+static bool use_select2(int64_t N, bool sharded) {
+    return !sharded && !tl_smc_no_sel2 && N >= select2_from() && N >= 2 * kSel2Block;
+}
+static unsigned select2_blocks(int64_t N) {
+    const int64_t ntile = (N + kSel2Block - 1) / kSel2Block;
+    int64_t g = ntile < 512 ? ntile : 512;  // two workgroups of 1024 per CU
+    if (const char* e = std::getenv("KABC_SMC_SELECT2_BLOCKS")) {
+        const long v = std::atol(e);
+        if (v >= 1) g = v < ntile ? v : ntile;
+    }
+    if (g > kSel2MaxG) g = kSel2MaxG;
+    return (unsigned)(g < 1 ? 1 : g);
+}
+// the phases of one selection, back to back on the stream (ordinary launches, no barrier inside)
+static hipError_t launch_select2(const SmcSelectArgs& sa, SmcSel2Scratch* g2, hipStream_t s) {
+    SmcSel2Args a;
+    a.s = sa;
+    a.g = g2;
+    const unsigned G = select2_blocks(sa.N);
+    if (!sa.part) hipLaunchKernelGGL(sel2_partials_kernel, dim3(G), dim3(kSel2Block), 0, s, a);
+    hipLaunchKernelGGL(sel2_stats_kernel, dim3(1), dim3(kSel2Block), 0, s, a, G);
+    hipLaunchKernelGGL(sel2_hist_kernel, dim3(G), dim3(kSel2Block), 0, s, a);
+    hipLaunchKernelGGL(sel2_collect_kernel, dim3(G), dim3(kSel2Block), 0, s, a);
+    hipLaunchKernelGGL(sel2_finish_kernel, dim3(G), dim3(kSel2Block), 0, s, a);
+    return hipGetLastError();
 }
 }  // namespace kabc
 
@@ -583,6 +625,12 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         KABC_HIP_CHECK(bufs.alloc(&sa.stamps, 8));
         KABC_HIP_CHECK(hipMemsetAsync(sa.stamps, 0, 64, s));
     }
+    // large ensembles: the selection as barrier-free kernels over all CUs (smc_select2_kernels.hpp)
+    SmcSel2Scratch* sel2 = nullptr;
+    if (use_select2(N, comm != nullptr)) KABC_HIP_CHECK(bufs.alloc(&sel2, 1));
+    auto do_select = [&](hipStream_t st) -> hipError_t {
+        return sel2 ? launch_select2(sa, sel2, st) : launch_select(sa, selG, st);
+    };
     SmcMcmcArgs ma;
     std::memset(&ma, 0, sizeof ma);
     for (int b = 0; b < 2; ++b) {
@@ -813,7 +861,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     // gathered) and whether the next pass is still open; with a simulator expensive enough to
     // be worth sharding, a host round trip per pass is noise.
     while (comm && !looped) {
-        KABC_HIP_CHECK(launch_select(sa, selG, s));
+        KABC_HIP_CHECK(do_select(s));
         KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
         KABC_HIP_CHECK(hipStreamSynchronize(s));
         if (hc.done) break;
@@ -852,7 +900,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         // (the next kBatch passes at once: pass t = *ctrl.pass + 1 + s in slot t mod kAuxRing)
         if (auxW && aux_ring > 1) launch_aux_prepass(cost->id, xa, s, 1);
         for (int it = 0; it < kBatch; ++it) {
-            KABC_HIP_CHECK(launch_select(sa, selG, s));
+            KABC_HIP_CHECK(do_select(s));
             bool ended = false;  // the iteration's end rode on the last pass_end launch
             for (int r0 = 0; r0 < R; r0 += kGroup) {
                 const int r1 = (r0 + kGroup < R) ? r0 + kGroup : R;
@@ -896,6 +944,8 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                       "resident -- another tenant holds the CUs; KABC_SMC_COOPERATIVE=1 launches the "
                       "select kernel cooperatively -- or the device is wedged)");
             rc = KABC_ERR_DEVICE;
+        } else if (hc.error == 5) {
+            rc = KABC_ERR_UNSUPPORTED;  // (the barrier-free select gave up: repeated below)
         } else if (hc.error == 4) {
             // more particles share one histogram bin of the costs than the loop kernel's candidate
             // list holds (heavy ties): a limit of that kernel, not of the problem.  The run is
@@ -955,6 +1005,14 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         tl_smc_no_loop = true;
         const kabc_status_t st2 = kabc_smc_run(ctx, prior, D, cost, o, res);
         tl_smc_no_loop = false;
+        return st2;
+    }
+    // (test hook: KABC_SMC_SELECT2_GIVE_UP=1 makes every run on the barrier-free select count as given up)
+    if (sel2 && !tl_smc_no_sel2 && hc.error == 0 && std::getenv("KABC_SMC_SELECT2_GIVE_UP")) hc.error = 5;
+    if (hc.error == 5 && sel2 && !tl_smc_no_sel2) {
+        tl_smc_no_sel2 = true;
+        const kabc_status_t st2 = kabc_smc_run(ctx, prior, D, cost, o, res);
+        tl_smc_no_sel2 = false;
         return st2;
     }
     if (sa.stamps) {
@@ -1192,6 +1250,18 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     KABC_HIP_CHECK(bufs.alloc(&sa.scratch, 1));
     KABC_HIP_CHECK(hipMemsetAsync(sa.scratch, 0, sizeof(SmcSelScratch), s));
     const unsigned selG = select_blocks(N);
+    // large ensembles: the selection as barrier-free kernels over all CUs (smc_select2_kernels.hpp)
+    SmcSel2Scratch* sel2 = nullptr;
+    if (use_select2(N, false)) KABC_HIP_CHECK(bufs.alloc(&sel2, 1));
+    auto do_select = [&](hipStream_t st) -> hipError_t {
+        return sel2 ? launch_select2(sa, sel2, st) : launch_select(sa, selG, st);
+    };
+    auto retry_without_sel2 = [&]() -> kabc_status_t {  // (a candidate bin beyond the list: the same run on the one-kernel select)
+        tl_smc_no_sel2 = true;
+        const kabc_status_t st2 = kabc_pfilter_run(ctx, prior, D, cost, o, res);
+        tl_smc_no_sel2 = false;
+        return st2;
+    };
     PfArgs pa;
     std::memset(&pa, 0, sizeof pa);
     pa.theta = th;
@@ -1226,7 +1296,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         const int kIterBatch = o->verbose ? 1 : 4;
         for (int b = 0; b < kIterBatch; ++b) {
             ++iters;
-            KABC_HIP_CHECK(launch_select(sa, selG, s));
+            KABC_HIP_CHECK(do_select(s));
             hipLaunchKernelGGL(pf_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
                                pending, ok, pctrl, sel, N);
             pa.iteration = (uint64_t)iters;
@@ -1239,6 +1309,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         KABC_HIP_CHECK(hipGetLastError());
         KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));
         KABC_HIP_CHECK(hipStreamSynchronize(s));
+        if (hp.error == 5 && sel2) return retry_without_sel2();
         if (hp.error == 3) {
             set_error("pfilter: a device-wide barrier timed out after 5 s (the select grid did not "
                       "become resident -- KABC_SMC_COOPERATIVE=1 launches it cooperatively -- or "
@@ -1265,7 +1336,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     }
     while (!batched_done) {
         ++iters;
-        KABC_HIP_CHECK(launch_select(sa, selG, s));
+        KABC_HIP_CHECK(do_select(s));
         hipLaunchKernelGGL(pf_mark_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s,
                            pending, ok, pctrl, sel, N);
         pa.iteration = (uint64_t)iters;
@@ -1280,6 +1351,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
             KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipMemcpyAsync(&hsel, sel, sizeof hsel, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipStreamSynchronize(s));
+            if (hsel.error == 5 && sel2) return retry_without_sel2();
             if (hsel.error == 3) {
                 set_error("pfilter: a device-wide barrier timed out after 5 s (the select grid did not "
                           "become resident -- KABC_SMC_COOPERATIVE=1 launches it cooperatively -- or "

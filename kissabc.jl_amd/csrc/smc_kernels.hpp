@@ -815,7 +815,10 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
         load_row<D>(theta_src + si * D, th);
         double Xi = X_src[si];
         double lpi = lpi_src[si];
-        alive_i = A.alive[i] != 0;
+        // (after a resample every particle is alive, src/smc.jl:152; the barrier-free select
+        // (smc_select2_kernels.hpp) leaves writing that to this kernel)
+        alive_i = A.ctrl->resampled != 0 || A.alive[i] != 0;
+        if (A.ctrl->resampled != 0) const_cast<uint8_t*>(A.alive)[i] = 1;
         if (alive_i) {
             const uint64_t N = (uint64_t)A.N;
             const uint32_t w = (uint32_t)i;

@@ -1097,10 +1097,8 @@ int32_t orc_abcde_run(const kabc_prior_t* prior, int32_t D, const kabc_cost_t* c
             if (dl[i] < el) el = dl[i];
             if (dl[i] > eh) eh = dl[i];
         }
-        if (o->earlystop && eh <= o->eps_target) break; /* :379-381 (before iters += 1 here
-                                                            would differ: the reference increments
-                                                            first; keep its count) */
-        iters += 1;
+        iters += 1;                                     /* :373: the reference counts the generation first ... */
+        if (o->earlystop && eh <= o->eps_target) break; /* :379-381 ... and then leaves (iters includes it) */
         memcpy(nth, th, sizeof(double) * N * D);
         memcpy(ndl, dl, sizeof(double) * N);
         memcpy(nlp, lp, sizeof(double) * N);

@@ -45,12 +45,17 @@ def test_abcde_bit_exact(k, orc, gpu_ctx, name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["gauss_5000", "ties_4096", "early_9000", "power2_8192"])
-def test_abcde_rank_structure_bit_exact(k, orc, gpu_ctx, name):
+@pytest.mark.parametrize("structure", ["blocks", "wavelet"])
+@pytest.mark.parametrize("name", ["gauss_5000", "ties_4096", "early_9000", "power2_8192", "ragged_16500"])
+def test_abcde_rank_structure_bit_exact(k, orc, gpu_ctx, monkeypatch, name, structure):
     """From 4096 particles on, the donor draw s = rand((1:N)[Δs .<= Δs[i]]) (src/smc.jl:392)
-    goes through a per-generation rank structure (costs sorted by rocPRIM, a wavelet matrix over
-    the particle order) instead of two O(N) scans per particle; the oracle keeps the scans.
-    Heavy ties (integer-valued costs) make the <= prefix sets differ from the strict ranks."""
+    goes through a per-generation structure instead of two O(N) scans per particle: up to 131 072
+    particles the costs sorted in blocks of 256 consecutive particles and one wavefront per draw
+    (two launches per generation; the default there), beyond -- and under KABC_ABCDE_RANK=wavelet
+    -- the costs sorted globally (own LSD radix sort) and a wavelet matrix over the particle
+    order.  The oracle keeps the scans.  Heavy ties (integer-valued costs) make the <= prefix
+    sets differ from the strict ranks; 16 500 particles: 65 blocks, two per lane, a ragged last one."""
+    monkeypatch.setenv("KABC_ABCDE_RANK", structure)
     N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
     du = k.Factored(k.DiscreteUniform(-30, 30), k.DiscreteUniform(-30, 30))
     cases = {
@@ -59,6 +64,7 @@ def test_abcde_rank_structure_bit_exact(k, orc, gpu_ctx, name):
         "early_9000": (N2, k.costs.GaussDist([1.0, -0.5]), 2.0,
                        dict(nparticles=9000, generations=10, alpha=0.3, earlystop=True)),
         "power2_8192": (N2, k.costs.NoisyBanana(0.0), 0.5, dict(nparticles=8192, generations=6)),
+        "ragged_16500": (du, k.costs.GaussDist([3.0, -2.0]), 0.5, dict(nparticles=16500, generations=5, alpha=0.2)),
     }
     pri, cost, eps, kw = cases[name]
     got = k.ABCDE(pri, cost, eps, seed=9, return_array=True, **kw)

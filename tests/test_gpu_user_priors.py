@@ -148,12 +148,13 @@ def _spec_models(k):
         "socks": (k.ApproxKernelizedPosterior(socks, k.costs.GaussDist([40.0, 0.8]), 3.0), 400, 9),
         "four_family_d4": (k.ApproxKernelizedPosterior(four, k.costs.NormShell(2.0), 0.5), 333, 5),
         "c4_prior_d16": (k.ApproxKernelizedPosterior(H16, k.costs.HierGaussSim(rng.normal(size=14)), 0.3), 640, 5),
-        "c2_normal_d2": (k.ApproxKernelizedPosterior(N2, k.costs.GaussDist([1.0, -0.5]), 0.1), 1024, 5),
+        "normal_d8": (k.ApproxKernelizedPosterior(k.Factored(*[k.Normal(0.5 * j, 1.0 + j) for j in range(8)]),
+                                                  k.costs.GaussDist(np.arange(8.0) / 4), 0.5), 1024, 5),
         "threshold_mixed_user": (k.ApproxPosterior(mixed, k.costs.NormShell(8.0), 6.0), 300, 9),
     }
 
 
-@pytest.mark.parametrize("name", ["socks", "four_family_d4", "c4_prior_d16", "c2_normal_d2",
+@pytest.mark.parametrize("name", ["socks", "four_family_d4", "c4_prior_d16", "normal_d8",
                                   "threshold_mixed_user"])
 def test_specialised_ais_kernels_bit_exact(k, orc, gpu_ctx, monkeypatch, name):
     """the same model on the prebuilt kernels, on its specialised kernels and on the oracle"""
@@ -199,6 +200,14 @@ def test_specialised_smc_kernels_bit_exact(k, orc, gpu_ctx, monkeypatch, path):
             assert r.info["iterations"] == ref["iterations"] and r.info["log"] == ref["log"]
             assert r.eps == ref["eps"] and np.array_equal(r.info["theta_all"], ref["theta_all"])
             assert np.array_equal(r.C, ref["C"])
+
+
+def test_small_all_normal_priors_stay_on_the_prebuilt_class(k, gpu_ctx):
+    """plain Normals up to seven parameters: the prebuilt NORMAL class is the faster kernel (C2)"""
+    N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    model = k.ApproxKernelizedPosterior(N2, k.costs.GaussDist([1.0, -0.5]), 0.1)
+    assert k.compile_model(model, families=1) == 0
+    assert k.AisEnsemble(model, 256, seed=1).init().spec_state() == ("none", -1)
 
 
 def test_specialize_env_and_release(k, orc, gpu_ctx, monkeypatch):

@@ -14,6 +14,10 @@ nt = int(os.environ.get("KABC_NT", "16"))
 m = bench.build_model(k)
 e = k.AisEnsemble(m, 65536, seed=1).init()
 e.advance(5, nt)
-e.set_timing(100)
-e.advance(50, nt)
-print("ablate", os.environ.get("KABC_ABLATE"), "nt", nt, "kernel ms (hipEvent)", e.kernel_ms())
+ts = []
+for _ in range(5):
+    e.set_timing(800, stride=8)   # (a pair per launch adds ~2.5 us of marker packets to the figure)
+    e.advance(400, nt)
+    ts.append(e.kernel_ms()[0] * 1e3)
+print("ablate", os.environ.get("KABC_ABLATE", "0"), "nt", nt, "kernel us (hipEvent, median of 5 x 800 launches)",
+      round(sorted(ts)[2], 3))
