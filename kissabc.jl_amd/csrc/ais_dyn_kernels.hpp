@@ -254,6 +254,7 @@ __global__ void __launch_bounds__(kWave) ais_dyn_init_kernel(const AisDynArgs A)
     A.ll[r] = ll;
 }
 
+#ifndef __HIPCC_RTC__  // host side
 using AisDynLaunchFn = void (*)(const AisDynArgs&, hipStream_t, int init);
 
 template <int COST>
@@ -263,5 +264,27 @@ inline void launch_ais_dyn(const AisDynArgs& a, hipStream_t s, int init) {
     if (init) hipLaunchKernelGGL((ais_dyn_init_kernel<COST>), dim3(grid), dim3(kWave), 0, s, a);
     else hipLaunchKernelGGL((ais_dyn_half_kernel<COST>), dim3(grid), dim3(kWave), 0, s, a);
 }
+
+// a host launch function (built-in costs, plugin .so built by hipcc) or the pair of kernels of a
+// run-time compiled unit (a hipRTC user cost, user prior families): plugin_registry.hpp kPfAisDyn
+struct AisDynLaunch {
+    AisDynLaunchFn fn = nullptr;
+    void* mod_half = nullptr;
+    void* mod_init = nullptr;
+    AisDynLaunch() = default;
+    AisDynLaunch(AisDynLaunchFn f) : fn(f) {}
+    AisDynLaunch(void* half, void* init) : mod_half(half), mod_init(init) {}
+    explicit operator bool() const { return fn != nullptr || (mod_half != nullptr && mod_init != nullptr); }
+    void operator()(const AisDynArgs& a, hipStream_t s, int init) const {
+        if (fn) {
+            fn(a, s, init);
+            return;
+        }
+        const unsigned grid = (unsigned)((a.rows_owned + kWave - 1) / kWave);
+        if (grid == 0) return;
+        (void)rtc_launch(init ? mod_init : mod_half, dim3(grid), dim3(kWave), &a, s);
+    }
+};
+#endif
 
 }  // namespace kabc

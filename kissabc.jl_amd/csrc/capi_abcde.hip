@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) wm_partition_kernel(const unsigned* sin, 
 // 256 costs in index order with four ballots.  Same count, same m, same index as the scans and
 // the wavelet matrix.
 constexpr int kDbBlock = 256;                 // particles per sorted block
-constexpr int64_t kDbMaxN = 131072;           // beyond: the wavelet matrix (lanes would walk > 8 blocks each)
+constexpr int64_t kDbMaxN = 32768;            // beyond: the wavelet matrix (measured crossover: 32 768: 1.8 vs 3.1 ms per 10 generations, 65 536: 5.5 vs 4.2)
 constexpr int kDbMaxPerLane = (int)(kDbMaxN / kDbBlock / kWave);
 
 // sorted[b * 256 + r] = r-th smallest cost of particles [256 b, 256 b + 256) (+Inf past N)
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) abcde_donor_blocks_kernel(const AbcdeArgs
     }
     const int nblocks = (int)((N + kDbBlock - 1) / kDbBlock);
     const int per = (nblocks + kWave - 1) / kWave;  // consecutive blocks per lane (<= kDbMaxPerLane)
-    // count of costs <= di in each of this lane's blocks: upper bound by bisection (8 steps of 256)
+    // count of costs <= di in each of this lane's blocks: upper bound by bisection
     int cb[kDbMaxPerLane];
     int c = 0;
 #pragma unroll
@@ -271,12 +271,14 @@ __global__ void __launch_bounds__(256) abcde_donor_blocks_kernel(const AbcdeArgs
         const int b = lane * per + q;
         if (q < per && b < nblocks) {
             const double* __restrict__ sb = sorted + (size_t)b * kDbBlock;
-            int lo = 0, hi = kDbBlock;
+            int lo = 0, hi = kDbBlock;  // 257 possible answers: nine steps
 #pragma unroll
-            for (int step = 0; step < 8; ++step) {
-                const int mid = (lo + hi) >> 1;
-                if (sb[mid] <= di) lo = mid + 1;
-                else hi = mid;
+            for (int step = 0; step < 9; ++step) {
+                if (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sb[mid] <= di) lo = mid + 1;
+                    else hi = mid;
+                }
             }
             cb[q] = lo;
             c += lo;
@@ -406,9 +408,13 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     // length(prior) > KABC_MAX_DIM: the run-time-dimension instantiation (D = 0) of the kernels,
     // prior components as device arrays (built-in DeviceCosts)
     const bool dyn = D > KABC_MAX_DIM;
-    if (dyn && cost->id >= KABC_COST_USER) {
-        set_error("ABCDE with length(prior) = %d > %d: built-in DeviceCosts only", D, KABC_MAX_DIM);
-        return KABC_ERR_UNSUPPORTED;
+    {
+        const CostPlugin* pl = cost->id >= KABC_COST_USER ? find_plugin(cost->id) : nullptr;
+        if (dyn && pl && !pl->rtc) {
+            set_error("ABCDE with length(prior) = %d > %d: built-in DeviceCosts or a user cost in the hipRTC form "
+                      "(kabc_compile_cost_plugin)", D, KABC_MAX_DIM);
+            return KABC_ERR_UNSUPPORTED;
+        }
     }
     if (N < 3 || N >= (1ll << 31)) {  // three distinct indices s, a, b are drawn (:394-401)
         set_error("nparticles must be >= 3 (and < 2^31)");
@@ -437,13 +443,7 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     // (run-time compiled kernels are loaded on the CURRENT device)
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     ModelUnit* unit = nullptr;
-    for (int k = 0; k < D && dyn; ++k)
-        if (prior[k].kind >= KABC_PRIOR_USER) {
-            set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
-            return KABC_ERR_UNSUPPORTED;
-        }
-    if (!dyn)
-        if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
+    if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
     if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
         const PluginKernel ki = unit_kernel(unit, kPfAbcdeInit, D, 0), kg = unit_kernel(unit, kPfAbcdeGen, D, 0);
         if (ki.mod) f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
@@ -453,7 +453,7 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     }
     if (!f_init || !f_gen) {
         AbcdeLaunch b_init, b_gen;
-        if (dyn) {
+        if (dyn && cost->id < KABC_COST_USER) {
             b_init = AbcdeLaunch(&l_init<0>);
             b_gen = AbcdeLaunch(&l_gen<0>);
         } else if (const CostPlugin* p = find_plugin(cost->id)) {

@@ -130,7 +130,7 @@ struct kabc_ais {
     int64_t cper[2];       // rows per rank and chunk (all-gather count / D)
     kabc_comm_t* comm;     // library-owned exchange (kabc_ais_create_dist), else NULL
     // length(prior) > KABC_MAX_DIM: run-time-dimension kernels (ais_dyn_kernels.hpp)
-    AisDynLaunchFn dyn;
+    AisDynLaunch dyn;
     std::vector<kabc_prior_t> raw_dyn;
     std::vector<PriorDev> prior_dyn;
     kabc_prior_t* d_raw;   // [D] raw components (dyn)
@@ -280,20 +280,10 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     mres.prior = resolved.data();
     m = &mres;
     const bool dyn = m->D > KABC_MAX_DIM;
-    AisDynLaunchFn dyn_fn = nullptr;
-    if (dyn) {
-        if (m->cost.id >= KABC_COST_USER) {
-            const CostPlugin* pl = find_plugin(m->cost.id);
-            dyn_fn = (pl && pl->ais_dyn) ? (AisDynLaunchFn)pl->ais_dyn() : nullptr;
-        } else {
-            dyn_fn = find_ais_dyn_kernel();
-        }
-        if (nchains != 1 || !dyn_fn) {
-            set_error("length(prior) = %d > %d runs on the run-time-dimension kernels: one chain per "
-                      "handle, built-in DeviceCosts or a plugin built from the current headers",
-                      m->D, KABC_MAX_DIM);
-            return KABC_ERR_UNSUPPORTED;
-        }
+    if (dyn && nchains != 1) {
+        set_error("length(prior) = %d > %d runs on the run-time-dimension kernels: one chain per handle",
+                  m->D, KABC_MAX_DIM);
+        return KABC_ERR_UNSUPPORTED;
     }
     // src/KissABC.jl:43-48
     if (n_total < m->D + 5) {
@@ -357,19 +347,37 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     // user prior families among the components, or a specialisation of exactly this model
     // (kabc_compile_model): the kernels of that unit, GENERAL class (plugin_registry.hpp)
     ModelUnit* unit = nullptr;
-    if (!dyn) {
-        if (kabc_status_t st = model_unit_for(m->prior, m->D, m->cost.id, &unit)) return st;
-    } else {
-        for (int k = 0; k < m->D; ++k)
-            if (m->prior[k].kind >= KABC_PRIOR_USER) {
-                set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, m->D);
-                return KABC_ERR_UNSUPPORTED;
+    if (kabc_status_t st = model_unit_for(m->prior, m->D, m->cost.id, &unit)) return st;
+    // length(prior) > KABC_MAX_DIM: the run-time-dimension kernels -- of the unit (user prior families:
+    // compiled with their snippets), of the user cost (hipRTC form, or its plugin .so), or the built-in ones
+    AisDynLaunch dyn_fn;
+    if (dyn) {
+        if (unit) {
+            const PluginKernel kh = unit_kernel(unit, kPfAisDyn, m->D, 0), ki = unit_kernel(unit, kPfAisDyn, m->D, 1);
+            dyn_fn = AisDynLaunch(kh.mod, ki.mod);
+            if (!dyn_fn) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
+        } else if (m->cost.id >= KABC_COST_USER) {
+            const CostPlugin* pl = find_plugin(m->cost.id);
+            if (pl && pl->rtc) {
+                const PluginKernel kh = plugin_kernel(pl, kPfAisDyn, m->D, 0), ki = plugin_kernel(pl, kPfAisDyn, m->D, 1);
+                dyn_fn = AisDynLaunch(kh.mod, ki.mod);
+            } else if (pl && pl->ais_dyn) {
+                dyn_fn = AisDynLaunch((AisDynLaunchFn)pl->ais_dyn());
             }
+        } else {
+            dyn_fn = AisDynLaunch(find_ais_dyn_kernel());
+        }
+        if (!dyn_fn) {
+            if (!get_error()[0])
+                set_error("length(prior) = %d > %d: no run-time-dimension kernels for cost id %d (a plugin .so "
+                          "built from older headers?)", m->D, KABC_MAX_DIM, m->cost.id);
+            return KABC_ERR_UNSUPPORTED;
+        }
     }
     AisLaunch fn;
     int spec_state = KABC_SPEC_NONE;
     const int spec_variant = kPriorGeneral + kPriorClasses * (m->posterior - 1);
-    if (unit) {
+    if (unit && !dyn) {
         const PluginKernel uk = unit_kernel(unit, kPfAis, m->D, spec_variant, &spec_state);
         if (uk.mod) fn = AisLaunch(uk.mod, &ais_half_geom, (unsigned)kAisBlock);
         // user families: there are no other kernels (message set by the compilation / load)

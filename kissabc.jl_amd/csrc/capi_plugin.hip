@@ -766,7 +766,13 @@ static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int 
         if (try_failed) return rtc_kernel_try(R_, head_, header, fma, names, want, try_failed);
         return kabc::rtc_kernel(R_, head_, header, fma, names, want);
     };
-    const std::string d = std::to_string(D), u = std::to_string(cost);
+    const bool big = D > KABC_MAX_DIM;  // run-time-dimension kernels: the D = 0 / dyn instantiations
+    if (big && family != kPfAisDyn && family != kPfSmcDyn && family != kPfAbcdeInit && family != kPfAbcdeGen &&
+        family != kPfAttempt && family != kPfPriorLogpdf && family != kPfPriorRand)
+        return k;
+    const std::string d = std::to_string(big ? 0 : D), u = std::to_string(cost);
+    // (the dyn kernels dispatch a built-in cost at run time: their COST argument only says "user cost")
+    const std::string udyn = std::to_string(cost == (int)KABC_COST_USER ? (int)KABC_COST_USER : 0);
     const std::string ais_init = "kabc::ais_init_kernel<" + d + ">";
     auto smc_names = [&](int simple) {
         const std::string sb = simple ? "true" : "false";
@@ -817,6 +823,18 @@ static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int 
             k.mod = rtc_kernel(R, head, "smc_small_kernel.hpp", false, {n}, n);
             break;
         }
+        case kPfAisDyn: {
+            const std::vector<std::string> n = {"kabc::ais_dyn_half_kernel<" + udyn + ">",
+                                                "kabc::ais_dyn_init_kernel<" + udyn + ">"};
+            k.mod = rtc_kernel(R, head, "ais_dyn_kernels.hpp", false, n, n[variant ? 1 : 0]);
+            break;
+        }
+        case kPfSmcDyn: {
+            const std::vector<std::string> n = {"kabc::smc_dyn_mcmc_kernel<" + udyn + ">",
+                                                "kabc::smc_dyn_init_kernel<" + udyn + ">"};
+            k.mod = rtc_kernel(R, head, "smc_dyn_kernels.hpp", false, n, n[variant ? 1 : 0]);
+            break;
+        }
         case kPfPriorLogpdf:
         case kPfPriorRand: {
             const std::vector<std::string> n = {"kabc::prior_logpdf_kernel", "kabc::prior_rand_kernel"};
@@ -846,7 +864,7 @@ PluginKernel plugin_kernel(const CostPlugin* p, int family, int D, int variant) 
         return k;
     }
     RtcPlugin* R = p->rtc;
-    if (D < 1 || D > KABC_MAX_DIM || !rtc_dim_listed(R, D)) return k;
+    if (D < 1 || D > KABC_MAX_DIM_DYN || !rtc_dim_listed(R, D)) return k;
     return rtc_family_kernel(R, cost_head(R), (int)KABC_COST_USER, R->pk_mask, family, D, variant);
 }
 
@@ -1021,8 +1039,8 @@ kabc_status_t model_unit_for(const kabc_prior_t* prior, int D, int cost_id, Mode
             set_error("prior kind %d is not a registered user family (kabc_compile_prior_plugin)", k);
             return KABC_ERR_INVALID_ARG;
         }
-    if (!uk.empty() && D > KABC_MAX_DIM) {
-        set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
+    if (!uk.empty() && D > KABC_MAX_DIM_DYN) {
+        set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM_DYN, D);
         return KABC_ERR_UNSUPPORTED;
     }
     // 1. the unit the kernels must come from when no specialisation serves
@@ -1063,7 +1081,7 @@ static bool is_init_family(int family) {
 
 PluginKernel unit_kernel(ModelUnit* u, int family, int D, int variant, int* spec_state) {
     if (spec_state) *spec_state = KABC_SPEC_NONE;
-    if (!u || D < 1 || D > KABC_MAX_DIM) return PluginKernel();
+    if (!u || D < 1 || D > KABC_MAX_DIM_DYN) return PluginKernel();
     if (!u->spec) return rtc_family_kernel(u, u->head, u->cost_tmpl, u->pk_mask, family, D, variant);
     PluginKernel k;
     if (!u->async) {
@@ -1085,7 +1103,7 @@ PluginKernel unit_kernel(ModelUnit* u, int family, int D, int variant, int* spec
 bool cost_dim_ok_rt(int cost_id, int D) {
     if (cost_id < KABC_COST_USER) return kabc_cost_dim_ok(cost_id, D) != 0;
     const CostPlugin* p = find_plugin(cost_id);
-    if (p && p->rtc) return D >= 1 && D <= KABC_MAX_DIM && rtc_dim_listed(p->rtc, D);
+    if (p && p->rtc) return D >= 1 && D <= KABC_MAX_DIM_DYN && rtc_dim_listed(p->rtc, D);
     return p && p->dim_ok(D) != 0;
 }
 
@@ -1122,11 +1140,9 @@ extern "C" kabc_status_t kabc_compile_cost_plugin(const char* src, const int32_t
     R->src = src;
     R->pk_mask = (posterior_mask & 7) ? (posterior_mask & 7) : 7;
     for (int i = 0; i < ndims; ++i) {
-        if (dims[i] < 1 || dims[i] > KABC_MAX_DIM) {
+        if (dims[i] < 1 || dims[i] > KABC_MAX_DIM_DYN) {
             delete R;
-            set_error("kabc_compile_cost_plugin: dims must lie in 1..%d (longer parameter vectors run on "
-                      "the run-time-dimension kernels of a plugin .so built by hipcc: "
-                      "kabc_register_cost_plugin)", KABC_MAX_DIM);
+            set_error("kabc_compile_cost_plugin: dims must lie in 1..%d", KABC_MAX_DIM_DYN);
             return KABC_ERR_UNSUPPORTED;
         }
         R->dims.push_back(dims[i]);
@@ -1154,7 +1170,7 @@ extern "C" kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family,
         set_error("kabc_plugin_precompile: %d is not a registered user cost", cost_id);
         return KABC_ERR_INVALID_ARG;
     }
-    if (family < kPfAis || (family > kPfAttempt && family != kPfSmcSmall)) {
+    if (family < kPfAis || (family > kPfAttempt && family != kPfSmcSmall && family != kPfAisDyn && family != kPfSmcDyn)) {
         set_error("kabc_plugin_precompile: unknown kernel family %d", family);
         return KABC_ERR_INVALID_ARG;
     }

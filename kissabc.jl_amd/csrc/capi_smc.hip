@@ -410,27 +410,30 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     // user prior families among the components, or a specialisation of exactly this model
     ModelUnit* unit = nullptr;
-    if (!dyn) {
-        if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
-    } else {
-        for (int k = 0; k < D; ++k)
-            if (prior[k].kind >= KABC_PRIOR_USER) {
-                set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
-                return KABC_ERR_UNSUPPORTED;
-            }
-    }
+    if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
     // (a specialisation an entry point made on its own is asked for the kernels of the driver that
     // actually runs, below; here: does a propose / accept kernel exist at all)
     SmcLaunch mcmc = dyn ? SmcLaunch() : find_smc_kernel(cost->id, D, simple, unit_required(unit) ? unit : nullptr);
-    bool mcmc_final = !unit || unit_required(unit);
-    if (!mcmc && unit_required(unit)) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
-    SmcDynLaunchFn dyn_fn = nullptr;
+    bool mcmc_final = !unit || unit_required(unit) || dyn;
+    if (!mcmc && !dyn && unit_required(unit)) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
+    // length(prior) > KABC_MAX_DIM: the run-time-dimension kernels -- of the unit (user prior families),
+    // of the user cost (hipRTC form, or its plugin .so), or the built-in ones
+    SmcDynLaunch dyn_fn;
     if (dyn) {
-        if (cost->id >= KABC_COST_USER) {
+        if (unit) {
+            const PluginKernel km = unit_kernel(unit, kPfSmcDyn, D, 0), ki = unit_kernel(unit, kPfSmcDyn, D, 1);
+            dyn_fn = SmcDynLaunch(km.mod, ki.mod);
+            if (!dyn_fn) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
+        } else if (cost->id >= KABC_COST_USER) {
             const CostPlugin* pl = find_plugin(cost->id);
-            dyn_fn = (pl && pl->smc_dyn) ? (SmcDynLaunchFn)pl->smc_dyn() : nullptr;
+            if (pl && pl->rtc) {
+                const PluginKernel km = plugin_kernel(pl, kPfSmcDyn, D, 0), ki = plugin_kernel(pl, kPfSmcDyn, D, 1);
+                dyn_fn = SmcDynLaunch(km.mod, ki.mod);
+            } else if (pl && pl->smc_dyn) {
+                dyn_fn = SmcDynLaunch((SmcDynLaunchFn)pl->smc_dyn());
+            }
         } else {
-            dyn_fn = &launch_smc_dyn<0>;
+            dyn_fn = SmcDynLaunch(&launch_smc_dyn<0>);
         }
     }
     if (!mcmc && !dyn_fn) {
@@ -1112,20 +1115,18 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     }
     AbcdeLaunch f_init;
     PfLaunch f_att;
-    if (dyn && cost->id >= KABC_COST_USER) {
-        set_error("pfilter with length(prior) = %d > %d: built-in DeviceCosts only", D, KABC_MAX_DIM);
-        return KABC_ERR_UNSUPPORTED;
+    {
+        const CostPlugin* pl = cost->id >= KABC_COST_USER ? find_plugin(cost->id) : nullptr;
+        if (dyn && pl && !pl->rtc) {
+            set_error("pfilter with length(prior) = %d > %d: built-in DeviceCosts or a user cost in the hipRTC "
+                      "form (kabc_compile_cost_plugin)", D, KABC_MAX_DIM);
+            return KABC_ERR_UNSUPPORTED;
+        }
     }
     // (run-time compiled kernels are loaded on the CURRENT device)
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     ModelUnit* unit = nullptr;
-    for (int k = 0; k < D && dyn; ++k)
-        if (prior[k].kind >= KABC_PRIOR_USER) {
-            set_error("a prior with user families supports length(prior) <= %d (got %d)", KABC_MAX_DIM, D);
-            return KABC_ERR_UNSUPPORTED;
-        }
-    if (!dyn)
-        if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
+    if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
     if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
         const PluginKernel ki = unit_kernel(unit, kPfAbcdeInit, D, 0), ka = unit_kernel(unit, kPfAttempt, D, 0);
         if (ki.mod) f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
@@ -1136,7 +1137,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     if (!f_init || !f_att) {
         AbcdeLaunch b_init;
         PfLaunch b_att;
-        if (dyn) {
+        if (dyn && cost->id < KABC_COST_USER) {
             b_init = AbcdeLaunch(&pf_l_init<0>);
             b_att = PfLaunch(&pf_l_attempt<0>);
         } else if (const CostPlugin* p = find_plugin(cost->id)) {

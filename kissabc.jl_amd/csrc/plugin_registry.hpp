@@ -33,7 +33,11 @@ bool cost_dim_ok_rt(int cost_id, int D);
 enum PluginFamily {
     kPfAis = 0, kPfAisInit, kPfSmc, kPfSmcInit, kPfSmcLoop, kPfAbcdeInit, kPfAbcdeGen, kPfAttempt,
     kPfPriorLogpdf, kPfPriorRand,  // (model units only: the Factored utility kernels)
-    kPfSmcSmall                    // (hipRTC units: the one-workgroup smc driver, smc_small_kernel.hpp)
+    kPfSmcSmall,                   // (hipRTC units: the one-workgroup smc driver, smc_small_kernel.hpp)
+    // (hipRTC units) the run-time-dimension kernels, length(prior) > KABC_MAX_DIM: variant 0 the
+    // half-generation / propose+accept kernel, 1 the init kernel (ais_dyn_kernels.hpp, smc_dyn_kernels.hpp);
+    // ABCDE / pfilter beyond KABC_MAX_DIM: their own families, instantiated with D = 0
+    kPfAisDyn, kPfSmcDyn
 };
 struct PluginKernel {
     void* host = nullptr;

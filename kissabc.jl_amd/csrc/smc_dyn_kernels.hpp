@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_dyn_mcmc_kernel(const SmcDynArg
     }
 }
 
+#ifndef __HIPCC_RTC__  // host side
 using SmcDynLaunchFn = void (*)(const SmcDynArgs&, hipStream_t, int init);
 
 template <int COST>
@@ -175,5 +176,26 @@ inline void launch_smc_dyn(const SmcDynArgs& a, hipStream_t s, int init) {
     if (init) hipLaunchKernelGGL((smc_dyn_init_kernel<COST>), dim3(grid), dim3(kSmcBlock), 0, s, a);
     else hipLaunchKernelGGL((smc_dyn_mcmc_kernel<COST>), dim3(grid), dim3(kSmcBlock), 0, s, a);
 }
+
+// (as AisDynLaunch, ais_dyn_kernels.hpp)
+struct SmcDynLaunch {
+    SmcDynLaunchFn fn = nullptr;
+    void* mod_mcmc = nullptr;
+    void* mod_init = nullptr;
+    SmcDynLaunch() = default;
+    SmcDynLaunch(SmcDynLaunchFn f) : fn(f) {}
+    SmcDynLaunch(void* mcmc, void* init) : mod_mcmc(mcmc), mod_init(init) {}
+    explicit operator bool() const { return fn != nullptr || (mod_mcmc != nullptr && mod_init != nullptr); }
+    void operator()(const SmcDynArgs& a, hipStream_t s, int init) const {
+        if (fn) {
+            fn(a, s, init);
+            return;
+        }
+        const unsigned grid = (unsigned)((a.N + kSmcBlock - 1) / kSmcBlock);
+        if (grid == 0) return;
+        (void)rtc_launch(init ? mod_init : mod_mcmc, dim3(grid), dim3(kSmcBlock), &a, s);
+    }
+};
+#endif
 
 }  // namespace kabc

@@ -72,10 +72,12 @@ def test_dynamic_dimension_limits_and_sharding(k, orc, gpu_ctx):
     grp.close()
 
 
-def test_dynamic_dimension_user_cost_and_utilities(k, orc, gpu_ctx):
-    """A run-time compiled user cost at D = 20 (the plugin carries its own instantiation of
-    the run-time-dimension kernels), and the Factored utilities (logpdf / push_p / rand on
-    the device) beyond 16 components."""
+@pytest.mark.parametrize("form", ["hiprtc", "hipcc"])
+def test_dynamic_dimension_user_cost_and_utilities(k, orc, gpu_ctx, monkeypatch, form):
+    """A run-time compiled user cost at D = 20 -- compiled in process (hipRTC: the run-time-dimension
+    kernels of its unit) or as a plugin .so built by hipcc (which carries its own instantiation of
+    them) -- and the Factored utilities (logpdf / push_p / rand on the device) beyond 16 components."""
+    monkeypatch.setenv("KABC_USER_PLUGIN", form)
     src = """
 KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
                               const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
@@ -84,7 +86,7 @@ KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
     for (int k = 0; k < D; ++k) s += (x[k] - params[0]) * (x[k] - params[0]);
     return kabc_sqrt(s) + 0.01 * kabc_fabs(z0);
 }"""
-    cost = k.costs.UserCost(src, dims=[20], params=[0.25], name="dyn_user", posteriors=["kernelized"])
+    cost = k.costs.UserCost(src, dims=[20], params=[0.25], name="dyn_user_" + form, posteriors=["kernelized"])
     orc.register_user_cost(cost)
     pri = k.Factored(*[k.Normal(0, 1)] * 19, k.DiscreteUniform(-2, 2))
     model = k.ApproxKernelizedPosterior(pri, cost, 0.7)

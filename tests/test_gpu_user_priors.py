@@ -130,9 +130,10 @@ def test_unregistered_kind_and_long_priors_fail_loudly(k, gpu_ctx):
     with pytest.raises(k.KabcError, match="invalid prior|not a registered"):
         k.AisEnsemble(k.ApproxKernelizedPosterior(k.Factored(Bogus(), k.Normal(0, 1)),
                                                   k.costs.GaussDist([0.0, 0.0]), 1.0), 64)
-    prior = k.Factored(*([k.Poisson(3.0)] + [k.Normal(0, 1)] * 16))
-    with pytest.raises(k.KabcError, match="user families"):
-        k.AisEnsemble(k.ApproxKernelizedPosterior(prior, k.costs.GaussDist(np.zeros(17)), 1.0), 64)
+    # (17 components with a user family: the run-time-dimension kernels, see below; the device
+    # path's own bound is KABC_MAX_DIM_DYN = 256 for every prior)
+    with pytest.raises(ValueError, match="256"):
+        k.Factored(*([k.Poisson(3.0)] + [k.Normal(0, 1)] * 256))
 
 
 # ---- kernels specialised for one model (kabc_compile_model) --------------------------------
@@ -218,3 +219,74 @@ def test_specialize_env_and_release(k, orc, gpu_ctx, monkeypatch):
     for v in ("1", "0"):
         monkeypatch.setenv("KABC_SPECIALIZE", v)
         assert np.array_equal(k.AisEnsemble(model, 200, seed=8).init().advance(3, 4, collect=True), ref)
+
+
+# ---- beyond 16 parameters: the run-time-dimension kernels compiled with the snippets --------
+def _big_prior(k, D):
+    comps = [k.Poisson(3.0), k.Normal(0, 2), k.Laplace(0.0, 1.5), k.Uniform(-3, 3), k.Truncated(k.Gamma(2.0, 1.5), 0.5, 6.0)]
+    return k.Factored(*[comps[j % len(comps)] for j in range(D)])
+
+
+@pytest.mark.parametrize("D", [17, 40])
+def test_user_families_beyond_16_parameters_bit_exact(k, orc, gpu_ctx, D):
+    """The reference's Factored has no bound on its length and takes any UnivariateDistribution
+    (src/priors.jl:11): user families with length(prior) > KABC_MAX_DIM run on the
+    run-time-dimension kernels, compiled by hipRTC with the families' snippets -- AIS, smc, ABCDE
+    and pfilter, bit-exact against the oracle running the same text."""
+    prior = _big_prior(k, D)
+    target = np.where(np.arange(D) % 5 == 0, 3.0, np.where(np.arange(D) % 5 == 4, 2.0, 0.3))
+    cost = k.costs.GaussDist(target)
+    model = k.ApproxKernelizedPosterior(prior, cost, 2.0)
+    N, nt, seed = 3 * D + 50, 3, 6
+    ens = k.AisEnsemble(model, N, seed=seed).init()
+    o = orc.OracleAIS(model, N, seed=seed).init()
+    x0, lp0, ll0, _ = ens.state()
+    xo, lpo, llo, _ = o.state()
+    assert np.array_equal(x0, xo) and np.array_equal(lp0, lpo) and np.array_equal(ll0, llo)
+    assert np.array_equal(ens.advance(3, nt, collect=True), o.generations_sync(3, nt))
+    assert ens.stats() == o.stats()
+    kw = dict(nparticles=40 * D, alpha=0.9, epstol=6.0 if D == 17 else 12.0)
+    g = k.smc(prior, cost, seed=2, return_array=True, **kw)
+    r = orc.smc(prior, cost, seed=2, **kw)
+    assert g.info["iterations"] == r["iterations"] > 2 and g.eps == r["eps"]
+    assert np.array_equal(g.info["theta_all"], r["theta_all"]) and np.array_equal(g.C, r["C"])
+    ga = k.ABCDE(prior, cost, 4.0, seed=9, return_array=True, nparticles=300, generations=15)
+    ra = orc.abcde(prior, cost, 4.0, seed=9, nparticles=300, generations=15)
+    assert np.array_equal(ga.P, ra["P"]) and np.array_equal(ga.C, ra["C"])
+    gp = k.pfilter(prior, cost, 300, seed=4, return_array=True, max_iters=6)
+    rp = orc.pfilter(prior, cost, 300, seed=4, max_iters=6)
+    assert np.array_equal(gp.P, rp["P"]) and np.array_equal(gp.C, rp["C"])
+
+
+def test_hiprtc_user_cost_beyond_16_parameters_bit_exact(k, orc, gpu_ctx):
+    """a user cost compiled in process (no hipcc, no plugin .so) with length(prior) = 17 and 40:
+    AIS, smc, ABCDE and pfilter on the run-time-dimension kernels of its hipRTC unit"""
+    src = """
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params, const double* data,
+                              int64_t ndata, kabc_cost_rng_t* rng) {
+    double z0, z1, s = 0.0;
+    kabc_cost_rng_normal2(rng, &z0, &z1);
+    for (int i = 0; i < D; ++i) s += (x[i] - params[0]) * (x[i] - params[0]);
+    return kabc_sqrt(s) + 0.01 * kabc_fabs(z0);
+}
+"""
+    cost = k.costs.UserCost(src, dims=[17, 40], params=[0.25], name="noisy_norm_big")
+    orc.register_user_cost(cost)
+    for D in (17, 40):
+        prior = k.Factored(*[k.Normal(0, 1.5), k.Uniform(-2, 2), k.Beta(2, 3)] * (D // 3) + [k.Normal(0, 1)] * (D % 3))
+        model = k.ApproxKernelizedPosterior(prior, cost, 1.0)
+        N, seed = 3 * D + 30, 3
+        ens = k.AisEnsemble(model, N, seed=seed).init()
+        assert np.array_equal(ens.advance(2, 4, collect=True),
+                              orc.OracleAIS(model, N, seed=seed).init().generations_sync(2, 4))
+        kw = dict(nparticles=50 * D, alpha=0.9, epstol=4.0 if D == 17 else 7.0)
+        g = k.smc(prior, cost, seed=2, return_array=True, **kw)
+        r = orc.smc(prior, cost, seed=2, **kw)
+        assert g.info["iterations"] == r["iterations"] and g.eps == r["eps"]
+        assert np.array_equal(g.info["theta_all"], r["theta_all"])
+        ga = k.ABCDE(prior, cost, 3.0, seed=9, return_array=True, nparticles=200, generations=10)
+        ra = orc.abcde(prior, cost, 3.0, seed=9, nparticles=200, generations=10)
+        assert np.array_equal(ga.P, ra["P"]) and np.array_equal(ga.C, ra["C"])
+        gp = k.pfilter(prior, cost, 200, seed=4, return_array=True, max_iters=5)
+        rp = orc.pfilter(prior, cost, 200, seed=4, max_iters=5)
+        assert np.array_equal(gp.P, rp["P"]) and np.array_equal(gp.C, rp["C"])
