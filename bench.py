@@ -758,6 +758,20 @@ def main():
                             "frac": ups * Bs / 1e9 / HBM_PEAK_GBS,
                             "note": "end to end (select + propose/accept + control), wall clock"},
                "mcmc_kernel_avg_ms": r.info["kernel_ms_mcmc"]}
+        # What an ε-iteration of the persistent loop kernel costs and what bounds it: two device-wide
+        # barriers at the XCD-aware price measured on this chip (3.8 us each at 128 workgroups:
+        # profiles/r03_xcd_barrier.json, rows written / barrier / another workgroup's rows read) and the
+        # pass's own dependent chain (draws -> resample lookups -> three rows -> prior -> simulator ->
+        # accept: 7.2 us by the kernel's phase stamps, profiles/r04_smc_c4.txt).  The contract roofline
+        # fraction of this workload cannot move (a pass is 17.9 MB = 2.2 us at 8 TB/s);
+        # latency_floor_frac = floor / measured is the number that can.
+        it_us = w * 1e6 / max(1, r.info["iterations"])
+        floor_us = 2 * 3.816 + 7.2
+        smc["iteration_us"] = it_us
+        smc["latency_floor_us"] = floor_us
+        smc["latency_floor_frac"] = floor_us / it_us
+        smc["latency_floor_formula"] = ("2 x XCD-aware barrier at 128 workgroups (3.816 us, r03_xcd_barrier.json) + "
+                                        "the pass's dependent chain (7.2 us, r04_smc_c4.txt phase stamps)")
         # HBM bytes of the loop kernel (one launch = the whole run) from the committed PMC passes
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_smc_loop.json"))):
             tj = json.load(open(tf))

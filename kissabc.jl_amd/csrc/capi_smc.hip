@@ -11,7 +11,6 @@
 #include "plugin_registry.hpp"
 #include "smc_loop_kernel.hpp"
 #include "smc_small_kernel.hpp"
-#include "smc_select2_kernels.hpp"
 #include "smc_dyn_kernels.hpp"
 #include "abcde_kernels.hpp"
 #include "pfilter_kernels.hpp"
@@ -242,68 +241,46 @@ static unsigned select_blocks(int64_t N) {
 // construction and costs ~21 us per launch, host and device side (131 072 particles x 16: 88 -> 67 us
 // per iteration without it, profiles/r04_smc_large.txt); KABC_SMC_COOPERATIVE=1 selects it.
 static unsigned select_capacity() {
-    static const unsigned cap = [] {
-        int dev = 0, per_cu = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 1u;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)smc_select_kernel, kSelBlock, 0) != hipSuccess)
-            return 1u;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 1u;
+    // (per device: a process may drive partitioned or different devices)
+    static std::mutex mu;
+    static std::vector<std::pair<int, unsigned>> caps;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1u;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const auto& c : caps)
+        if (c.first == dev) return c.second;
+    unsigned cap = 1u;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)smc_select_kernel, kSelBlock, 0) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
         const long c = (long)per_cu * cus;
-        return c < 1 ? 1u : (unsigned)c;
-    }();
+        cap = c < 1 ? 1u : (unsigned)c;
+    }
+    caps.emplace_back(dev, cap);
     return cap;
 }
-static hipError_t launch_select(const SmcSelectArgs& sa, unsigned G, hipStream_t s) {
+// set while a run is repeated with cooperative launches after an ordinary launch of the select kernel
+// did not become co-resident in time (several large runs or another tenant holding the CUs)
+static thread_local bool tl_smc_force_coop = false;
+static bool select_cooperative() {
     const char* e = std::getenv("KABC_SMC_COOPERATIVE");  // (read per launch: a test switches it)
-    const bool coop = e && e[0] == '1';
+    return tl_smc_force_coop || (e && e[0] == '1');
+}
+static hipError_t launch_select(const SmcSelectArgs& sa, unsigned G, hipStream_t s) {
+    SmcSelectArgs a = sa;
+    const bool coop = select_cooperative();
+    // 100 MHz ticks: 0.2 s (then the run is repeated cooperatively) / 5 s; KABC_SMC_BARRIER_TIMEOUT_MS (tests)
+    a.barrier_timeout = coop ? 500000000ull : 20000000ull;
+    if (const char* e = coop ? nullptr : std::getenv("KABC_SMC_BARRIER_TIMEOUT_MS")) {  // (the ordinary launch's)
+        const double ms = std::atof(e);
+        if (ms > 0) a.barrier_timeout = (unsigned long long)(ms * 1e5);
+    }
     if (G <= 1u || !coop) {
-        hipLaunchKernelGGL(smc_select_kernel, dim3(G), dim3(kSelBlock), 0, s, sa);
+        hipLaunchKernelGGL(smc_select_kernel, dim3(G), dim3(kSelBlock), 0, s, a);
         return hipGetLastError();
     }
-    SmcSelectArgs a = sa;
     void* args[] = {&a};
     return hipLaunchCooperativeKernel((void*)smc_select_kernel, dim3(G), dim3(kSelBlock), args, 0, s);
-}
-
-// set while a run is repeated with the one-kernel select after the barrier-free kernels gave up
-// (a candidate bin beyond their list: smc_select2_kernels.hpp)
-static thread_local bool tl_smc_no_sel2 = false;
-
-// From how many particles the selection runs as barrier-free kernels over all CUs
-// (smc_select2_kernels.hpp); below, the one-kernel select on at most 16 workgroups (co-resident
-// on any device that runs this library at all).  KABC_SMC_SELECT2_FROM overrides (0 = never).
-static int64_t select2_from() {
-    if (const char* e = std::getenv("KABC_SMC_SELECT2_FROM")) {
-        const long long v = std::atoll(e);
-        return v <= 0 ? INT64_MAX : (int64_t)v;
-    }
-    return (int64_t)1 << 17;
-}
-static bool use_select2(int64_t N, bool sharded) {
-    return !sharded && !tl_smc_no_sel2 && N >= select2_from() && N >= 2 * kSel2Block;
-}
-static unsigned select2_blocks(int64_t N) {
-    const int64_t ntile = (N + kSel2Block - 1) / kSel2Block;
-    int64_t g = ntile < 512 ? ntile : 512;  // two workgroups of 1024 per CU
-    if (const char* e = std::getenv("KABC_SMC_SELECT2_BLOCKS")) {
-        const long v = std::atol(e);
-        if (v >= 1) g = v < ntile ? v : ntile;
-    }
-    if (g > kSel2MaxG) g = kSel2MaxG;
-    return (unsigned)(g < 1 ? 1 : g);
-}
-// the phases of one selection, back to back on the stream (ordinary launches, no barrier inside)
-static hipError_t launch_select2(const SmcSelectArgs& sa, SmcSel2Scratch* g2, hipStream_t s) {
-    SmcSel2Args a;
-    a.s = sa;
-    a.g = g2;
-    const unsigned G = select2_blocks(sa.N);
-    if (!sa.part) hipLaunchKernelGGL(sel2_partials_kernel, dim3(G), dim3(kSel2Block), 0, s, a);
-    hipLaunchKernelGGL(sel2_stats_kernel, dim3(1), dim3(kSel2Block), 0, s, a, G);
-    hipLaunchKernelGGL(sel2_hist_kernel, dim3(G), dim3(kSel2Block), 0, s, a);
-    hipLaunchKernelGGL(sel2_collect_kernel, dim3(G), dim3(kSel2Block), 0, s, a);
-    hipLaunchKernelGGL(sel2_finish_kernel, dim3(G), dim3(kSel2Block), 0, s, a);
-    return hipGetLastError();
 }
 }  // namespace kabc
 
@@ -628,12 +605,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         KABC_HIP_CHECK(bufs.alloc(&sa.stamps, 8));
         KABC_HIP_CHECK(hipMemsetAsync(sa.stamps, 0, 64, s));
     }
-    // large ensembles: the selection as barrier-free kernels over all CUs (smc_select2_kernels.hpp)
-    SmcSel2Scratch* sel2 = nullptr;
-    if (use_select2(N, comm != nullptr)) KABC_HIP_CHECK(bufs.alloc(&sel2, 1));
-    auto do_select = [&](hipStream_t st) -> hipError_t {
-        return sel2 ? launch_select2(sa, sel2, st) : launch_select(sa, selG, st);
-    };
+    auto do_select = [&](hipStream_t st) -> hipError_t { return launch_select(sa, selG, st); };
     SmcMcmcArgs ma;
     std::memset(&ma, 0, sizeof ma);
     for (int b = 0; b < 2; ++b) {
@@ -943,12 +915,8 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
             set_error("quantiles are undefined in presence of NaNs");
             rc = KABC_ERR_NAN_COST;
         } else if (hc.error == 3) {
-            set_error("smc: a device-wide barrier timed out after 5 s (the grid did not become "
-                      "resident -- another tenant holds the CUs; KABC_SMC_COOPERATIVE=1 launches the "
-                      "select kernel cooperatively -- or the device is wedged)");
+            set_error("smc: a device-wide barrier of a cooperative launch timed out after 5 s (the device is wedged)");
             rc = KABC_ERR_DEVICE;
-        } else if (hc.error == 5) {
-            rc = KABC_ERR_UNSUPPORTED;  // (the barrier-free select gave up: repeated below)
         } else if (hc.error == 4) {
             // more particles share one histogram bin of the costs than the loop kernel's candidate
             // list holds (heavy ties): a limit of that kernel, not of the problem.  The run is
@@ -1004,18 +972,20 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     }
     // (test hook: KABC_SMC_LOOP_GIVE_UP=1 makes every loop-kernel run count as given up)
     if (looped && !tl_smc_no_loop && std::getenv("KABC_SMC_LOOP_GIVE_UP")) hc.error = 4;
+    // (test hook: KABC_SMC_SELECT_TIME_OUT=1 makes the first, ordinary-launch run count as timed out)
+    if (!looped && !select_cooperative() && hc.error == 0 && std::getenv("KABC_SMC_SELECT_TIME_OUT")) hc.error = 3;
+    if (hc.error == 3 && !looped && !select_cooperative()) {
+        // an ordinary launch of the select grid did not become co-resident within 0.2 s: the same run
+        // with cooperative launches (co-residency asserted by the runtime; ~21 us per launch dearer)
+        tl_smc_force_coop = true;
+        const kabc_status_t st2 = smc_run_impl(ctx, comm, prior, D, cost, o, res);
+        tl_smc_force_coop = false;
+        return st2;
+    }
     if (hc.error == 4 && looped && !tl_smc_no_loop) {
         tl_smc_no_loop = true;
         const kabc_status_t st2 = kabc_smc_run(ctx, prior, D, cost, o, res);
         tl_smc_no_loop = false;
-        return st2;
-    }
-    // (test hook: KABC_SMC_SELECT2_GIVE_UP=1 makes every run on the barrier-free select count as given up)
-    if (sel2 && !tl_smc_no_sel2 && hc.error == 0 && std::getenv("KABC_SMC_SELECT2_GIVE_UP")) hc.error = 5;
-    if (hc.error == 5 && sel2 && !tl_smc_no_sel2) {
-        tl_smc_no_sel2 = true;
-        const kabc_status_t st2 = kabc_smc_run(ctx, prior, D, cost, o, res);
-        tl_smc_no_sel2 = false;
         return st2;
     }
     if (sa.stamps) {
@@ -1251,18 +1221,7 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     KABC_HIP_CHECK(bufs.alloc(&sa.scratch, 1));
     KABC_HIP_CHECK(hipMemsetAsync(sa.scratch, 0, sizeof(SmcSelScratch), s));
     const unsigned selG = select_blocks(N);
-    // large ensembles: the selection as barrier-free kernels over all CUs (smc_select2_kernels.hpp)
-    SmcSel2Scratch* sel2 = nullptr;
-    if (use_select2(N, false)) KABC_HIP_CHECK(bufs.alloc(&sel2, 1));
-    auto do_select = [&](hipStream_t st) -> hipError_t {
-        return sel2 ? launch_select2(sa, sel2, st) : launch_select(sa, selG, st);
-    };
-    auto retry_without_sel2 = [&]() -> kabc_status_t {  // (a candidate bin beyond the list: the same run on the one-kernel select)
-        tl_smc_no_sel2 = true;
-        const kabc_status_t st2 = kabc_pfilter_run(ctx, prior, D, cost, o, res);
-        tl_smc_no_sel2 = false;
-        return st2;
-    };
+    auto do_select = [&](hipStream_t st) -> hipError_t { return launch_select(sa, selG, st); };
     PfArgs pa;
     std::memset(&pa, 0, sizeof pa);
     pa.theta = th;
@@ -1310,11 +1269,15 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         KABC_HIP_CHECK(hipGetLastError());
         KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));
         KABC_HIP_CHECK(hipStreamSynchronize(s));
-        if (hp.error == 5 && sel2) return retry_without_sel2();
+        if (!select_cooperative() && hp.error == 0 && std::getenv("KABC_SMC_SELECT_TIME_OUT")) hp.error = 3;  // (test hook)
         if (hp.error == 3) {
-            set_error("pfilter: a device-wide barrier timed out after 5 s (the select grid did not "
-                      "become resident -- KABC_SMC_COOPERATIVE=1 launches it cooperatively -- or "
-                      "the device is wedged)");
+            if (!select_cooperative()) {  // an ordinary launch that did not become co-resident in time: the same run, cooperatively
+                tl_smc_force_coop = true;
+                const kabc_status_t st2 = kabc_pfilter_run(ctx, prior, D, cost, o, res);
+                tl_smc_force_coop = false;
+                return st2;
+            }
+            set_error("pfilter: a device-wide barrier of a cooperative launch timed out after 5 s (the device is wedged)");
             return KABC_ERR_DEVICE;
         }
         if (hp.error == 9) {
@@ -1352,11 +1315,14 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
             KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipMemcpyAsync(&hsel, sel, sizeof hsel, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipStreamSynchronize(s));
-            if (hsel.error == 5 && sel2) return retry_without_sel2();
             if (hsel.error == 3) {
-                set_error("pfilter: a device-wide barrier timed out after 5 s (the select grid did not "
-                          "become resident -- KABC_SMC_COOPERATIVE=1 launches it cooperatively -- or "
-                          "the device is wedged)");
+                if (!select_cooperative()) {  // an ordinary launch that did not become co-resident in time: the same run, cooperatively
+                    tl_smc_force_coop = true;
+                    const kabc_status_t st2 = kabc_pfilter_run(ctx, prior, D, cost, o, res);
+                    tl_smc_force_coop = false;
+                    return st2;
+                }
+                set_error("pfilter: a device-wide barrier of a cooperative launch timed out after 5 s (the device is wedged)");
                 return KABC_ERR_DEVICE;
             }
             if (hsel.error) {

@@ -102,8 +102,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_dyn_mcmc_kernel(const SmcDynArg
         double lpi = A.lpi[cur][si];
         double* dst = A.theta[1 - cur] + i * D;
         bool accepted = false;
-        alive_i = A.ctrl->resampled != 0 || A.alive[i] != 0;  // (smc_kernels.hpp smc_mcmc_kernel)
-        if (A.ctrl->resampled != 0) A.alive[i] = 1;
+        alive_i = A.alive[i] != 0;
         if (alive_i) {
             const uint64_t N = (uint64_t)A.N;
             const uint32_t w = (uint32_t)i;

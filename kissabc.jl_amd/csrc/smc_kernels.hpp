@@ -109,6 +109,10 @@ struct SmcSelectArgs {
     const unsigned long long* part;
     int64_t npart;
     SmcSelScratch* scratch;  // used when the kernel runs with more than one workgroup
+    // how long a workgroup waits at a device-wide barrier before the kernel gives up (ticks of
+    // s_memrealtime, 100 MHz): 0.2 s for the ordinary launch (capi_smc.hip launch_select: the run is
+    // then repeated with a cooperative launch, whose co-residency the runtime asserts), 5 s for that one
+    unsigned long long barrier_timeout;
 };
 
 struct SmcMcmcArgs {
@@ -270,11 +274,13 @@ __device__ __forceinline__ void for_each_alive(const uint8_t* __restrict__ alive
 // them are resident).  Sense-reversing: one atomic per workgroup, thread 0 spins on the
 // generation word; 2.4 us at 32 x 1024 threads, about a kernel boundary (cooperative
 // groups' grid.sync() is 5.1 us; tools/gridsync_probe.hip).  G == 1: __syncthreads.
-// Residency: launch_select (capi_smc.hip) launches a grid that fits the device (G clamped to
-// occupancy x CUs) on an in-order stream, or cooperatively under KABC_SMC_COOPERATIVE=1.  The spin
-// is bounded either way (5 s of s_memrealtime): on time-out the abort word is set, every workgroup
-// leaves the kernel, and kabc_smc_run / kabc_pfilter_run return KABC_ERR_DEVICE instead of hanging.
-__device__ __forceinline__ bool sel_grid_barrier(SmcSelScratch* g, unsigned G) {
+// Residency: launch_select (capi_smc.hip) launches a grid that fits the device (G clamped to a
+// quarter of occupancy x CUs) on an in-order stream, or cooperatively (KABC_SMC_COOPERATIVE=1, and
+// whenever an ordinary launch has timed out).  The spin is bounded either way (A.barrier_timeout):
+// on time-out the abort word is set and every workgroup leaves the kernel; after an ordinary launch
+// kabc_smc_run / kabc_pfilter_run repeat the run with cooperative launches -- the same run, every
+// draw is counter-based -- and only a cooperative launch that times out is KABC_ERR_DEVICE.
+__device__ __forceinline__ bool sel_grid_barrier(SmcSelScratch* g, unsigned G, unsigned long long timeout) {
     __shared__ int s_ok;
     // every wavefront's own stores are in the L2 before thread 0 releases for the workgroup
     // (__syncthreads() waits for LDS / scalar traffic only; smc_loop_kernel.hpp loop_sync_stores_done)
@@ -297,7 +303,7 @@ __device__ __forceinline__ bool sel_grid_barrier(SmcSelScratch* g, unsigned G) {
                 while (*gen == my) {
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 1023u) == 0u &&
-                        (*ab || __builtin_amdgcn_s_memrealtime() - t0 > 500000000ull)) {  // 5 s @ 100 MHz
+                        (*ab || __builtin_amdgcn_s_memrealtime() - t0 > timeout)) {
                         atomicExch(&g->bar_abort, 1u);
                         ok = 0;
                         break;
@@ -315,7 +321,7 @@ __device__ __forceinline__ bool sel_grid_barrier(SmcSelScratch* g, unsigned G) {
 }
 // every use: a timed-out barrier ends the kernel (uniformly: all workgroups see the abort word)
 #define KABC_SEL_BARRIER(g, G)                                   \
-    if (!sel_grid_barrier(g, G)) {                               \
+    if (!sel_grid_barrier(g, G, A.barrier_timeout)) {            \
         if (blockIdx.x == 0 && threadIdx.x == 0) {               \
             A.ctrl->error = 3;                                   \
             A.ctrl->done = 1;                                    \
@@ -815,10 +821,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
         load_row<D>(theta_src + si * D, th);
         double Xi = X_src[si];
         double lpi = lpi_src[si];
-        // (after a resample every particle is alive, src/smc.jl:152; the barrier-free select
-        // (smc_select2_kernels.hpp) leaves writing that to this kernel)
-        alive_i = A.ctrl->resampled != 0 || A.alive[i] != 0;
-        if (A.ctrl->resampled != 0) const_cast<uint8_t*>(A.alive)[i] = 1;
+        alive_i = A.alive[i] != 0;
         if (alive_i) {
             const uint64_t N = (uint64_t)A.N;
             const uint32_t w = (uint32_t)i;

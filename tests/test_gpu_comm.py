@@ -294,3 +294,28 @@ def test_smc_sharded_cost_loop_matches_single_gpu_and_oracle(k, orc, gpu_ctx, wo
         assert out[r].info["proposals"] == single.info["proposals"]
     for c in comms:
         c.close()
+
+
+def test_bench_world_n_line_rehearsed_on_one_gpu(gpu_ctx):
+    """bench.py's world-N line (the one `python bench.py --gpus N` relays from rank 0 on a multi-GPU
+    node) rehearsed with N emulated ranks on ONE device through the P2P communicator
+    (KABC_BENCH_EMULATE_RANKS): it carries n_gpus, the exchange diagnostics, and a value whose
+    proposals equal walkers x sub-steps."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["KABC_BENCH_EMULATE_RANKS"] = "4"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "5", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-alt", "--no-smc", "--min-seconds", "0.05",
+                        "--headline-seconds", "0.2"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 4 and d["config"]["emulated_ranks"] == 4 and d["scaling"] == "weak"
+    assert d["config"]["walkers_total"] == 4 * 65536
+    h = d["by_ntransitions"][str(d["config"]["ntransitions"])]
+    x = h["exchange"]
+    assert x["chunks"] >= 1 and x["compute_us_per_half"] > 0 and x["exchange_us_per_half"] > 0
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0

@@ -273,3 +273,30 @@ def test_general_priors_beyond_eight_parameters(k, orc, gpu_ctx, monkeypatch, pa
     assert got.info["log"] == ref["log"] and got.eps == ref["eps"]
     assert np.array_equal(got.info["theta_all"], ref["theta_all"])
     assert np.array_equal(got.info["alive"], ref["alive"]) and np.array_equal(got.C, ref["C"])
+
+
+def test_select_launch_that_times_out_is_repeated_cooperatively(k, orc, gpu_ctx, monkeypatch):
+    """The select kernel's device-wide barriers need its workgroups co-resident.  It is launched as an
+    ordinary grid a quarter of the device's capacity at most; if that grid does not become resident
+    within 0.2 s (several large runs, another tenant holding the CUs) the kernel gives up and the SAME
+    run -- every draw is counter-based -- is repeated with cooperative launches, whose co-residency
+    the runtime asserts.  Forced here two ways: the test hook, and a barrier time-out of 10 ns that
+    a real 32-workgroup grid cannot meet."""
+    monkeypatch.setenv("KABC_SMC_LOOP", "0")
+    N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    cost = k.costs.GaussDist([1.0, -0.5])
+    kw = dict(nparticles=140000, alpha=0.9, epstol=0.2, seed=3)
+    ref = k.smc(N2, cost, return_array=True, **kw)
+    ro = orc.smc(N2, cost, **kw)
+    assert ref.eps == ro["eps"] and np.array_equal(ref.info["theta_all"], ro["theta_all"])
+    for env in ({"KABC_SMC_SELECT_TIME_OUT": "1"}, {"KABC_SMC_BARRIER_TIMEOUT_MS": "0.0001"}):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        r = k.smc(N2, cost, return_array=True, **kw)
+        assert r.eps == ref.eps and r.info["iterations"] == ref.info["iterations"]
+        assert np.array_equal(r.info["theta_all"], ref.info["theta_all"]) and np.array_equal(r.C, ref.C)
+        gp = k.pfilter(N2, cost, 140000, seed=4, return_array=True, max_iters=4)
+        for kk in env:
+            monkeypatch.delenv(kk)
+        gp0 = k.pfilter(N2, cost, 140000, seed=4, return_array=True, max_iters=4)
+        assert np.array_equal(gp.P, gp0.P) and np.array_equal(gp.C, gp0.C)
