@@ -277,7 +277,7 @@ kabc_status_t kabc_prefetch_model(const kabc_model_t* model, int32_t families);
 /* process-wide counters of the above: out[0] compilations handed to the worker, out[1] code
  * objects it delivered that were loaded, out[2] failures, out[3] units found in the cache at
  * first sight */
-void kabc_spec_counters(uint64_t out[4]);
+kabc_status_t kabc_spec_counters(uint64_t out[4]);
 /* entry point of the worker process (csrc/rtc_worker.c); not for callers */
 int32_t kabc_rtc_worker_main(const char* jobfile);
 

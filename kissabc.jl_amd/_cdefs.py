@@ -130,7 +130,7 @@ PROTOTYPES = {
     "kabc_compile_model": (C.c_int, [C.POINTER(Model), C.c_int32, C.POINTER(C.c_int32)]),
     "kabc_model_release": (C.c_int, [C.c_int32]),
     "kabc_prefetch_model": (C.c_int, [C.POINTER(Model), C.c_int32]),
-    "kabc_spec_counters": (None, [C.POINTER(C.c_uint64)]),
+    "kabc_spec_counters": (C.c_int, [C.POINTER(C.c_uint64)]),
     "kabc_rtc_worker_main": (C.c_int32, [C.c_char_p]),
     "kabc_ais_spec_state": (C.c_int, [VP, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "kabc_ais_create": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_uint64, C.POINTER(VP)]),

@@ -1196,12 +1196,31 @@ kabc_status_t kabc_ais_advance_multi(kabc_ais_t** hs, int32_t n, int64_t ngenera
     for (int64_t g = 0; g < ngenerations; ++g) {
         for (int hf = 0; hf < 2; ++hf) {
             if (xk == 1) {
+                // exchange diagnostics (kabc_ais_exchange_us), as kabc_ais_advance records them: every
+                // shard's kernels between e0 and e1 on its stream, the gather between e1 and e2
+                kabc_ais::XT* xts[KABC_COMM_MAX_WORLD];
                 for (int i = 0; i < n; ++i) {
-                    KABC_HIP_CHECK(hipSetDevice(hs[i]->ctx->device));
-                    if (kabc_status_t st = kabc_ais_half_generation(hs[i], hf, ntransitions, nullptr))
+                    kabc_ais_t* h = hs[i];
+                    KABC_HIP_CHECK(hipSetDevice(h->ctx->device));
+                    xts[i] = (h->timing && h->xt_used < h->xt.size()) ? &h->xt[h->xt_used] : nullptr;
+                    if (xts[i]) KABC_HIP_CHECK(hipEventRecord(xts[i]->e0, h->ctx->stream));
+                    if (kabc_status_t st = kabc_ais_half_generation(h, hf, ntransitions, nullptr))
                         return st;
+                    if (xts[i]) {
+                        if (kabc_status_t stc = timing_close_pair(h)) return stc;
+                        KABC_HIP_CHECK(hipEventRecord(xts[i]->e1, h->ctx->stream));
+                        KABC_HIP_CHECK(hipEventRecord(xts[i]->x0[0], h->ctx->stream));
+                    }
                 }
                 if (kabc_status_t st = gather_multi(hs, n, hf, 0)) return st;
+                for (int i = 0; i < n; ++i) {
+                    if (!xts[i]) continue;
+                    KABC_HIP_CHECK(hipSetDevice(hs[i]->ctx->device));
+                    KABC_HIP_CHECK(hipEventRecord(xts[i]->x1[0], hs[i]->ctx->stream));
+                    KABC_HIP_CHECK(hipEventRecord(xts[i]->e2, hs[i]->ctx->stream));
+                    xts[i]->closed = true;
+                    ++hs[i]->xt_used;
+                }
                 continue;
             }
             if (kabc_status_t st = comm_exchange_fence_multi(comms, n, false)) return st;

@@ -1372,12 +1372,16 @@ extern "C" kabc_status_t kabc_model_release(int32_t handle) {
     return KABC_ERR_INVALID_ARG;
 }
 
-extern "C" void kabc_spec_counters(uint64_t out[4]) {
-    if (!out) return;
+extern "C" kabc_status_t kabc_spec_counters(uint64_t out[4]) {
+    if (!out) {
+        set_error("kabc_spec_counters: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
     out[0] = g_spec_counters.spawned.load();
     out[1] = g_spec_counters.loaded.load();
     out[2] = g_spec_counters.failed.load();
     out[3] = g_spec_counters.cache_hits.load();
+    return KABC_OK;
 }
 
 // The worker process's whole job (csrc/rtc_worker.c calls this after it has detached): read the

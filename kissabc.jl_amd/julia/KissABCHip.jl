@@ -677,8 +677,26 @@ function compile_model(prior::Distribution, cost::DeviceCost; families::Integer 
     h[]
 end
 release_model(h::Integer) = check(ccall((:kabc_model_release, libkabc), Cint, (Int32,), Int32(h)))
+"""
+    prefetch_model(model; families = 0)
+The library specialises an eligible model ON ITS OWN without ever waiting for the compiler (a
+detached worker process; include/kabc.h "THE DEFAULT" -- what Julia's per-type compilation of
+`logpdf(::Factored)` gives the reference, src/priors.jl:11,30-36).  This starts that compilation
+ahead of the first `sample` / `smc`; it returns at once.
+"""
+function prefetch_model(model::DeviceModel; families::Integer = 0)
+    with_model(model) do cm
+        check(ccall((:kabc_prefetch_model, libkabc), Cint, (Ref{KabcModel}, Int32), cm, Int32(families)))
+    end
+end
+"(started, loaded, failed, cache_hits): process-wide counters of the background specialisations"
+function spec_counters()
+    out = zeros(UInt64, 4)
+    check(ccall((:kabc_spec_counters, libkabc), Cint, (Ptr{UInt64},), out))
+    (started = out[1], loaded = out[2], failed = out[3], cache_hits = out[4])
+end
 
-export DeviceCost, UserCost, UserPrior, compile_model, release_model, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
+export DeviceCost, UserCost, UserPrior, compile_model, release_model, prefetch_model, spec_counters, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
        AbsDiff, NormShell, NoisyQuadDU, Mixture, NoisyBanana, WienerRms, sample_sharded, unique_id,
        comm_init_rank
 end # module
