@@ -380,13 +380,18 @@ __device__ __forceinline__ void wave_lds_fence() {
 #else
 #define KABL 0
 #endif
-template <int D>
+struct NoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `mid()` runs as soon as the partner rows of the sub-step (mva, bb, cc) are in the record: the
+// prologue passes a workgroup barrier there, behind which the consumer requests its first rows.
+template <int D, class Mid = NoMid>
 __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t seed,
                                                 ChunkRec<D>& R, int si,
                                                 uint64_t t, uint32_t w_base, int n_active,
                                                 uint8_t* listB, int lane,
                                                 const double* logtab,
-                                                const kabc_u128_t* pre01 = nullptr) {
+                                                const kabc_u128_t* pre01 = nullptr, Mid mid = Mid()) {
     constexpr int NB = RecGeom<D>::NB;
     const uint64_t nc = (uint64_t)A.n_comp;
     const bool active = lane < n_active;
@@ -428,6 +433,7 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t
         R.cc[si][lane] = move >= 2 ? c : a;
     }
     R.mva[si][lane] = ((uint32_t)move << 30) | a;
+    mid();
     // -- compaction of the move-dependent extra work (wave ballot + mbcnt)
     const unsigned long long mDE = __ballot(move == 2), mWK = __ballot(move == 3);
     const unsigned long long mB = mDE | mWK;
@@ -572,6 +578,7 @@ ais_half_kernel(const AisArgs A0) {
     }
     __shared__ ChunkRec<D> rec[2];
     __shared__ uint8_t listB[kChunk][kBatch];
+
     // prepared prior components: read by the consumer with wave-uniform LDS
     // addresses (broadcast).  By-value kernel arguments made hipcc pin ~250 SGPRs
     // and spill them to VGPR lanes (385 v_readlane per transition).
@@ -735,18 +742,42 @@ ais_half_kernel(const AisArgs A0) {
     // registers this kernel is short of (reloaded from spill lanes in every sub-step).
     uint64_t seed_v = A.seed;
     asm volatile("" : "+v"(seed_v));
+    // The consumer's partner rows: (r0a, r0b) serve a chunk's first sub-step, (r1a, r1b) are the
+    // second register set of the sub-step pipeline (see the consumer).  The rows of
+    // chunk 0's first sub-step are in flight already when the chunk loop starts -- requested in the prologue as soon as the
+    // producers have drawn the partners (a third of the way through their fill: the request's L2
+    // round trip hides under the rest of it; 8.03 -> 7.79 us per launch at ntransitions = 1, nothing
+    // at 16 and 100: profiles/r05_ab_prologue_prefetch.txt).  The same across every chunk boundary
+    // (the previous chunk's last sub-step requesting the next chunk's first rows once wave 1 has
+    // drawn them) was measured too and COSTS 1.6 % at 100: in steady state the SIMD's other waves
+    // fill that round trip, and the flag test + register-set copy are consumer instructions.
+    // The rows come from the frozen half: WHEN they are read cannot matter.
+    constexpr bool kLate = D > kLateFrom;
+    double r0a[D], r0b[D], r1a[kLate ? 1 : D], r1b[kLate ? 1 : D];
+    // (wave-uniform and, outside the probes build, a compile-time constant)
+    const bool pro_rows = !(KABL & 5);
     // prologue: producers fill chunk 0
     if (wave > 0) {
         const int si = wave - 1;
         if (si < A.nt && !(KABL & 4)) {
             produce_substep<D>(A, seed_v, rec[0], si, A.t0 + (uint64_t)si, w_base, n_active, listB[si],
-                               lane, slogtab, pro01);
+                               lane, slogtab, pro01, [] { __syncthreads(); });
             if constexpr (kAuxW > 0)
                 prepare_cost_aux<COST, kAuxW>(A, A.t0 + (uint64_t)si, w_base, lane, saux[0][si],
                                               slogtab, r0, n_active);
             if constexpr (kPre > 0)
                 produce_cost_normals<kPre>(seed_v, A.t0 + (uint64_t)si, w_base, lane, spre[0][si], slogtab);
+        } else {
+            __syncthreads();
         }
+    } else {
+        __syncthreads();  // (the partner rows of every sub-step of chunk 0 are in the record)
+#ifndef KABC_NO_XCHUNK_PREFETCH  // (A/B builds: tools/ab_ais_variant.sh)
+        if (active && pro_rows) {
+            load_row<D>(comp_row(rec[0].mva[0][lane] & 0x3fffffffu), r0a);
+            load_row<D>(comp_row(rec[0].bb[0][lane]), r0b);
+        }
+#endif
     }
     KABC_TIMED_BARRIER();
 
@@ -803,10 +834,13 @@ ais_half_kernel(const AisArgs A0) {
                 // whatever its move (bb defaults to a): no divergence around the loads.
                 // The sub-step body is instantiated twice with the two register sets
                 // swapped, so no row is ever copied.
-                constexpr bool kLate = D > kLateFrom;
-                double r0a[D], r0b[D], r1a[kLate ? 1 : D], r1b[kLate ? 1 : D];
-                load_row<D>(comp_row(R.mva[0][lane] & 0x3fffffffu), r0a);
-                load_row<D>(comp_row(R.bb[0][lane]), r0b);
+#ifndef KABC_NO_XCHUNK_PREFETCH
+                if (c > 0 || !pro_rows)  // (scalar; chunk 0's were requested in the prologue)
+#endif
+                {
+                    load_row<D>(comp_row(R.mva[0][lane] & 0x3fffffffu), r0a);
+                    load_row<D>(comp_row(R.bb[0][lane]), r0b);
+                }
                 // `si` is a compile-time constant (SubStepIx<q>): every LDS address of the
                 // sub-step is then (scalar buffer base + lane) + an immediate offset, not a
                 // handful of VALU shifts and adds on the consumer's issue stream per sub-step.
@@ -819,7 +853,7 @@ ais_half_kernel(const AisArgs A0) {
                     constexpr int sq = si + 1 < kChunk ? si + 1 : si;
                     const uint32_t mva = R.mva[si][lane];
                     uint32_t mvan = R.mva[sq][lane], bn = R.bb[sq][lane];
-                    if (sq >= ns) {  // (scalar) the chunk's last sub-step: no next one in it
+                    if (si + 1 >= ns) {  // (scalar) the chunk's last sub-step: no next one in it
                         mvan = mva;
                         bn = R.bb[si][lane];
                     }

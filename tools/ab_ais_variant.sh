@@ -4,7 +4,7 @@
 # tests on the experimental build.
 V=$1; R=${2:-3}
 run() {
-  python bench.py --no-cpu-baseline --no-smc --min-seconds 0.5 2>/dev/null | python -c "
+  python bench.py --no-cpu-baseline --no-smc --no-cold-spec --min-seconds 0.5 --headline-seconds 1.5 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print({nt:(round(v['kernel_avg_us'],2), round(v['value']/1e9,2)) for nt,v in d['by_ntransitions'].items()})"
