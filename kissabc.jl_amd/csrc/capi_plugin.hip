@@ -363,9 +363,50 @@ static bool cache_load(const std::string& path, size_t nnames, std::vector<char>
     return ok;
 }
 
+// The cache directory is bounded (KABC_RTC_CACHE_MB, default 512): before a code object is stored
+// the oldest ones go until it fits -- a service that sees thousands of distinct models (every
+// distinct prior tuple is a unit of its own) must not fill the disk.  Leftovers of workers that died
+// (lock / job files older than ten minutes) go on the same occasion.
+static void cache_trim(const std::string& dir, size_t incoming) {
+    double cap_mb = 512.0;
+    if (const char* e = std::getenv("KABC_RTC_CACHE_MB")) cap_mb = std::atof(e);
+    if (!(cap_mb > 0.0)) return;
+    const double cap = cap_mb * 1048576.0;
+    struct Ent { std::string path; time_t mtime; double size; };
+    std::vector<Ent> co;
+    double total = (double)incoming;
+    const time_t now = time(nullptr);
+    if (DIR* d = opendir(dir.c_str())) {
+        while (const dirent* e = readdir(d)) {
+            const std::string n = e->d_name;
+            if (n.size() < 6 || n.compare(0, 5, "kabc_") != 0) continue;
+            const std::string p = dir + "/" + n;
+            struct stat st;
+            if (stat(p.c_str(), &st) != 0) continue;
+            const bool is_co = n.size() > 3 && n.compare(n.size() - 3, 3, ".co") == 0;
+            if (is_co) {
+                co.push_back({p, st.st_mtime, (double)st.st_size});
+                total += (double)st.st_size;
+            } else if (now - st.st_mtime > 600 &&
+                       (n.find(".lock") != std::string::npos || n.find(".job") != std::string::npos ||
+                        n.find(".tmp") != std::string::npos)) {
+                (void)unlink(p.c_str());
+            }
+        }
+        closedir(d);
+    }
+    if (total <= cap) return;
+    std::sort(co.begin(), co.end(), [](const Ent& a, const Ent& b) { return a.mtime < b.mtime; });
+    for (const Ent& e : co) {
+        if (total <= cap) break;
+        if (unlink(e.path.c_str()) == 0) total -= e.size;
+    }
+}
+
 static void cache_store(const std::string& dir, const std::string& path, const std::vector<char>& code,
                         const std::vector<std::string>& lowered) {
     (void)mkdir(dir.c_str(), 0777);
+    cache_trim(dir, code.size());
     const std::string tmp = path + "." + std::to_string((long long)getpid()) + ".tmp";
     FILE* f = std::fopen(tmp.c_str(), "wb");
     if (!f) return;  // (a read-only install: compile every time)

@@ -233,3 +233,25 @@ def test_abcde_and_pfilter_default_path(k, orc, gpu_ctx, monkeypatch, tmp_path):
             assert _wait_for(lambda: len([n for n in os.listdir(tmp_path) if n.endswith(".co")]) >= 2
                              and not any(n.endswith((".lock", ".job")) for n in os.listdir(tmp_path)), timeout=400)
     assert _counters(k)["loaded"] >= c0["loaded"] + 2
+
+
+def test_cache_directory_is_bounded(k, monkeypatch, tmp_path):
+    """KABC_RTC_CACHE_MB: the oldest code objects go before a new one is stored; leftovers of
+    workers that died (old lock / job files) go on the same occasion."""
+    _fresh_cache(monkeypatch, tmp_path)
+    old = tmp_path / "kabc_0000000000000000ffffffffffffffff.co"
+    old.write_bytes(b"x" * (600 * 1024))
+    stale = tmp_path / "kabc_1111111111111111ffffffffffffffff.co.lock"
+    stale.write_bytes(b"")
+    past = time.time() - 3600
+    os.utime(old, (past, past))
+    os.utime(stale, (past, past))
+    monkeypatch.setenv("KABC_RTC_CACHE_MB", "0.5")
+    lib = k._lib.load()
+    cm = _model(k, 6.5, 7.25).to_c()
+    k._lib.check(lib.kabc_prefetch_model(C.byref(cm), 1))
+    assert _wait_for(lambda: len([n for n in os.listdir(tmp_path) if n.endswith(".co")]) >= 1
+                     and not any(n.endswith(".job") for n in os.listdir(tmp_path)), timeout=240)
+    names = os.listdir(tmp_path)
+    assert old.name not in names and stale.name not in names
+    assert len([n for n in names if n.endswith(".co")]) == 1
