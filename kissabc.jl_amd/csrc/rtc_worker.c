@@ -18,6 +18,13 @@ int main(int argc, char** argv) {
         fprintf(stderr, "usage: %s <libkabc_hip.so> <job file>   (started by libkabc_hip.so itself)\n", argv[0]);
         return 2;
     }
+    /* nothing of the parent's stays open in here (device nodes, sockets, its files): a compiler
+     * that runs for seconds must not keep them alive past the parent's own close() */
+    {
+        long maxfd = sysconf(_SC_OPEN_MAX);
+        if (maxfd < 0 || maxfd > 65536) maxfd = 65536;
+        for (int fd = 3; fd < (int)maxfd; ++fd) (void)close(fd);
+    }
     const pid_t p = fork();
     if (p < 0) return 3;
     if (p > 0) _exit(0);
