@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     if (p > 0) _exit(0);
     (void)setsid();
     signal(SIGHUP, SIG_IGN);
-    (void)nice(5); /* the sampler's host thread goes first */
+    if (nice(5) == -1) { /* (the sampler's host thread goes first; not being allowed to is fine) */ }
     void* dl = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
     if (!dl) return 4;
     int32_t (*run)(const char*) = (int32_t(*)(const char*))dlsym(dl, "kabc_rtc_worker_main");
