@@ -98,6 +98,7 @@ class Context:
 
     def close(self):
         if self._h and self._owned:
+            release_pinned_cache()   # (page-locked result blocks kept for reuse go with the context)
             load().kabc_ctx_destroy(self._h)
         self._h = C.c_void_p()
 
@@ -126,7 +127,20 @@ _pinned_lock = threading.RLock()   # (re-entrant: a GC pass inside the locked re
 
 
 def _pinned_cache_cap():
+    """KABC_PINNED_CACHE_MB (default 1024): page-locked bytes kept on the free list"""
     return int(float(os.environ.get("KABC_PINNED_CACHE_MB", "1024")) * (1 << 20))
+
+
+def release_pinned_cache():
+    """Hand every cached page-locked block back to the driver (also done when a Context closes)."""
+    global _pinned_free_bytes
+    with _pinned_lock:
+        blocks = [p for lst in _pinned_free.values() for p in lst]
+        _pinned_free.clear()
+        _pinned_free_bytes = 0
+    if _lib is not None:
+        for p in blocks:
+            _lib.kabc_host_free(C.c_void_p(p))
 
 
 class _PinnedBlock:
