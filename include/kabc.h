@@ -540,6 +540,28 @@ kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, in
                                 const kabc_cost_t* cost, const kabc_smc_opts_t* opts,
                                 kabc_smc_result_t* result);
 
+/* The same with the choice of what the ranks share out:
+ *   KABC_SMC_DIST_COST_LOOP  (kabc_smc_run_dist's default) the propose / accept pass only; every rank
+ *                            repeats the epsilon-selection (src/smc.jl:134-153) on the gathered costs.
+ *   KABC_SMC_DIST_PARTICLES  SURVEY §8e "SMC": rank r OWNS the particles of its blocks -- their alive
+ *                            mask lives on that rank only and the selection runs over the rank's own
+ *                            costs: the quantile from all-gathered 1024-bin histograms of the order-
+ *                            preserving keys + an all-gather of the <= 4096 candidate keys, the ESS from
+ *                            all-gathered counts, and -- on a resample only -- an all-gather of the
+ *                            ranks' compacted alive indices (idx = repeat(idxalive, ...), :146-147).
+ *                            Partners are read from the gathered ensemble, as in the other mode.
+ *                            The selection's passes shrink with the world size (the redundant
+ *                            selection is the serial fraction of the other mode: 83 us per iteration
+ *                            at 2 M particles whatever the number of ranks) at the price of four to
+ *                            five small dependent all-gathers per iteration: for large ensembles.
+ * Both modes return kabc_smc_run's result bit for bit, on every rank.  kabc_smc_run_dist reads
+ * KABC_SMC_DIST=particles|cost_loop (every rank must see the same value). */
+#define KABC_SMC_DIST_COST_LOOP 0
+#define KABC_SMC_DIST_PARTICLES 1
+kabc_status_t kabc_smc_run_dist_mode(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
+                                     const kabc_cost_t* cost, const kabc_smc_opts_t* opts, int32_t mode,
+                                     kabc_smc_result_t* result);
+
 /* ---- ABCDE(prior, cost, ϵ_target; kwargs...) -- src/smc.jl:347-430 -----------
  * ABC differential evolution (exported, undocumented and untested in the reference:
  * parity is oracle-vs-device only).  Generation-synchronous and double-buffered in

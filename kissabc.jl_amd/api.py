@@ -389,12 +389,15 @@ class SmcResult(collections.namedtuple("SmcResult", ["P", "C", "eps", "info"])):
 
 def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.015, epstol=0.0,
         r_epstol=None, min_r_ess=None, max_stretch=2.0, verbose=False, parallel=False, seed=0,
-        ctx=None, return_array=False, comm=None):
+        ctx=None, return_array=False, comm=None, shard=None):
     """smc(prior, cost; ...) -- src/smc.jl:92-206, same keywords and defaults.
     `parallel` is accepted and ignored (every particle is a GPU lane).
     `comm` (a comm.Comm): the cost loop is sharded over the communicator's ranks
     (kabc_smc_run_dist -- the reference's `parallel = true` leg across GPUs, for expensive
     simulators); collective, every rank gets the same result, equal to the single-GPU one.
+    `shard` = "particles": the ranks own their particles and the epsilon-selection is sharded too
+    (kabc_smc_run_dist_mode, KABC_SMC_DIST_PARTICLES); "cost_loop": the pass only; None:
+    kabc_smc_run_dist's default (KABC_SMC_DIST).
     Returns (P, C, ϵ) as the reference does (+ an `info` dict)."""
     fac = as_factored(prior)
     scalar = isinstance(prior, UnivariateDistribution)
@@ -428,7 +431,12 @@ def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.01
     r.iter_log = log
     r.iter_log_cap = 4096
     cc = cost.to_c()
-    if comm is not None:
+    if shard not in (None, "cost_loop", "particles"):
+        raise ValueError('shard is None, "cost_loop" or "particles"')
+    if comm is not None and shard is not None:
+        _lib.check(lib.kabc_smc_run_dist_mode(comm.handle, fac.to_c(), D, C.byref(cc), C.byref(o),
+                                              1 if shard == "particles" else 0, C.byref(r)))
+    elif comm is not None:
         _lib.check(lib.kabc_smc_run_dist(comm.handle, fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))
     else:
         _lib.check(lib.kabc_smc_run(ctx.handle, fac.to_c(), D, C.byref(cc), C.byref(o), C.byref(r)))

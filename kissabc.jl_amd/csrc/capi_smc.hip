@@ -12,6 +12,7 @@
 #include "smc_loop_kernel.hpp"
 #include "smc_small_kernel.hpp"
 #include "smc_dyn_kernels.hpp"
+#include "smc_dsel_kernels.hpp"
 #include "abcde_kernels.hpp"
 #include "pfilter_kernels.hpp"
 
@@ -303,6 +304,8 @@ void kabc_smc_default_opts(kabc_smc_opts_t* o) {
 
 // set while a run is repeated on the kernel-per-phase path after the persistent loop kernel gave up
 static thread_local bool tl_smc_no_loop = false;
+// kabc_smc_run_dist_mode: what the ranks of the communicator share out (KABC_SMC_DIST_*)
+static thread_local int tl_smc_dist_mode = 0;
 
 static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc_prior_t* prior,
                                   int32_t D, const kabc_cost_t* cost, const kabc_smc_opts_t* o,
@@ -314,11 +317,15 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
     return smc_run_impl(ctx, nullptr, prior, D, cost, o, res);
 }
 
-kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
-                                const kabc_cost_t* cost, const kabc_smc_opts_t* o,
-                                kabc_smc_result_t* res) {
+kabc_status_t kabc_smc_run_dist_mode(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
+                                     const kabc_cost_t* cost, const kabc_smc_opts_t* o, int32_t mode,
+                                     kabc_smc_result_t* res) {
     if (!comm) {
         set_error("kabc_smc_run_dist: communicator is NULL");
+        return KABC_ERR_INVALID_ARG;
+    }
+    if (mode != KABC_SMC_DIST_COST_LOOP && mode != KABC_SMC_DIST_PARTICLES) {
+        set_error("kabc_smc_run_dist_mode: mode is KABC_SMC_DIST_COST_LOOP or KABC_SMC_DIST_PARTICLES");
         return KABC_ERR_INVALID_ARG;
     }
     if (D > KABC_MAX_DIM) {
@@ -326,7 +333,19 @@ kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, in
                   KABC_MAX_DIM);
         return KABC_ERR_UNSUPPORTED;
     }
-    return smc_run_impl(comm->ctx, comm, prior, D, cost, o, res);
+    tl_smc_dist_mode = mode;
+    const kabc_status_t st = smc_run_impl(comm->ctx, comm, prior, D, cost, o, res);
+    tl_smc_dist_mode = 0;
+    return st;
+}
+
+kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
+                                const kabc_cost_t* cost, const kabc_smc_opts_t* o,
+                                kabc_smc_result_t* res) {
+    // KABC_SMC_DIST=particles: the selection sharded as well (every rank must see the same value)
+    const char* e = std::getenv("KABC_SMC_DIST");
+    const int32_t mode = (e && std::strcmp(e, "particles") == 0) ? KABC_SMC_DIST_PARTICLES : KABC_SMC_DIST_COST_LOOP;
+    return kabc_smc_run_dist_mode(comm, prior, D, cost, o, mode, res);
 }
 
 static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc_prior_t* prior,
@@ -458,7 +477,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         KABC_HIP_CHECK(bufs.alloc(&X[b], Npad));
         KABC_HIP_CHECK(bufs.alloc(&lp[b], Npad));
     }
-    KABC_HIP_CHECK(bufs.alloc(&alive, (size_t)N));
+    KABC_HIP_CHECK(bufs.alloc(&alive, Npad));  // (padded: gathered at the end of a particle-sharded run)
     KABC_HIP_CHECK(bufs.alloc(&cidx, (size_t)N));
     KABC_HIP_CHECK(bufs.alloc(&ctrl, 1));
     KABC_HIP_CHECK(bufs.alloc(&slots, (size_t)kSmcSlots * 8 * world));
@@ -606,6 +625,117 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         KABC_HIP_CHECK(hipMemsetAsync(sa.stamps, 0, 64, s));
     }
     auto do_select = [&](hipStream_t st) -> hipError_t { return launch_select(sa, selG, st); };
+    // Particles sharded (KABC_SMC_DIST_PARTICLES): the selection over this rank's own costs, the ranks'
+    // contributions all-gathered between its phases (smc_dsel_kernels.hpp).  Collective and synchronous.
+    const bool dist_particles = comm && tl_smc_dist_mode == KABC_SMC_DIST_PARTICLES;
+    DselArgs dz;
+    std::memset(&dz, 0, sizeof dz);
+    unsigned dselG = 0;
+    if (dist_particles) {
+        dz.Xbuf[0] = X[0];
+        dz.Xbuf[1] = X[1];
+        dz.alive = alive;
+        dz.cidx = cidx;
+        dz.ctrl = ctrl;
+        dz.part = part;
+        dz.npart = npart;
+        dz.N = N;
+        dz.p_lo = std::min<int64_t>(wg_lo * kSmcBlock, N);
+        dz.p_hi = std::min<int64_t>((wg_lo + wg_n) * kSmcBlock, N);
+        dz.alpha = alpha;
+        dz.min_r_ess = min_r_ess;
+        dz.rank = rank;
+        dz.world = world;
+        dz.seg_len = wg_per * kSmcBlock;
+        KABC_HIP_CHECK(bufs.alloc(&dz.st, 1));
+        KABC_HIP_CHECK(bufs.alloc(&dz.hist, (size_t)world * kSelBins));
+        KABC_HIP_CHECK(bufs.alloc(&dz.cand, (size_t)world * kDselCandStride));
+        KABC_HIP_CHECK(bufs.alloc(&dz.misc, (size_t)world * 8));
+        KABC_HIP_CHECK(bufs.alloc(&dz.seg, (size_t)world * dz.seg_len));
+        KABC_HIP_CHECK(bufs.alloc(&dz.sub_cnt, (size_t)kDselMaxGrid));
+        KABC_HIP_CHECK(hipMemsetAsync(dz.hist, 0, sizeof(unsigned) * world * kSelBins, s));
+        KABC_HIP_CHECK(hipMemsetAsync(dz.cand, 0, sizeof(unsigned long long) * world * kDselCandStride, s));
+        KABC_HIP_CHECK(hipMemsetAsync(dz.misc, 0, sizeof(unsigned long long) * world * 8, s));
+        const int64_t len = dz.p_hi - dz.p_lo;
+        const int64_t g = (len + 2 * kSelBlock - 1) / (2 * kSelBlock);  // 2048 particles per workgroup
+        dselG = len <= 0 ? 0u : (unsigned)std::min<int64_t>(std::max<int64_t>(g, 1), kDselMaxGrid);
+    }
+    DselState hz;
+    std::memset(&hz, 0, sizeof hz);
+    auto dsel_look = [&]() -> kabc_status_t {  // the state the deciding kernel left
+        KABC_HIP_CHECK(hipGetLastError());
+        KABC_HIP_CHECK(hipMemcpyAsync(&hz, dz.st, sizeof hz, hipMemcpyDeviceToHost, s));
+        KABC_HIP_CHECK(hipStreamSynchronize(s));
+        return KABC_OK;
+    };
+    auto dsel_gather = [&](void* base, size_t doubles_per_rank) -> kabc_status_t {
+        double* b[1] = {reinterpret_cast<double*>(base)};
+        const size_t c[1] = {doubles_per_rank};
+        return comm_allgather_many(comm, b, c, 1);
+    };
+    long dsel_calls = 0, dsel_rounds = 0, dsel_lists = 0, dsel_scans = 0, dsel_resamples = 0;  // (KABC_SMC_STAMPS)
+    auto dist_select = [&]() -> kabc_status_t {
+        ++dsel_calls;
+        // Every kernel tests the selection state before it acts, so the phases of the USUAL course are
+        // enqueued without a look in between -- one histogram round when more than 4096 particles may be
+        // alive, the candidate list, the ranking, the counts, the compaction -- and the host looks once;
+        // what the usual course did not cover (more rounds, the scan above the range) is caught up below.
+        auto round = [&]() -> kabc_status_t {
+            if (dselG) hipLaunchKernelGGL(dsel_hist_kernel, dim3(dselG), dim3(kSelBlock), 0, s, dz);
+            if (kabc_status_t st = dsel_gather(dz.hist, kSelBins / 2)) return st;
+            hipLaunchKernelGGL(dsel_narrow_kernel, dim3(1), dim3(kSelBlock), 0, s, dz);
+            ++dsel_rounds;
+            return KABC_OK;
+        };
+        auto tail = [&](bool list) -> kabc_status_t {
+            if (list) {
+                if (dselG) hipLaunchKernelGGL(dsel_collect_kernel, dim3(dselG), dim3(kSelBlock), 0, s, dz);
+                if (kabc_status_t st = dsel_gather(dz.cand, kDselCandStride)) return st;
+                hipLaunchKernelGGL(dsel_rank_kernel, dim3(1), dim3(kSelBlock), 0, s, dz);
+                ++dsel_lists;
+            }
+            if (dselG) hipLaunchKernelGGL(dsel_count_kernel, dim3(dselG), dim3(kSelBlock), 0, s, dz);
+            if (kabc_status_t st = dsel_gather(dz.misc, 8)) return st;
+            // (a rank without particles still decides -- ESS, resample -- like the others)
+            hipLaunchKernelGGL(dsel_compact_kernel, dim3(dselG ? dselG : 1u), dim3(kSelBlock), 0, s, dz);
+            return dsel_look();
+        };
+        hipLaunchKernelGGL(dsel_begin_kernel, dim3(1), dim3(kSelBlock), 0, s, dz);
+        int rounds = 0;
+        if (N > (int64_t)kSelCand) {
+            if (kabc_status_t st = round()) return st;
+            ++rounds;
+        }
+        if (kabc_status_t st = tail(true)) return st;
+        while (!hz.error && hz.state != 3) {
+            if (hz.state == 0) {
+                if (++rounds > kSelRounds) {  // cannot happen: 7 rounds x 10 bits > 64 bits
+                    set_error("smc: the sharded selection did not narrow its key range");
+                    return KABC_ERR_INVALID_STATE;
+                }
+                if (kabc_status_t st = round()) return st;
+                if (kabc_status_t st = tail(true)) return st;
+            } else if (hz.state == 4) {  // the smallest key above the range is not among the candidates
+                ++dsel_scans;
+                if (dselG) hipLaunchKernelGGL(dsel_above_kernel, dim3(dselG), dim3(kSelBlock), 0, s, dz);
+                if (kabc_status_t st = dsel_gather(dz.misc, 8)) return st;
+                hipLaunchKernelGGL(dsel_above_fold_kernel, dim3(1), dim3(64), 0, s, dz);
+                if (kabc_status_t st = tail(false)) return st;
+            } else {
+                set_error("smc: the sharded selection stopped in state %d", (int)hz.state);
+                return KABC_ERR_INVALID_STATE;
+            }
+        }
+        if (hz.error) return KABC_OK;  // (in the control block: the caller reads it)
+        if (hz.resample) {
+            ++dsel_resamples;
+            if (kabc_status_t st = dsel_gather(dz.seg, (size_t)dz.seg_len / 2)) return st;
+            hipLaunchKernelGGL(dsel_finish_kernel, dim3(256), dim3(256), 0, s, dz);
+        }
+        hipLaunchKernelGGL(dsel_publish_kernel, dim3(1), dim3(64), 0, s, dz);
+        KABC_HIP_CHECK(hipGetLastError());
+        return KABC_OK;
+    };
     SmcMcmcArgs ma;
     std::memset(&ma, 0, sizeof ma);
     for (int b = 0; b < 2; ++b) {
@@ -836,7 +966,11 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     // gathered) and whether the next pass is still open; with a simulator expensive enough to
     // be worth sharding, a host round trip per pass is noise.
     while (comm && !looped) {
-        KABC_HIP_CHECK(do_select(s));
+        if (dist_particles) {
+            if (kabc_status_t st = dist_select()) return st;
+        } else {
+            KABC_HIP_CHECK(do_select(s));
+        }
         KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
         KABC_HIP_CHECK(hipStreamSynchronize(s));
         if (hc.done) break;
@@ -951,6 +1085,8 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         if (res->cost)
             KABC_HIP_CHECK(hipMemcpyAsync(res->cost, d_Xout, sizeof(double) * N,
                                           hipMemcpyDeviceToHost, s));
+        if (dist_particles)  // every rank holds the mask of its own range only
+            if (kabc_status_t st = dsel_gather(alive, (size_t)wg_per * kSmcBlock / 8)) return st;
         if (res->alive)
             KABC_HIP_CHECK(hipMemcpyAsync(res->alive, alive, (size_t)N, hipMemcpyDeviceToHost, s));
         const int64_t nlog = hc.iteration < log_cap ? hc.iteration : log_cap;
@@ -988,6 +1124,10 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         tl_smc_no_loop = false;
         return st2;
     }
+    if (dist_particles && sa.stamps && rank == 0)
+        fprintf(stderr, "[kabc smc sharded selection, %d ranks] %ld selections: %ld histogram rounds, %ld candidate "
+                        "lists, %ld scans above the range, %ld resamples (workgroups per pass and rank: %u)\n",
+                world, dsel_calls, dsel_rounds, dsel_lists, dsel_scans, dsel_resamples, dselG);
     if (sa.stamps) {
         unsigned long long st[8];
         if (hipMemcpy(st, sa.stamps, 64, hipMemcpyDeviceToHost) == hipSuccess && st[7])

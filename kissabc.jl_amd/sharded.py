@@ -152,3 +152,94 @@ class ShardedAIS:
             if self.world > 1:
                 dist.all_reduce(t, group=self.group)
         return dict(zip(("proposals", "cost_evals", "accepted"), (int(v) for v in t.tolist())))
+
+
+# ---- smc with sharded particles: the ε-selection's exchange logic -----------------------------
+def _keys_of(x):
+    """order-preserving map double -> u64 (csrc/smc_kernels.hpp key_of)"""
+    import numpy as np
+    u = np.ascontiguousarray(x, dtype=np.float64).view(np.uint64)
+    neg = (u >> np.uint64(63)).astype(bool)
+    return np.where(neg, ~u, u | np.uint64(1 << 63))
+
+
+def _val_of(k):
+    import numpy as np
+    k = np.uint64(k)
+    u = (k & np.uint64((1 << 63) - 1)) if (k >> np.uint64(63)) else ~k
+    return float(np.array([u], dtype=np.uint64).view(np.float64)[0])
+
+
+def sharded_select(X_own, alive_own, lo, N, alpha, min_r_ess, all_gather, cand_cap=4096):
+    """Host mirror of the phases of csrc/smc_dsel_kernels.hpp (kabc_smc_run_dist_mode,
+    KABC_SMC_DIST_PARTICLES) for ONE selection: this rank owns the particles [lo, lo + len(X_own)).
+    `all_gather(array) -> [array of rank 0, array of rank 1, ...]` is the only communication
+    (tests/test_sharded_gloo.py: torch.distributed over gloo).  Returns what every rank ends up with:
+    (eps, flag, ESS, resample, alive_own_new, idxalive of the whole ensemble or None without a resample).
+    src/smc.jl:134-147."""
+    import numpy as np
+    X_own = np.asarray(X_own, dtype=np.float64)
+    alive_own = np.asarray(alive_own, dtype=bool)
+    keys = _keys_of(X_own[alive_own])
+    # begin: n, key range (the device takes them from the producers' gathered partials)
+    st = all_gather(np.array([keys.size, int(keys.min()) if keys.size else 2**64 - 1,
+                              int(keys.max()) if keys.size else 0], dtype=np.uint64))
+    n = int(sum(int(s[0]) for s in st))
+    if n == 0:
+        raise ValueError("collection must be non-empty")
+    klo = min(int(s[1]) for s in st)
+    khi = max(int(s[2]) for s in st)
+    mn = _val_of(klo)
+    aleph = n * alpha + (1.0 - alpha)
+    j = min(max(int(aleph), 1), n - 1) if n > 1 else 1
+    gq = min(max(aleph - j, 0.0), 1.0)
+    kt, nrange = j - 1, n
+    state = 2 if klo == khi else (1 if n <= cand_cap else 0)
+    while state == 0:     # hist + narrow: 1024 bins over the occupied key range
+        span = khi - klo
+        shift = max(span.bit_length() - 10, 0)
+        sel = keys[(keys >= np.uint64(klo)) & (keys <= np.uint64(khi))]
+        mine = np.bincount(((sel - np.uint64(klo)) >> np.uint64(shift)).astype(np.int64), minlength=1024)
+        c = sum(np.asarray(h, dtype=np.int64) for h in all_gather(mine.astype(np.uint32)))
+        before = np.concatenate([[0], np.cumsum(c)[:-1]])
+        b = int(np.flatnonzero((c > 0) & (kt >= before) & (kt < before + c))[0])
+        nlo = klo + (b << shift)
+        nhi = min(nlo + (1 << shift) - 1, khi)
+        klo, khi, kt, nrange = nlo, nhi, kt - int(before[b]), int(c[b])
+        state = 2 if shift == 0 else (1 if nrange <= cand_cap else 0)
+    need_above = False
+    if state == 1:        # collect + rank
+        sel = keys[(keys >= np.uint64(klo)) & (keys <= np.uint64(khi))]
+        cand = np.sort(np.concatenate([np.asarray(a, dtype=np.uint64) for a in all_gather(sel)]))
+        assert cand.size == nrange
+        ka = int(cand[kt])
+        if kt + 1 < cand.size:
+            kb = int(cand[kt + 1])
+        else:
+            need_above = True
+    else:                 # every key of the range equals klo
+        ka = klo
+        if kt + 1 < nrange:
+            kb = klo
+        else:
+            need_above = True
+    if need_above and n > 1:   # the smallest alive key above the range
+        above = keys[keys > np.uint64(khi)]
+        kb = min(int(a[0]) for a in all_gather(np.array([int(above.min()) if above.size else 2**64 - 1],
+                                                        dtype=np.uint64)))
+    a = _val_of(ka)
+    b = a if n == 1 else _val_of(kb)
+    eps = a + gq * (b - a) if (np.isfinite(a) and np.isfinite(b)) else (1.0 - gq) * a + gq * b
+    flag = 0 if eps > mn else 1
+    new_alive = (X_own <= eps) if flag else (X_own < eps)
+    counts = [int(c[0]) for c in all_gather(np.array([int(new_alive.sum())], dtype=np.int64))]
+    ESS = sum(counts)
+    resample = alpha * ESS <= N * min_r_ess
+    idx = None
+    if resample:
+        if ESS == 0:
+            raise ValueError("collection must be non-empty")
+        idx = np.concatenate([np.asarray(s, dtype=np.int64)
+                              for s in all_gather(lo + np.flatnonzero(new_alive))])
+        new_alive = np.ones_like(new_alive)
+    return eps, flag, ESS, bool(resample), new_alive, idx

@@ -211,6 +211,42 @@ def test_rccl_world1_pipelined_chunks(tmp_path):
     assert np.array_equal(x2, x0) and s2["accepted"] == s0["accepted"]
 
 
+SMC_CHILD = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, {root!r})
+import kissabc_jl_amd as k
+prior = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+cost = k.costs.NoisyBanana(0.5)
+kw = dict(nparticles=9000, alpha=0.9, epstol=0.05, seed=4, return_array=True)
+plain = k.smc(prior, cost, **kw)
+comm = k.Comm.from_env()
+res = {{}}
+for shard in ("cost_loop", "particles"):
+    got = k.smc(prior, cost, comm=comm, shard=shard, **kw)
+    res[shard] = bool(got.eps == plain.eps and np.array_equal(got.info["theta_all"], plain.info["theta_all"])
+                      and np.array_equal(got.C, plain.C) and np.array_equal(got.info["alive"], plain.info["alive"])
+                      and got.info["log"] == plain.info["log"])
+comm.close()
+assert "torch" not in sys.modules
+import ctypes
+ctypes.CDLL(None).fflush(None)
+print(json.dumps(dict(res, iterations=plain.info["iterations"])), flush=True)
+"""
+
+
+def test_smc_dist_modes_on_an_rccl_communicator_world1():
+    """both modes of kabc_smc_run_dist_mode on a one-process-per-GPU RCCL communicator (world 1: every
+    all-gather of the sharded selection is a real ncclAllGather on the context's stream)"""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", KABC_NO_TORCH_PRELOAD="1")
+    r = subprocess.run([sys.executable, "-c", SMC_CHILD.format(root=ROOT)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["cost_loop"] is True and d["particles"] is True and d["iterations"] > 20
+
+
 def _bench(extra_env, launcher):
     env = dict(os.environ, KABC_FORCE_COLLECTIVE="1", **extra_env)
     cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1",
@@ -292,6 +328,83 @@ def test_smc_sharded_cost_loop_matches_single_gpu_and_oracle(k, orc, gpu_ctx, wo
         assert out[r].info["iterations"] == ref["iterations"]
         assert out[r].info["cost_evals"] == single.info["cost_evals"]
         assert out[r].info["proposals"] == single.info["proposals"]
+    for c in comms:
+        c.close()
+
+
+def _run_ranks(k, comms, fn):
+    """one host thread per rank of a P2P communicator group; returns the per-rank results"""
+    import threading
+    world = len(comms)
+    out, err = [None] * world, []
+
+    def run(r):
+        try:
+            out[r] = fn(comms[r])
+        except Exception as e:          # a failing rank must not leave the others in the rendezvous
+            err.append(repr(e))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=900)
+    assert not err and all(o is not None for o in out), err
+    return out
+
+
+@pytest.mark.parametrize("world,name", [(w, n) for n in ["banana_inf", "C4_hier16_small", "gauss_d2_minress",
+                                                         "mixture_retrys", "dirac", "ties"] for w in (2, 4, 8)]
+                         + [(3, "hier16_40k")])
+def test_smc_sharded_particles_equals_oracle(k, orc, gpu_ctx, world, name):
+    """kabc_smc_run_dist_mode(KABC_SMC_DIST_PARTICLES) -- SURVEY §8e "SMC": the ranks OWN their particles;
+    ε from all-gathered histograms of the order-preserving keys + a candidate gather, ESS from gathered
+    counts, the resample index from the gathered compacted segments (src/smc.jl:131-153), partners from
+    the gathered ensemble.  Ranks are host threads on the P2P backend (one GPU; uneven and empty shards:
+    `dirac` has 100 particles = 2 blocks for up to 8 ranks).  Every rank returns the oracle's result bit
+    for bit: positions, costs, alive mask, ε and the per-iteration log."""
+    from test_gpu_smc_parity import _cases
+    if name == "ties":   # heavy ties: whole key ranges collapse to one value (state 2 of the narrowing)
+        prior, cost = k.Factored(k.Normal(1, 0.5), k.DiscreteUniform(1, 10)), k.costs.NoisyQuadDU(5.5)
+        kw = dict(nparticles=6000, epstol=0.05)
+    elif name == "hier16_40k":   # several workgroups per pass and rank, histogram rounds, uneven shards
+        prior, cost, _ = _cases(k)["C4_hier16_small"]
+        kw = dict(nparticles=40000, alpha=0.95, epstol=0.3)
+    else:
+        prior, cost, kw = _cases(k)[name]
+    ref = orc.smc(prior, cost, seed=5, **kw)
+    comms = k.comm.init_all([0] * world, "p2p")
+    out = _run_ranks(k, comms, lambda c: k.smc(prior, cost, seed=5, return_array=True, comm=c,
+                                               shard="particles", **kw))
+    for r in range(world):
+        got = out[r]
+        assert got.info["iterations"] == ref["iterations"], r
+        assert got.info["log"] == ref["log"], r
+        assert got.eps == ref["eps"], r
+        assert np.array_equal(got.info["alive"], ref["alive"]), r
+        assert np.array_equal(got.info["theta_all"], ref["theta_all"]), r
+        assert np.array_equal(got.C, ref["C"]), r
+        assert got.info["cost_evals"] == ref["cost_evals"] and got.info["proposals"] == ref["proposals"]
+    for c in comms:
+        c.close()
+
+
+def test_smc_sharded_particles_two_million(k, gpu_ctx):
+    """the same at 2 097 152 particles x 16 parameters (C4's model) on 4 ranks, against kabc_smc_run on
+    one GPU (which the parity suite pins to the oracle at the sizes the oracle finishes): several
+    narrowing candidates per rank, 8192 blocks per rank, resamples of half a million rows"""
+    from test_gpu_smc_parity import _cases
+    prior, cost, _ = _cases(k)["C4_hier16_small"]
+    kw = dict(nparticles=2097152, alpha=0.5, epstol=1.0, seed=11)
+    single = k.smc(prior, cost, return_array=True, **kw)
+    assert single.info["iterations"] >= 3 and any(l["resampled"] for l in single.info["log"])
+    comms = k.comm.init_all([0] * 4, "p2p")
+    out = _run_ranks(k, comms, lambda c: k.smc(prior, cost, return_array=True, comm=c, shard="particles", **kw))
+    for got in out:
+        assert got.eps == single.eps and got.info["log"] == single.info["log"]
+        assert np.array_equal(got.info["alive"], single.info["alive"])
+        assert np.array_equal(got.info["theta_all"], single.info["theta_all"])
+        assert np.array_equal(got.C, single.C)
     for c in comms:
         c.close()
 

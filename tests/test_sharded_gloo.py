@@ -125,3 +125,89 @@ def test_sharded_requires_divisible_ensemble(k):
     with pytest.raises(ValueError):
         # single process => world 1 => needs N % 2 == 0
         ShardedAIS(_model(k), 513, engine=E())
+
+
+# ---- smc with sharded particles: the selection's exchange logic (sharded.sharded_select) ----------
+def _select_direct(X, alive, alpha, min_r_ess):
+    """src/smc.jl:134-147 on the whole ensemble (the formulas of csrc/smc_kernels.hpp smc_select_kernel)"""
+    xs = np.sort(X[alive])
+    n = xs.size
+    aleph = n * alpha + (1.0 - alpha)
+    j = min(max(int(aleph), 1), n - 1) if n > 1 else 1
+    g = min(max(aleph - j, 0.0), 1.0)
+    a, b = xs[j - 1], (xs[j] if n > 1 else xs[j - 1])
+    eps = a + g * (b - a) if (np.isfinite(a) and np.isfinite(b)) else (1.0 - g) * a + g * b
+    flag = 0 if eps > xs[0] else 1
+    new = (X <= eps) if flag else (X < eps)
+    ess = int(new.sum())
+    res = alpha * ess <= X.size * min_r_ess
+    return eps, flag, ess, bool(res), (np.ones_like(new) if res else new), (np.flatnonzero(new) if res else None)
+
+
+def _select_cases():
+    rng = np.random.default_rng(12)
+    N = 20000
+    out = {}
+    x = rng.normal(size=N) ** 2
+    out["smooth"] = (x, np.ones(N, bool), 0.95, 0.2)
+    out["resample"] = (x, rng.random(N) < 0.5, 0.6, 0.9)
+    t = np.round(rng.normal(size=N) * 3)          # heavy ties: whole ranges collapse to one key
+    out["ties"] = (t, rng.random(N) < 0.8, 0.9, 0.2)
+    out["all_equal"] = (np.full(N, 2.5), np.ones(N, bool), 0.5, 0.2)
+    c = x.copy()
+    c[rng.random(N) < 0.3] = np.inf               # KernelizedPosterior-style infinite costs
+    out["with_inf"] = (c, np.ones(N, bool), 0.95, 0.2)
+    s = np.concatenate([rng.normal(size=N - 3), [1e300, -1e300, 0.0]])   # 64-bit key range in use
+    out["wide"] = (s, np.ones(N, bool), 0.999, 0.2)
+    out["small"] = (rng.normal(size=300), rng.random(300) < 0.7, 0.9, 0.5)
+    return out
+
+
+def _select_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from kissabc_jl_amd.sharded import sharded_select
+
+    def all_gather(a):      # ragged: sizes first, then padded payloads (as the device pads its segments)
+        a = np.ascontiguousarray(a)
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([a.size]))
+        m = max(int(s) for s in sizes)
+        buf = np.zeros(max(m, 1), dtype=a.dtype)
+        buf[:a.size] = a
+        parts = [torch.zeros(max(m, 1) * a.dtype.itemsize, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(buf.view(np.uint8).copy()))
+        return [p.numpy().view(a.dtype)[:int(s)] for p, s in zip(parts, sizes)]
+
+    res = {}
+    for name, (X, alive, alpha, mre) in _select_cases().items():
+        N = X.size
+        blocks = (N + 63) // 64          # ownership by blocks of 64 particles, as kabc_smc_run_dist
+        per = (blocks + world - 1) // world
+        lo, hi = min(rank * per * 64, N), min((rank + 1) * per * 64, N)
+        eps, flag, ess, resample, new_own, idx = sharded_select(X[lo:hi], alive[lo:hi], lo, N, alpha, mre,
+                                                                all_gather)
+        full = np.concatenate(all_gather(new_own.astype(np.uint8))).astype(bool)
+        res[name] = (eps, flag, ess, resample, full, idx)
+    if rank == world - 1:   # (any rank: they all hold the same)
+        np.savez(out_path, **{f"{n}_{i}": (np.array(-1) if v is None else np.asarray(v))
+                              for n, r in res.items() for i, v in enumerate(r)})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_selection_equals_the_selection_on_the_whole_ensemble(tmp_path, world):
+    out = str(tmp_path / "select.npz")
+    mp.spawn(_select_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    got = np.load(out)
+    for name, (X, alive, alpha, mre) in _select_cases().items():
+        eps, flag, ess, resample, new, idx = _select_direct(X, alive, alpha, mre)
+        assert float(got[f"{name}_0"]) == eps, name
+        assert int(got[f"{name}_1"]) == flag and int(got[f"{name}_2"]) == ess, name
+        assert bool(got[f"{name}_3"]) == resample, name
+        assert np.array_equal(got[f"{name}_4"], new), name
+        if resample:
+            assert np.array_equal(got[f"{name}_5"], idx), name
