@@ -598,7 +598,12 @@ kcost(c::DeviceCost) = KabcCost(c.id, length(c.params), pointer(c.params), lengt
 function KissABC.smc(prior::Distribution, cost::DeviceCost; rng = Random.GLOBAL_RNG,
                      nparticles::Int = 100, alpha = 0.95, mcmc_retrys::Int = 0, mcmc_tol = 0.015,
                      epstol = 0.0, r_epstol = (1 - alpha)^1.5 / 50, min_r_ess = alpha^2,
-                     max_stretch = 2.0, verbose::Bool = false, parallel::Bool = false)
+                     max_stretch = 2.0, verbose::Bool = false, parallel::Bool = false,
+                     comm::Ptr{Cvoid} = C_NULL, shard::Symbol = :cost_loop)
+    # comm (a communicator of init_rank): collective over its ranks, every rank passes the same arguments
+    # and an `rng` in the same state, and receives the same result -- smc's, bit for bit.
+    # shard = :cost_loop  the propose / accept pass is shared out (the reference's `parallel = true` leg);
+    #         :particles  the ranks own their particles, the ε-selection is sharded as well (SURVEY §8e)
     pri = lower_prior(prior)
     D, N = length(pri), nparticles
     theta = Matrix{Float64}(undef, D, max(N, 1))
@@ -608,9 +613,15 @@ function KissABC.smc(prior::Distribution, cost::DeviceCost; rng = Random.GLOBAL_
                     max_stretch, rand(rng, UInt64), 0)
     r = KabcSmcResult(pointer(theta), pointer(C), pointer(alive), 0.0, 0, 0, 0, 0, C_NULL, 0, 0.0, 0)
     GC.@preserve pri cost theta C alive begin
-        check(ccall((:kabc_smc_run, libkabc), Cint,
-                    (Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcOpts}, Ref{KabcSmcResult}),
-                    context(), pri, D, kcost(cost), o, r))          # argument errors: the reference's messages
+        if comm == C_NULL
+            check(ccall((:kabc_smc_run, libkabc), Cint,
+                        (Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcOpts}, Ref{KabcSmcResult}),
+                        context(), pri, D, kcost(cost), o, r))      # argument errors: the reference's messages
+        else
+            check(ccall((:kabc_smc_run_dist_mode, libkabc), Cint,
+                        (Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcOpts}, Int32, Ref{KabcSmcResult}),
+                        comm, pri, D, kcost(cost), o, Int32(shard == :particles ? 1 : 0), r))
+        end
     end
     (P = particles_of(prior, theta, findall(!=(0x00), alive)), C = C, ϵ = r.eps)   # src/smc.jl:205
 end

@@ -316,8 +316,11 @@ MUTATIONS = [
      "(:kabc_ais_advance, libkabc), Cint, (Ptr{Cvoid}, Int64, Int32, Ptr{Float64}, Ptr{Cvoid}),\n                st.handle",
      "(:kabc_ais_advance, libkabc), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Cvoid}),\n                st.handle"),
     ("a dropped argument in kabc_smc_run",
-     "(Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcOpts}, Ref{KabcSmcResult}),\n                    context(), pri, D, kcost(cost), o, r))          #",
-     "(Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcResult}),\n                    context(), pri, D, kcost(cost), r))          #"),
+     "(Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcOpts}, Ref{KabcSmcResult}),\n                        context(), pri, D, kcost(cost), o, r))      #",
+     "(Ptr{Cvoid}, Ptr{KabcPrior}, Int32, Ref{KabcCost}, Ref{KabcSmcResult}),\n                        context(), pri, D, kcost(cost), r))      #"),
+    ("the mode of kabc_smc_run_dist_mode passed after the result",
+     "Ref{KabcSmcOpts}, Int32, Ref{KabcSmcResult}),\n                        comm, pri, D, kcost(cost), o, Int32(shard == :particles ? 1 : 0), r))",
+     "Ref{KabcSmcOpts}, Ref{KabcSmcResult}, Int32),\n                        comm, pri, D, kcost(cost), o, r, Int32(shard == :particles ? 1 : 0)))"),
     ("handle out-parameter as a plain pointer value",
      "(:kabc_ctx_create, libkabc), Cint, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}})",
      "(:kabc_ctx_create, libkabc), Cint, (Int32, Ptr{Cvoid}, Ptr{Cvoid})"),
