@@ -2,7 +2,7 @@
  * what a Julia `ccall`, a cgo or a JNI binding would do.
  *
  *   gcc -std=c99 -O2 -Iinclude examples/abi_demo.c -o /tmp/abi_demo \
- *       -Lkissabc.jl_amd/lib -lkabc_hip -Wl,-rpath,$PWD/kissabc.jl_amd/lib
+ *       -Lkissabc.jl_amd/lib -lkabc_hip -lpthread -Wl,-rpath,$PWD/kissabc.jl_amd/lib
  *   /tmp/abi_demo
  *
  * 1. sample(ApproxKernelizedPosterior(Factored(Normal(0,5), Normal(0,5)), cost, 0.1),
@@ -12,8 +12,11 @@
  * 2. smc(prior, cost; nparticles = 2000, alpha = 0.9, epstol = 0.05) on the same cost.
  * 3. the same AIS ensemble sharded over two ranks driven from this one process
  *    (kabc_comm_init_all + kabc_ais_create_dist + kabc_ais_*_multi).
+ * 4. the smc of step 2 with its PARTICLES sharded over two ranks, one host thread per rank
+ *    (kabc_smc_run_dist_mode, KABC_SMC_DIST_PARTICLES): every rank returns step 2's result.
  * Prints one line of key=value pairs; tests/test_gpu_abi_demo.py compares it with the
  * Python mirror's result for the same seeds (bit-identical). */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -29,6 +32,22 @@
             return 1;                                                        \
         }                                                                    \
     } while (0)
+
+/* one rank of step 4: a collective call, every rank with the same arguments */
+typedef struct rank_job {
+    kabc_comm_t* comm;
+    const kabc_prior_t* prior;
+    const kabc_cost_t* cost;
+    const kabc_smc_opts_t* opts;
+    kabc_smc_result_t res;
+    kabc_status_t status;
+} rank_job_t;
+
+static void* rank_main(void* arg) {
+    rank_job_t* j = (rank_job_t*)arg;
+    j->status = kabc_smc_run_dist_mode(j->comm, j->prior, 2, j->cost, j->opts, KABC_SMC_DIST_PARTICLES, &j->res);
+    return NULL;
+}
 
 int main(void) {
     if (kabc_device_count() < 1) {
@@ -124,9 +143,45 @@ int main(void) {
         free(xb);
     }
 
-    printf("version=%d sharded_equal=%d proposals=%llu accepted=%llu mean0=%.17g mean1=%.17g last0=%.17g last1=%.17g "
+    /* ---- smc with sharded particles: two ranks, a host thread each (with one process per GPU and
+     * kabc_comm_init_rank every process makes the one call itself) */
+    int smc_sharded_equal = 0;
+    {
+        const int32_t devs[2] = {0, 0};
+        kabc_ctx_t* cx[2];
+        kabc_comm_t* cm[2];
+        rank_job_t job[2];
+        pthread_t th[2];
+        CHECK(kabc_comm_init_all(2, devs, KABC_COMM_P2P, cx, cm));
+        memset(job, 0, sizeof job);
+        for (int rk = 0; rk < 2; ++rk) {
+            job[rk].comm = cm[rk];
+            job[rk].prior = prior;
+            job[rk].cost = &model.cost;
+            job[rk].opts = &o;
+            job[rk].res.theta = (double*)malloc(sizeof(double) * 2000 * 2);
+            job[rk].res.cost = (double*)malloc(sizeof(double) * 2000);
+            job[rk].res.alive = (uint8_t*)malloc(2000);
+            if (pthread_create(&th[rk], NULL, rank_main, &job[rk]) != 0) return 3;
+        }
+        smc_sharded_equal = 1;
+        for (int rk = 0; rk < 2; ++rk) {
+            pthread_join(th[rk], NULL);
+            smc_sharded_equal = smc_sharded_equal && job[rk].status == KABC_OK && job[rk].res.eps == r.eps &&
+                                job[rk].res.iterations == r.iterations &&
+                                memcmp(job[rk].res.theta, r.theta, sizeof(double) * 2000 * 2) == 0 &&
+                                memcmp(job[rk].res.cost, r.cost, sizeof(double) * 2000) == 0 &&
+                                memcmp(job[rk].res.alive, r.alive, 2000) == 0;
+            free(job[rk].res.theta);
+            free(job[rk].res.cost);
+            free(job[rk].res.alive);
+        }
+        for (int rk = 0; rk < 2; ++rk) CHECK(kabc_comm_destroy(cm[rk]));
+    }
+
+    printf("version=%d sharded_equal=%d smc_sharded_equal=%d proposals=%llu accepted=%llu mean0=%.17g mean1=%.17g last0=%.17g last1=%.17g "
            "smc_eps=%.17g smc_iterations=%lld smc_alive=%lld smc_sum0=%.17g\n",
-           (int)kabc_version(), sharded_equal, (unsigned long long)stats.proposals,
+           (int)kabc_version(), sharded_equal, smc_sharded_equal, (unsigned long long)stats.proposals,
            (unsigned long long)stats.accepted, m0, m1, last0, last1, r.eps,
            (long long)r.iterations, (long long)r.n_alive, s0);
     free(r.theta);

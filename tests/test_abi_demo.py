@@ -15,7 +15,7 @@ def _build(tmp_path):
     exe = str(tmp_path / "abi_demo")
     cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
            os.path.join(ROOT, "examples", "abi_demo.c"), "-o", exe, "-L", LIBDIR, "-lkabc_hip",
-           f"-Wl,-rpath,{LIBDIR}"]
+           "-lpthread", f"-Wl,-rpath,{LIBDIR}"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
@@ -49,3 +49,4 @@ def test_abi_demo_matches_python_mirror(tmp_path, k, gpu_ctx):
     assert int(got["smc_alive"]) == s.info["n_alive"]
     assert float(got["smc_sum0"]) == float(np.cumsum(s.info["theta_all"][:, 0])[-1])
     assert int(got["version"]) == 310 and int(got["sharded_equal"]) == 1
+    assert int(got["smc_sharded_equal"]) == 1     # kabc_smc_run_dist_mode, particles sharded over two ranks
