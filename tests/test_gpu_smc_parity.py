@@ -300,3 +300,55 @@ def test_select_launch_that_times_out_is_repeated_cooperatively(k, orc, gpu_ctx,
             monkeypatch.delenv(kk)
         gp0 = k.pfilter(N2, cost, 140000, seed=4, return_array=True, max_iters=4)
         assert np.array_equal(gp.P, gp0.P) and np.array_equal(gp.C, gp0.C)
+
+
+NAN_SRC = """
+KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
+                              const double* data, int64_t ndata, kabc_cost_rng_t* rng) {
+    const double r = kabc_sqrt(x[0] * x[0] + x[1] * x[1]);
+    /* 0/0 once a particle comes within params[0] of the origin; params[0] < 0: in the initial draw already */
+    return (r < params[0] || params[0] < 0.0) ? (r - r) / (r - r) : r;
+}
+"""
+
+
+@pytest.mark.parametrize("where", ["init", "later"])
+@pytest.mark.parametrize("driver", ["small", "loop", "kernels", "cost_loop", "particles"])
+def test_nan_cost_is_the_references_quantile_error(k, orc, gpu_ctx, monkeypatch, driver, where):
+    """`quantile` of costs with a NaN among the alive ones throws (Statistics: "quantiles are undefined in
+    presence of NaNs"; src/smc.jl:134): the same message from every driver of the ε-loop and from both
+    sharding modes, in the initial population or iterations later -- as the oracle's restatement"""
+    cost = k.costs.UserCost(NAN_SRC, dims=[2], params=[-1.0 if where == "init" else 0.4], name="nan_" + where)
+    orc.register_user_cost(cost)
+    prior = k.Factored(k.Normal(0, 3), k.Normal(0, 3))
+    N = 200 if driver == "small" else 3000
+    kw = dict(nparticles=N, alpha=0.9, epstol=0.01, seed=3)
+    with pytest.raises(Exception) as eo:
+        orc.smc(prior, cost, **kw)
+    assert "quantiles are undefined in presence of NaNs" in str(eo.value)
+    if driver in ("loop", "kernels"):
+        monkeypatch.setenv("KABC_SMC_LOOP", "1" if driver == "loop" else "0")
+    if driver in ("cost_loop", "particles"):
+        import threading
+        comms = k.comm.init_all([0, 0, 0], "p2p")
+        errs = []
+
+        def run(c):
+            try:
+                k.smc(prior, cost, comm=c, shard=driver, return_array=True, **kw)
+                errs.append("no error")
+            except k.KabcError as e:
+                errs.append(str(e))
+
+        th = [threading.Thread(target=run, args=(c,)) for c in comms]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+        for c in comms:
+            c.close()
+        assert errs == ["quantiles are undefined in presence of NaNs"] * 3
+    else:
+        with pytest.raises(k.KabcError) as e:
+            k.smc(prior, cost, return_array=True, **kw)
+        assert str(e.value) == "quantiles are undefined in presence of NaNs"
