@@ -355,7 +355,7 @@ def _run_ranks(k, comms, fn):
 
 @pytest.mark.parametrize("world,name", [(w, n) for n in ["banana_inf", "C4_hier16_small", "gauss_d2_minress",
                                                          "mixture_retrys", "dirac", "ties"] for w in (2, 4, 8)]
-                         + [(3, "hier16_40k")])
+                         + [(3, "hier16_40k"), (3, "readme_sim_retrys"), (2, "readme_defaults")])
 def test_smc_sharded_particles_equals_oracle(k, orc, gpu_ctx, world, name):
     """kabc_smc_run_dist_mode(KABC_SMC_DIST_PARTICLES) -- SURVEY §8e "SMC": the ranks OWN their particles;
     ε from all-gathered histograms of the order-preserving keys + a candidate gather, ESS from gathered
