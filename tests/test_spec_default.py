@@ -255,3 +255,64 @@ def test_cache_directory_is_bounded(k, monkeypatch, tmp_path):
     names = os.listdir(tmp_path)
     assert old.name not in names and stale.name not in names
     assert len([n for n in names if n.endswith(".co")]) == 1
+
+
+SHARED_CHILD = r"""
+import os, sys, json, time
+import ctypes as C
+import numpy as np
+sys.path.insert(0, {root!r})
+import kissabc_jl_amd as k
+prior = k.Factored(k.Normal(0, 5), k.Beta(2.75, 3.25))
+model = k.ApproxKernelizedPosterior(prior, k.costs.GaussDist([1.0, 0.5]), 0.1)
+# all children start their first call together
+while time.time() < {go!r}:
+    time.sleep(0.005)
+ens = k.AisEnsemble(model, 256, seed=9).init()
+out = [ens.advance(1, 3, collect=True)]
+t0 = time.time()
+while ens.spec_state()[0] == "pending" and time.time() - t0 < 240:
+    time.sleep(0.05)
+    out.append(ens.advance(1, 3, collect=True))
+state = ens.spec_state()[0]
+for _ in range(3):
+    out.append(ens.advance(1, 3, collect=True))
+cnt = (C.c_uint64 * 4)()
+k._lib.load().kabc_spec_counters(cnt)
+np.save({out!r}, np.concatenate(out))
+print(json.dumps(dict(state=state, spawned=int(cnt[0]), generations=len(out))), flush=True)
+"""
+
+
+@pytest.mark.gpu
+def test_processes_sharing_a_cold_cache_compile_a_unit_once(k, orc, gpu_ctx, tmp_path):
+    """four processes meet the same model at the same moment with an empty cache directory: the lock
+    file lets ONE of them start the worker, all of them switch to the unit it delivers, every trajectory
+    is the oracle's, and nothing is left behind in the cache but the code object"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    env = {k_: v for k_, v in os.environ.items() if k_ != "KABC_SPECIALIZE"}
+    env["KABC_RTC_CACHE_DIR"] = str(cache)
+    go = time.time() + 8.0
+    procs = [subprocess.Popen([sys.executable, "-c",
+                               SHARED_CHILD.format(root=root, go=go, out=str(tmp_path / f"x{i}.npy"))],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(4)]
+    res = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        res.append(json.loads(so.strip().splitlines()[-1]))
+    assert all(r["state"] == "active" for r in res), res
+    assert sum(r["spawned"] for r in res) == 1, res          # one worker for the four of them
+    prior = k.Factored(k.Normal(0, 5), k.Beta(2.75, 3.25))
+    model = k.ApproxKernelizedPosterior(prior, k.costs.GaussDist([1.0, 0.5]), 0.1)
+    gmax = max(r["generations"] for r in res)
+    ref = orc.OracleAIS(model, 256, seed=9).init().generations_sync(gmax, 3)
+    for i, r in enumerate(res):
+        assert np.array_equal(np.load(tmp_path / f"x{i}.npy"), ref[:r["generations"]]), i
+    left = sorted(os.listdir(cache))
+    assert len(left) == 1 and left[0].endswith(".co"), left
