@@ -389,6 +389,28 @@ def test_smc_sharded_particles_equals_oracle(k, orc, gpu_ctx, world, name):
         c.close()
 
 
+def test_smc_dist_mode_argument_errors(k, gpu_ctx):
+    import ctypes as C
+    from kissabc_jl_amd import _cdefs as cd
+    lib = k._lib.load()
+    comms = k.comm.init_all([0], "p2p")
+    prior = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    cost = k.costs.GaussDist([1.0, -0.5])
+    o, r, cc = cd.SmcOpts(), cd.SmcResult(), cost.to_c()
+    lib.kabc_smc_default_opts(C.byref(o))
+    assert lib.kabc_smc_run_dist_mode(comms[0].handle, prior.to_c(), 2, C.byref(cc), C.byref(o), 7, C.byref(r)) != 0
+    assert b"KABC_SMC_DIST_COST_LOOP or KABC_SMC_DIST_PARTICLES" in lib.kabc_last_error()
+    assert lib.kabc_smc_run_dist_mode(None, prior.to_c(), 2, C.byref(cc), C.byref(o), 1, C.byref(r)) != 0
+    assert b"communicator is NULL" in lib.kabc_last_error()
+    with pytest.raises(ValueError):
+        k.smc(prior, cost, comm=comms[0], shard="rows")
+    # a world of one rank: the sharded selection without a peer equals kabc_smc_run
+    a = k.smc(prior, cost, nparticles=5000, epstol=0.05, seed=2, return_array=True)
+    b = k.smc(prior, cost, nparticles=5000, epstol=0.05, seed=2, return_array=True, comm=comms[0], shard="particles")
+    assert a.eps == b.eps and np.array_equal(a.info["theta_all"], b.info["theta_all"]) and a.info["log"] == b.info["log"]
+    comms[0].close()
+
+
 def test_smc_sharded_particles_two_million(k, gpu_ctx):
     """the same at 2 097 152 particles x 16 parameters (C4's model) on 4 ranks, against kabc_smc_run on
     one GPU (which the parity suite pins to the oracle at the sizes the oracle finishes): several
