@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) wm_partition_kernel(const unsigned* sin, 
     sout[((v >> b) & 1u) ? (int64_t)*nz + ones : p - ones] = v;
 }
 
-// ---- the donor draw of medium ensembles (4096 .. 131 072 particles): TWO launches per generation
+// ---- the donor draw of medium ensembles (1536 .. 32 768 particles): TWO launches per generation
 // The rank structure above costs ~68 dependent launches per generation (an 8-pass radix sort of
 // 128-512 KB of keys, then a wavelet-matrix level per index bit): 242 us per generation at 16 384
 // particles, nearly all of it kernel boundaries.  The donor draw
@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(256) wm_partition_kernel(const unsigned* sin, 
 // 256 costs in index order with four ballots.  Same count, same m, same index as the scans and
 // the wavelet matrix.
 constexpr int kDbBlock = 256;                 // particles per sorted block
+constexpr int64_t kDbMinN = 1536;             // below: teams of sixteen lanes over the costs in LDS (measured
+                                              // crossover, profiles/r05_abcde_sizes.txt: 1000: 1.16 vs 1.23 ms per 50
+                                              // generations, 2000: 1.58 vs 1.27, 4000: 2.45 vs 1.33)
 constexpr int64_t kDbMaxN = 32768;            // beyond: the wavelet matrix (measured crossover: 32 768: 1.8 vs 3.1 ms per 10 generations, 65 536: 5.5 vs 4.2)
 constexpr int kDbMaxPerLane = (int)(kDbMaxN / kDbBlock / kWave);
 
@@ -538,7 +541,9 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
     // (KABC_ABCDE_RANK=wavelet | blocks: force one of the two structures from kRankMinN particles on)
     const char* rank_env = std::getenv("KABC_ABCDE_RANK");
     const bool force_wm = rank_env && rank_env[0] == 'w';
-    const bool use_blocks = N >= kRankMinN && !force_wm && N <= kDbMaxN;
+    int64_t blocks_from = kDbMinN;  // (KABC_ABCDE_BLOCKS_FROM: probes)
+    if (const char* e = std::getenv("KABC_ABCDE_BLOCKS_FROM")) blocks_from = std::atoll(e) > 0 ? std::atoll(e) : blocks_from;
+    const bool use_blocks = N >= blocks_from && !force_wm && N <= kDbMaxN;
     double* d_bsorted = nullptr;
     if (N >= kRankMinN && !use_blocks) {
         R.levels = 1;
@@ -563,7 +568,7 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
         A.wm_levels = R.levels;
         A.wm_words = R.words;
     }
-    // in between (256 <= N < 4096): the donor draws by teams of sixteen lanes, one launch per
+    // in between (256 <= N < 1536): the donor draws by teams of sixteen lanes, one launch per
     // generation in front of the generation kernel (KABC_ABCDE_DONOR=0: the kernel's own scans)
     int32_t* d_donor = nullptr;
     {

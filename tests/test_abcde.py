@@ -48,8 +48,8 @@ def test_abcde_bit_exact(k, orc, gpu_ctx, name):
 @pytest.mark.parametrize("structure", ["blocks", "wavelet"])
 @pytest.mark.parametrize("name", ["gauss_5000", "ties_4096", "early_9000", "power2_8192", "ragged_16500"])
 def test_abcde_rank_structure_bit_exact(k, orc, gpu_ctx, monkeypatch, name, structure):
-    """From 4096 particles on, the donor draw s = rand((1:N)[Δs .<= Δs[i]]) (src/smc.jl:392)
-    goes through a per-generation structure instead of two O(N) scans per particle: up to 131 072
+    """Larger ensembles: the donor draw s = rand((1:N)[Δs .<= Δs[i]]) (src/smc.jl:392)
+    goes through a per-generation structure instead of two O(N) scans per particle: up to 32 768
     particles the costs sorted in blocks of 256 consecutive particles and one wavefront per draw
     (two launches per generation; the default there), beyond -- and under KABC_ABCDE_RANK=wavelet
     -- the costs sorted globally (own LSD radix sort) and a wavelet matrix over the particle
@@ -92,17 +92,23 @@ def test_abcde_beyond_16_parameters_bit_exact(k, orc, gpu_ctx, D):
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,kw", [(2000, dict(generations=30)),
                                   (4095, dict(generations=8, alpha=0.3, earlystop=True)),
+                                  (1536, dict(generations=10)),
                                   (257, dict(generations=40, proposal_width=0.7))])
-def test_abcde_team_donor_draw_bit_exact(k, orc, gpu_ctx, monkeypatch, N, kw):
+def test_abcde_medium_donor_draws_bit_exact(k, orc, gpu_ctx, monkeypatch, N, kw):
     """256 <= N < 4096: the donor draw rand((1:N)[Δs .<= Δs[i]]) by teams of sixteen lanes
-    (abcde_donor_kernel; ragged last ranges at 4095 and 257, ties from a discrete prior) equals
-    the oracle's, and the generation kernel's own scans (KABC_ABCDE_DONOR=0) give the same run."""
+    (abcde_donor_kernel, the default below 1536 particles; ragged last ranges at 4095 and 257, ties from a
+    discrete prior), through block-sorted costs (the default from 1536 on; 257 particles: two blocks, one of
+    them a single particle), by the generation kernel's own scans (KABC_ABCDE_DONOR=0) and on whatever the
+    library picks itself: the oracle's run, every time."""
     pri = k.Factored(k.DiscreteUniform(-10, 10), k.Normal(0, 3))
     cost = k.costs.GaussDist([3.0, -2.0])
-    got = k.ABCDE(pri, cost, 0.5, nparticles=N, seed=11, return_array=True, **kw)
-    monkeypatch.setenv("KABC_ABCDE_DONOR", "0")
-    own = k.ABCDE(pri, cost, 0.5, nparticles=N, seed=11, return_array=True, **kw)
     ref = orc.abcde(pri, cost, 0.5, nparticles=N, seed=11, **kw)
-    for r in (got, own):
-        assert np.array_equal(r.P, ref["P"]) and np.array_equal(r.C, ref["C"])
-        assert r.info["generations_run"] == ref["generations_run"] and r.info["nsims"] == ref["nsims"]
+    for env in ({}, {"KABC_ABCDE_BLOCKS_FROM": "1000000000"}, {"KABC_ABCDE_BLOCKS_FROM": "256"},
+                {"KABC_ABCDE_BLOCKS_FROM": "1000000000", "KABC_ABCDE_DONOR": "0"}):
+        for name in ("KABC_ABCDE_BLOCKS_FROM", "KABC_ABCDE_DONOR"):
+            monkeypatch.delenv(name, raising=False)
+        for name, v in env.items():
+            monkeypatch.setenv(name, v)
+        r = k.ABCDE(pri, cost, 0.5, nparticles=N, seed=11, return_array=True, **kw)
+        assert np.array_equal(r.P, ref["P"]) and np.array_equal(r.C, ref["C"]), env
+        assert r.info["generations_run"] == ref["generations_run"] and r.info["nsims"] == ref["nsims"], env

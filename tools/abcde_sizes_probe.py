@@ -15,10 +15,12 @@ for N in [int(a) for a in sys.argv[1:]] or [50, 256, 1000, 2000, 4000, 8192, 163
     gens = 50 if N < 32768 else 10
     row = {"N": N, "generations": gens}
     for name, env in (("default", {"KABC_ABCDE_DONOR": "1"}), ("own_scans", {"KABC_ABCDE_DONOR": "0"}),
-                      ("wavelet", {"KABC_ABCDE_RANK": "wavelet"})):
-        if (name == "own_scans" and N >= 4096) or (name == "wavelet" and (N < 4096 or N > 131072)):
+                      ("wavelet", {"KABC_ABCDE_RANK": "wavelet"}), ("blocks", {"KABC_ABCDE_BLOCKS_FROM": "256"})):
+        if (name == "own_scans" and N >= 4096) or (name == "wavelet" and (N < 4096 or N > 131072)) or \
+                (name == "blocks" and (N < 256 or N >= 4096)):
             continue
         os.environ.pop("KABC_ABCDE_RANK", None)
+        os.environ.pop("KABC_ABCDE_BLOCKS_FROM", None)
         os.environ.update(env)
         kw = dict(nparticles=N, generations=gens, seed=3)
         k.ABCDE(N2, cost, 0.01, return_array=True, **kw)
