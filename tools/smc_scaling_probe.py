@@ -21,7 +21,7 @@ for N in [int(a) for a in sys.argv[1:]] or [32768, 65536, 131072, 524288, 209715
         walls.append(time.perf_counter() - t0)
     wall = sorted(walls)[1]
     it = r.info["iterations"]
-    print(json.dumps({"N": N, "loop_env": os.environ.get("KABC_SMC_LOOP"), "select2_from": os.environ.get("KABC_SMC_SELECT2_FROM"), "iterations": it, "wall_ms": wall * 1e3,
+    print(json.dumps({"N": N, "loop_env": os.environ.get("KABC_SMC_LOOP"), "iterations": it, "wall_ms": wall * 1e3,
                       "us_per_iteration": wall * 1e6 / it, "updates_per_s": r.info["proposals"] / wall,
                       "GBps_algorithmic": r.info["proposals"] * 545 / wall / 1e9,
                       "mcmc_kernel_avg_ms": r.info["kernel_ms_mcmc"]}), flush=True)
