@@ -1182,6 +1182,15 @@ PfLaunchFn pf_pick_attempt(int D, std::integer_sequence<int, Ds...>) {
     static const PfLaunchFn f[] = {&pf_l_attempt<Ds + 1>...};
     return f[D - 1];
 }
+template <int D>
+void pf_l_small(const PfSmallArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL((pf_small_kernel<D>), dim3(1), dim3(kPfSmallBlock), 0, s, a);
+}
+template <int... Ds>
+PfSmallLaunchFn pf_pick_small(int D, std::integer_sequence<int, Ds...>) {
+    static const PfSmallLaunchFn f[] = {&pf_l_small<Ds + 1>...};
+    return f[D - 1];
+}
 }  // namespace
 
 extern "C" {
@@ -1235,8 +1244,19 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     }
     // (run-time compiled kernels are loaded on the CURRENT device)
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t N = kabc_pfilter_nparticles(o->nparticles, o->q, D);
+    // Up to 256 particles (the reference's default is 100) with a built-in cost: the whole loop in one
+    // launch of ONE workgroup (pf_small_kernel; KABC_PF_SMALL=0 or KABC_PF_PASSES=1: the launches per
+    // phase).  At this size a model's own kernels would buy nothing: none are asked for.
+    bool small = false;
+    {
+        const char* e = std::getenv("KABC_PF_SMALL");
+        const char* pe = std::getenv("KABC_PF_PASSES");
+        small = N <= (int64_t)kPfSmallBlock && cost->id < KABC_COST_USER && !(e && e[0] == '0') && !(pe && pe[0] == '1');
+    }
     ModelUnit* unit = nullptr;
-    if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit)) return st;
+    if (kabc_status_t st = model_unit_for(prior, D, cost->id, &unit, !small)) return st;
+    if (unit && unit_required(unit)) small = false;  // (user prior families: only their unit knows them)
     if (unit) {  // user prior families / a specialised model (plugin_registry.hpp)
         const PluginKernel ki = unit_kernel(unit, kPfAbcdeInit, D, 0), ka = unit_kernel(unit, kPfAttempt, D, 0);
         if (ki.mod) f_init = AbcdeLaunch(ki.mod, &abcde_geom, (unsigned)kAbcdeBlock);
@@ -1267,7 +1287,6 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
         if (!f_init) f_init = b_init;
         if (!f_att) f_att = b_att;
     }
-    const int64_t N = kabc_pfilter_nparticles(o->nparticles, o->q, D);
     KABC_HIP_CHECK(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     DevBufs bufs;
@@ -1392,7 +1411,42 @@ kabc_status_t kabc_pfilter_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32
     // FOUR iterations enqueued per host round trip (kernels of iterations after the last are
     // no-ops); verbose runs look after every iteration, to print it.
     bool batched_done = false;
-    while (pf_loop) {
+    if (small && pf_loop) {
+        PfSmallArgs sm;
+        std::memset(&sm, 0, sizeof sm);
+        sm.pf = pa;
+        sm.pf.pending = nullptr;
+        sm.pf.idxok = nullptr;
+        sm.pf.sel = nullptr;
+        sm.q = o->q;
+        sm.eff_tol = o->eff_tol;
+        sm.epstol = o->epstol;
+        sm.max_iters = o->max_iters;
+        sm.iters_this_launch = o->verbose ? 1 : 0;
+        const PfSmallLaunchFn f_small = dyn ? &pf_l_small<0> : pf_pick_small(D, std::make_integer_sequence<int, KABC_MAX_DIM>{});
+        while (true) {
+            f_small(sm, s);
+            KABC_HIP_CHECK(hipGetLastError());
+            KABC_HIP_CHECK(hipMemcpyAsync(&hp, pctrl, sizeof hp, hipMemcpyDeviceToHost, s));
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+            if (hp.error == 9) {
+                set_error("pfilter: a particle was not replaced after 2^24 proposals");
+                return KABC_ERR_RETRY_EXHAUSTED;
+            }
+            if (hp.error) {
+                set_error("pfilter: quantile of the costs is undefined (NaN or empty)");
+                return KABC_ERR_NAN_COST;
+            }
+            if (o->verbose)
+                fprintf(stderr, "(iters, ϵ, eff) = (%lld, %.17g, %.17g)\n", (long long)hp.iters, hp.eps, hp.eff);
+            if (hp.done) break;
+        }
+        iters = hp.iters;
+        eps = hp.eps;
+        eff = hp.eff;
+        batched_done = true;
+    }
+    while (pf_loop && !batched_done) {
         const int kIterBatch = o->verbose ? 1 : 4;
         for (int b = 0; b < kIterBatch; ++b) {
             ++iters;
