@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256) wm_partition_kernel(const unsigned* sin, 
 // the wavelet matrix.
 constexpr int kDbBlock = 256;                 // particles per sorted block
 constexpr int64_t kDbMinN = 1536;             // below: teams of sixteen lanes over the costs in LDS (measured
-                                              // crossover, profiles/r05_abcde_sizes.txt: 1000: 1.16 vs 1.23 ms per 50
+                                              // crossover, profiles/r05_abcde_blocks_from.txt: 1000: 1.16 vs 1.23 ms per 50
                                               // generations, 2000: 1.58 vs 1.27, 4000: 2.45 vs 1.33)
 constexpr int64_t kDbMaxN = 32768;            // beyond: the wavelet matrix (measured crossover: 32 768: 1.8 vs 3.1 ms per 10 generations, 65 536: 5.5 vs 4.2)
 constexpr int kDbMaxPerLane = (int)(kDbMaxN / kDbBlock / kWave);

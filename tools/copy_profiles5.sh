@@ -22,6 +22,8 @@ cp $S/smc_scaling.jsonl $P/r05_smc_scaling.jsonl
 cp $S/abcde.json $P/r05_abcde.json
 cp $S/abcde_sizes.txt $P/r05_abcde_sizes.txt
 cp $S/pfilter.txt $P/r05_pfilter.txt
+cp $S/small_defaults.txt $P/r05_small_defaults.txt
+cp $S/smc_dist_modes.jsonl $P/r05_smc_dist_modes.jsonl
 cp $S/bench_emulated8.json $P/r05_bench_emulated8_rehearsal.json
 grep '^cycles' $S/pmc_collect.log | sed "s/^cycles //" > /tmp/_cyc.txt
 python3 - <<PY

@@ -30,8 +30,10 @@ python3 tools/spec_probe.py > $O/spec_probe.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/spec_stats -- python3 tools/spec_probe.py socks general4 hier16_sim > /dev/null 2>&1
 python3 tools/smc_scaling_probe.py 131072 524288 2097152 > $O/smc_scaling.jsonl 2>/dev/null
 python3 tools/abcde_probe.py > $O/abcde.json 2>/dev/null
-python3 tools/abcde_sizes_probe.py 1000 4000 4096 8192 16384 32768 65536 > $O/abcde_sizes.txt 2>/dev/null
+python3 tools/abcde_sizes_probe.py 256 1000 1536 2000 4000 4096 8192 16384 32768 65536 > $O/abcde_sizes.txt 2>/dev/null
 python3 tools/pfilter_probe.py > $O/pfilter.txt 2>/dev/null
+python3 tools/small_defaults_probe.py > $O/small_defaults.txt 2>/dev/null
+KABC_NO_TORCH_PRELOAD=1 python3 tools/smc_dist_probe.py > $O/smc_dist_modes.jsonl 2>/dev/null
 python3 tools/pmc_collect.py $O > $O/pmc_collect.log 2>&1
 python3 tools/config_sweep.py > $O/config_sweep.jsonl 2>/dev/null
 (rocm-smi --showclocks --showpower 2>/dev/null || true) > $O/rocm_smi_after.txt
