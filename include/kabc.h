@@ -33,10 +33,10 @@ extern "C" {
 
 #define KABC_VERSION 310 /* 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
-/* AIS and smc accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM run-time-dimension
- * kernels keep the walker / particle rows in memory (several times slower per evaluation, same
- * results).  User cost plugins follow.  ABCDE / pfilter stop at KABC_MAX_DIM.  The reference has
- * no bound (src/priors.jl:10-13). */
+/* AIS, smc, ABCDE and pfilter accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM
+ * run-time-dimension kernels keep the walker / particle rows in memory (several times slower per
+ * evaluation, same results).  Run-time compiled user costs and user prior families follow; a model's own
+ * specialised kernels stop at KABC_MAX_DIM.  The reference has no bound (src/priors.jl:10-13). */
 #define KABC_MAX_DIM_DYN 256
 /* AIS ensemble size: nparticles < 2^31 and (nparticles / 2) * length(prior) * 8 bytes < 4 GiB
  * (partner rows are addressed by a 32-bit byte offset into their half: 134 M walkers at
@@ -595,7 +595,9 @@ kabc_status_t kabc_abcde_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t
  * Rejection-refresh particle filter (exported, undocumented and untested in the
  * reference: parity is oracle-vs-device only).  Every iteration the particles above
  * the q-quantile of the costs are re-proposed from three distinct survivors until
- * they pass the prior-MH test and land below ϵ. */
+ * they pass the prior-MH test and land below ϵ.  Up to 256 particles with a built-in cost the whole loop
+ * is ONE launch of one workgroup (the reference's default N is 100); beyond, a selection launch + one launch
+ * in which every particle runs its rejection loop to the end, per iteration.  Same result either way. */
 typedef struct kabc_pfilter_opts {
     int64_t nparticles;     /* N (positional in the reference); raised to ceil((4D+1)/q) if N*q <= 4D */
     double q;               /* 0.7   */
