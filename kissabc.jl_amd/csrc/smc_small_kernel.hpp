@@ -53,15 +53,17 @@ struct SmcSmallArgs {
     const PriorDev* prior;  // [D] prepared components, device memory
 };
 
-// sum of a 0/1 flag over the workgroup (every thread gets it): wave ballots + one LDS line
-__device__ __forceinline__ unsigned small_count(bool f, unsigned* s_cnt, int wid, int lane) {
-    const unsigned long long b = __ballot(f);
-    if (lane == 0) s_cnt[wid] = (unsigned)__popcll(b);
+// sums of up to three 0/1 flags over the workgroup (every thread gets them), packed 10 bits each: wave
+// ballots, one LDS word per wave, ONE workgroup barrier.  The caller alternates between two lines
+// (`s_cnt`), so no trailing barrier is needed: a line is rewritten only after another barrier.
+__device__ __forceinline__ unsigned small_count3(bool f0, bool f1, bool f2, unsigned* s_cnt, int wid, int lane) {
+    const unsigned c = (unsigned)__popcll(__ballot(f0)) | ((unsigned)__popcll(__ballot(f1)) << 10) |
+                       ((unsigned)__popcll(__ballot(f2)) << 20);
+    if (lane == 0) s_cnt[wid] = c;
     __syncthreads();
     unsigned t = 0;
 #pragma unroll
     for (int w = 0; w < kSmallWaves; ++w) t += s_cnt[w];
-    __syncthreads();  // (s_cnt is reused by the next call)
     return t;
 }
 
@@ -71,7 +73,7 @@ __global__ void __launch_bounds__(kSmallBlock) smc_small_kernel(const SmcSmallAr
     __shared__ double s_X[kSmallBlock], s_lpi[kSmallBlock];
     __shared__ unsigned long long s_key[kSmallBlock];
     __shared__ int s_cidx[kSmallBlock];
-    __shared__ unsigned s_cnt[kSmallWaves];
+    __shared__ unsigned s_cnt[kSmallWaves], s_cntA[kSmallWaves], s_cntB[kSmallWaves];
     __shared__ double s_ab[3];  // the two bracketing order statistics, the minimum
     __shared__ PriorDev s_prior[D];
     __shared__ __attribute__((aligned(16))) double s_logtab[KABC_MATH_TAB_WORDS];
@@ -108,8 +110,8 @@ __global__ void __launch_bounds__(kSmallBlock) smc_small_kernel(const SmcSmallAr
     while (passes_left >= R) {
         // ================= Step 1 (:134-143): ε = quantile(Xs[alive], α), alive mask, ESS
         const double Xi = in ? s_X[tid] : 0.0;
-        const unsigned n = small_count(alive_i, s_cnt, wid, lane);
-        const unsigned nn = small_count(alive_i && Xi != Xi, s_cnt, wid, lane);
+        const unsigned nc = small_count3(alive_i, alive_i && Xi != Xi, false, s_cntA, wid, lane);
+        const unsigned n = nc & 1023u, nn = (nc >> 10) & 1023u;
         if (n == 0u || nn > 0u) {
             c.error = nn > 0u ? 1 : 2;
             c.done = 1;
@@ -246,15 +248,16 @@ __global__ void __launch_bounds__(kSmallBlock) smc_small_kernel(const SmcSmallAr
                     }
                 }
             }
-            const unsigned n_prop = small_count(alive_i, s_cnt, wid, lane);  // (also: every read of the frozen rows is done)
+            // (the barrier inside: every read of the frozen rows is done)
+            const unsigned pc = small_count3(alive_i, acc, evald, s_cntB, wid, lane);
+            const unsigned n_prop = pc & 1023u, n_acc = (pc >> 10) & 1023u, n_eval = pc >> 20;
             if (acc) {
 #pragma unroll
                 for (int k = 0; k < D; ++k) s_th[tid][k] = nth[k];
                 s_X[tid] = nX;
                 s_lpi[tid] = nlp;
             }
-            const unsigned n_acc = small_count(acc, s_cnt, wid, lane);
-            const unsigned n_eval = small_count(evald, s_cnt, wid, lane);
+            if (R > 1) __syncthreads();  // (a retry pass reads the rows just written; uniform)
             c.accepted += n_acc;
             c.cost_evals += n_eval;
             c.proposals += n_prop;
