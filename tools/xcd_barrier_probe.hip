@@ -126,16 +126,44 @@ __device__ __forceinline__ void xcd_barrier_inv1(Bar* b, unsigned nb, unsigned x
     __syncthreads();
 }
 
+// MODE 3 (round 5): the release side without a returning atomic on the critical path.  Every workgroup counts
+// itself on its XCD with a fire-and-forget atomic; ONE workgroup per XCD (the first that registered: the
+// leader) polls that counter, writes the XCD's L2 back when it is full and counts the XCD on the global
+// counter, again without waiting for the result; everybody polls the global counter.  The last workgroup's
+// chain is store drain -> atomic -> (leader sees it) -> write-back -> atomic -> (pollers see it) instead of
+// store drain -> atomic round trip -> write-back -> atomic round trip -> store -> (pollers see it).
+__device__ __forceinline__ void xcd_barrier_leader(Bar* b, unsigned nb, unsigned xcd, unsigned members, unsigned nxcd,
+                                                   bool leader) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        (void)__hip_atomic_fetch_add(&b->xcount[xcd].v, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (leader) {
+            spin_until(&b->xcount[xcd].v, (unsigned long long)(nb + 1u) * members);
+            asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+            (void)__hip_atomic_fetch_add(&b->gcount.v, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        spin_until(&b->gcount.v, (unsigned long long)(nb + 1u) * nxcd);
+        asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(256) k_check(double* buf0, double* buf1, unsigned rows, int iters, Bar* bar,
                                                unsigned long long* errors, unsigned* xcd_of) {
     const unsigned G = gridDim.x;
     unsigned xcd = 0, members = 0, nxcd = 0;
     unsigned nb = 0;
+    __shared__ int s_leader;
     if (MODE >= 1) {
         xcd = xcc_id();
         if (threadIdx.x == 0) {
-            if (atomicAdd(&bar->members[xcd].v, 1ull) == 0ull) atomicAdd(&bar->nxcd.v, 1ull);
+            s_leader = 0;
+            if (atomicAdd(&bar->members[xcd].v, 1ull) == 0ull) {
+                atomicAdd(&bar->nxcd.v, 1ull);
+                s_leader = 1;
+            }
             xcd_of[blockIdx.x] = xcd;
         }
         plain_barrier(bar, G, nb++);
@@ -157,7 +185,8 @@ __global__ void __launch_bounds__(256) k_check(double* buf0, double* buf1, unsig
         }
         if (MODE == 0) plain_barrier(bar, G, nb);
         else if (MODE == 1) xcd_barrier(bar, nb - 1u, xcd, members, nxcd);
-        else xcd_barrier_inv1(bar, nb - 1u, xcd, members, nxcd);
+        else if (MODE == 2) xcd_barrier_inv1(bar, nb - 1u, xcd, members, nxcd);
+        else xcd_barrier_leader(bar, nb - 1u, xcd, members, nxcd, s_leader != 0);
         ++nb;
         const unsigned r = mix(blockIdx.x, threadIdx.x & 15u) % rows;  // L1-resident across iterations
         const double2* q = reinterpret_cast<const double2*>(w + (size_t)r * 8);
@@ -186,7 +215,7 @@ int main() {
     for (unsigned G : {32u, 64u, 128u, 256u, 512u}) {
         unsigned rows = G * 64u;
         int iters = 2000;
-        for (int mode = 0; mode < 3; ++mode) {
+        for (int mode = 0; mode < 4; ++mode) {
             float ms = 0.f;
             unsigned long long herr = 0;
             for (int rep = 0; rep < 2; ++rep) {
@@ -196,14 +225,14 @@ int main() {
                 CK(hipMemset(b1, 0, nbuf));
                 void* args[] = {&b0, &b1, &rows, &iters, &bar, &err, &xcd_of};
                 CK(hipEventRecord(e0));
-                CK(hipLaunchCooperativeKernel(mode == 0 ? (void*)k_check<0> : mode == 1 ? (void*)k_check<1> : (void*)k_check<2>,
+                CK(hipLaunchCooperativeKernel(mode == 0 ? (void*)k_check<0> : mode == 1 ? (void*)k_check<1> : mode == 2 ? (void*)k_check<2> : (void*)k_check<3>,
                                               dim3(G), dim3(256), args, 0, 0));
                 CK(hipEventRecord(e1));
                 CK(hipEventSynchronize(e1));
                 CK(hipEventElapsedTime(&ms, e0, e1));
                 CK(hipMemcpy(&herr, err, 8, hipMemcpyDeviceToHost));
             }
-            const char* nm = mode == 0 ? "plain" : mode == 1 ? "xcd_l1inv_sc0" : "xcd_release_only";
+            const char* nm = mode == 0 ? "plain" : mode == 1 ? "xcd_l1inv_sc0" : mode == 2 ? "xcd_release_only" : "xcd_leader";
             printf(", \"%s_%u\": %.3f, \"%s_errors_%u\": %llu", nm, G, ms * 1e3 / iters, nm, G, herr);
             if (mode == 1) {
                 unsigned h[512], cnt[16] = {};
