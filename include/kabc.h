@@ -207,7 +207,9 @@ kabc_status_t kabc_compile_cost_plugin(const char* src, const int32_t* dims, int
  * use.  family: 0 AIS half-generation (variant = prior class + 4 * (posterior kind - 1); prior
  * class 0 box, 1 constant/Gaussian-in-a-box, 2 general), 1 AIS init, 2 smc propose+accept
  * (variant = 1 for priors without Beta / Gamma / LogNormal / NegativeBinomial components, else
- * 0), 3 smc init, 4 smc persistent loop, 5 / 6 ABCDE init / generation, 7 pfilter attempt. */
+ * 0), 3 smc init, 4 smc persistent loop, 5 / 6 ABCDE init / generation, 7 pfilter attempt,
+ * 10 the one-workgroup smc driver, 13 the one-workgroup AIS driver of small ensembles (variant as
+ * family 0; prior classes 0 and 2). */
 kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family, int32_t D, int32_t variant);
 
 /* ---- user prior families ------------------------------------------------------
@@ -234,8 +236,8 @@ kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family, int32_t D,
 kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32_t* out_kind);
 
 /* ---- kernels specialised for ONE model ------------------------------------------
- * Compiles the kernel families of `families` (bit 0 AIS, 1 smc, 2 ABCDE, 3 pfilter; 0 = AIS +
- * smc) for exactly this prior tuple and cost: every component's family and parameters are
+ * Compiles the kernel families of `families` (bit 0 AIS, 1 smc, 2 ABCDE, 3 pfilter, 4 AIS of small
+ * ensembles; 0 = AIS + smc) for exactly this prior tuple and cost: every component's family and parameters are
  * compile-time constants of the generated translation unit -- no family dispatch, no
  * per-component parameter records in LDS, the normalisers folded.  Results are bit-identical to
  * the prebuilt kernels' (same formulas, same operation order).  Afterwards kabc_ais_create* /
@@ -253,6 +255,7 @@ kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32
 #define KABC_FAMILY_SMC 2
 #define KABC_FAMILY_ABCDE 4
 #define KABC_FAMILY_PFILTER 8
+#define KABC_FAMILY_AIS_SMALL 16 /* the AIS kernel of small ensembles (kabc_ais_driver) */
 kabc_status_t kabc_compile_model(const kabc_model_t* model, int32_t families, int32_t* out_handle);
 kabc_status_t kabc_model_release(int32_t handle);
 /* THE DEFAULT (KABC_SPECIALIZE unset): kabc_ais_create* / kabc_smc_run / kabc_abcde_run /
@@ -363,6 +366,13 @@ kabc_status_t kabc_ais_get_stats(kabc_ais_t* h, kabc_stats_t* stats);
  * *launches_before_switch = launches that ran on the prebuilt kernels before the model's own
  * took over (0: specialised from the first launch; -1: not switched) */
 kabc_status_t kabc_ais_spec_state(kabc_ais_t* h, int32_t* state, int64_t* launches_before_switch);
+/* Which driver kabc_ais_advance runs this handle on: 1 = the one-workgroup kernel of small
+ * ensembles (every generation of a call in ONE launch of one workgroup per chain, both halves in
+ * LDS: csrc/ais_small_kernel.hpp -- nparticles <= 512, <= 256 from nine parameters on; the shape
+ * of every sample() call in the reference's tests and examples, src/KissABC.jl:66-80,
+ * test/runtests.jl:82-131), 0 = one launch per half-generation.  Same bits either way.
+ * KABC_AIS_SMALL=0 in the environment of kabc_ais_create* keeps every handle on 0. */
+int32_t kabc_ais_driver(const kabc_ais_t* h);
 /* number of walkers this handle owns, and per half */
 int64_t kabc_ais_owned(const kabc_ais_t* h, int32_t half);
 /* Per-launch timing: bracket each of the next `max_launches` half-generation

@@ -23,7 +23,7 @@ PRIOR_UNIFORM, PRIOR_NORMAL, PRIOR_TRUNCNORMAL, PRIOR_BETA, PRIOR_DISCRETE_UNIFO
 PRIOR_USER_INIT = 10
 PRIOR_MVNORMAL = 11
 PRIOR_USER = 100         # kinds >= this: families compiled at run time (kabc_compile_prior_plugin)
-FAMILY_AIS, FAMILY_SMC, FAMILY_ABCDE, FAMILY_PFILTER = 1, 2, 4, 8
+FAMILY_AIS, FAMILY_SMC, FAMILY_ABCDE, FAMILY_PFILTER, FAMILY_AIS_SMALL = 1, 2, 4, 8, 16
 
 POSTERIOR_KERNELIZED, POSTERIOR_THRESHOLD, POSTERIOR_COMMON = 1, 2, 3
 
@@ -133,6 +133,7 @@ PROTOTYPES = {
     "kabc_spec_counters": (C.c_int, [C.POINTER(C.c_uint64)]),
     "kabc_rtc_worker_main": (C.c_int32, [C.c_char_p]),
     "kabc_ais_spec_state": (C.c_int, [VP, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    "kabc_ais_driver": (C.c_int32, [VP]),
     "kabc_ais_create": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_uint64, C.POINTER(VP)]),
     "kabc_ais_create_batch": (C.c_int, [VP, C.POINTER(Model), C.c_int64, C.c_int32,
                                         C.POINTER(C.c_uint64), C.POINTER(VP)]),

@@ -263,6 +263,12 @@ class AisEnsemble:
         _lib.check(_lib.load().kabc_ais_spec_state(self._h, C.byref(st), C.byref(n)))
         return self.SPEC_STATES[st.value], n.value
 
+    @property
+    def driver(self):
+        """"small": kabc_ais_advance runs every generation of a call in one launch of one workgroup
+        per chain (csrc/ais_small_kernel.hpp); "halves": one launch per half-generation."""
+        return "small" if _lib.load().kabc_ais_driver(self._h) else "halves"
+
     def ensemble(self):
         """[N][D] unrounded positions of ALL walkers in walker-id order (for a sharded
         handle: this rank's copy after the last all-gather)."""

@@ -7,7 +7,7 @@
 // with two s_mov_b32 at every use (scalar registers are what this kernel is short of).  Same
 // v_fma_f64, same results; -0.8 % per launch at ntransitions = 100, -3 % at 1.
 #define KABC_FMA_C_VGPR
-#include "ais_kernels.hpp"
+#include "ais_small_kernel.hpp"
 
 #ifndef KABC_INST_COST
 #error "compile with -DKABC_INST_COST=<cost id>"
@@ -60,10 +60,40 @@ static AisLaunchFn table(int D, int pcx, std::integer_sequence<int, PCXs...>) {
     return r;
 }
 
+// the one-workgroup kernel of small ensembles (ais_small_kernel.hpp): the classes BOX, NORMAL and
+// GENERAL (a SIMPLE prior runs on GENERAL: same bits; the model's own kernel replaces it anyway),
+// not for a cost with a grid-wide pre-pass (ais_aux_kernels.hpp)
+template <int COST, int D, int PCX>
+static AisSmallLaunchFn pick_small() {
+    constexpr int pc = PCX % kPriorClasses;
+    constexpr bool is_normal = pc == kPriorNormal;
+    constexpr bool pc_ok = KABC_INST_PCSEL == 0 || (KABC_INST_PCSEL == 1) == is_normal;
+    if constexpr (pc_ok && pc != kPriorSimple && COST != KABC_COST_NORMAL_MEANSTD_SIM && D >= KABC_INST_DLO &&
+                  D <= KABC_INST_DHI && cost_dim_ok_c(COST, D))
+        return &launch_ais_small<D, COST, pc, PCX / kPriorClasses + 1>;
+    else return nullptr;
+}
+template <int COST, int PCX, int... Ds>
+static AisSmallLaunchFn row_small(int D, std::integer_sequence<int, Ds...>) {
+    AisSmallLaunchFn f[] = {pick_small<COST, Ds + 1, PCX>()...};
+    return (D >= 1 && D <= (int)sizeof...(Ds)) ? f[D - 1] : nullptr;
+}
+template <int COST, int... PCXs>
+static AisSmallLaunchFn table_small(int D, int pcx, std::integer_sequence<int, PCXs...>) {
+    using Dims = std::make_integer_sequence<int, KABC_MAX_DIM>;
+    AisSmallLaunchFn r = nullptr;
+    ((pcx == PCXs ? (void)(r = row_small<COST, PCXs>(D, Dims{})) : (void)0), ...);
+    return r;
+}
+
 #define KABC_CAT2(a, b) a##b
 #define KABC_CAT(a, b) KABC_CAT2(a, b)
 AisLaunchFn KABC_CAT(KABC_CAT(find_ais_kernel_cost_, KABC_INST_COST), KABC_INST_SUFFIX)(int D, int pcx) {
     return table<KABC_INST_COST>(D, pcx, std::make_integer_sequence<int, kAisVariants>{});
+}
+
+AisSmallLaunchFn KABC_CAT(KABC_CAT(find_ais_small_kernel_cost_, KABC_INST_COST), KABC_INST_SUFFIX)(int D, int pcx) {
+    return table_small<KABC_INST_COST>(D, pcx, std::make_integer_sequence<int, kAisVariants>{});
 }
 
 }  // namespace kabc

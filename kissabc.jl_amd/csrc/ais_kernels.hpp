@@ -130,17 +130,21 @@ struct SubStepIx {  // a sub-step's index within its chunk, as a type
     static constexpr int value = Q;
 };
 
-template <int D>
-struct ChunkRec {
-    uint32_t mva[kChunk][kBatch];   // (move << 30) | partner row a
-    uint32_t bb[kChunk][kBatch];    // partner row b (DE, walk)
-    uint32_t cc[kChunk][kBatch];    // partner row c (walk)
-    double logu[kChunk][kBatch];    // log(u) = -randexp(rng)          (src/types.jl:74)
+// (CH sub-steps per buffer: kChunk for the half-generation kernel, 1 for a ring slot of the
+// one-workgroup kernel of ais_small_kernel.hpp)
+template <int D, int CH>
+struct RecBuf {
+    uint32_t mva[CH][kBatch];   // (move << 30) | partner row a
+    uint32_t bb[CH][kBatch];    // partner row b (DE, walk)
+    uint32_t cc[CH][kBatch];    // partner row c (walk)
+    double logu[CH][kBatch];    // log(u) = -randexp(rng)          (src/types.jl:74)
     // stretch: zs[0] = Z, zs[1] = (D-1) log Z     (src/transition.jl:56-58)
     // de     : zs[0] = gamma, zs[1..D] = randn per coordinate (:3, :13)
     // walk   : zs[0..2] = the three randn           (:38-40)
-    double zs[kChunk][RecGeom<D>::NZ][kBatch];
+    double zs[CH][RecGeom<D>::NZ][kBatch];
 };
+template <int D>
+using ChunkRec = RecBuf<D, kChunk>;
 
 template <int POSTERIOR_RUNTIME = 0>
 __device__ __forceinline__ bool ld_valid(int posterior, double lp, double ll) {
@@ -385,13 +389,18 @@ struct NoMid {
 };
 // `mid()` runs as soon as the partner rows of the sub-step (mva, bb, cc) are in the record: the
 // prologue passes a workgroup barrier there, behind which the consumer requests its first rows.
-template <int D, class Mid = NoMid>
-__device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t seed,
-                                                ChunkRec<D>& R, int si,
+// WALK = false (ais_small_kernel.hpp: the producers run ahead of the half-steps, so the partner rows a
+// walk displacement is made of are not final yet): the three normals stay in zs[0..2], listB
+// [nDE, nDE + nWK) names the walk lanes and counts = {nDE, nWK}; the consumer finishes the displacement.
+// Args: anything with n_comp, x_comp (WALK only) and ablate.
+template <int D, class Mid = NoMid, bool WALK = true, class Rec = ChunkRec<D>, class Args = AisArgs>
+__device__ __forceinline__ void produce_substep(const Args& A, const uint64_t seed,
+                                                Rec& R, int si,
                                                 uint64_t t, uint32_t w_base, int n_active,
                                                 uint8_t* listB, int lane,
                                                 const double* logtab,
-                                                const kabc_u128_t* pre01 = nullptr, Mid mid = Mid()) {
+                                                const kabc_u128_t* pre01 = nullptr, Mid mid = Mid(),
+                                                int32_t* counts = nullptr) {
     constexpr int NB = RecGeom<D>::NB;
     const uint64_t nc = (uint64_t)A.n_comp;
     const bool active = lane < n_active;
@@ -467,10 +476,17 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t
             vc = *reinterpret_cast<const double*>(cb + (size_t)(R.cc[si][l] * (uint32_t)(D * 8) + ko));
         }
     };
-    int wl0, wl1;
+    int wl0 = -1, wl1 = -1;
     double wa0, wb0, wc0, wa1, wb1, wc1;  // (defined exactly where wl0 / wl1 >= 0)
-    walk_fetch(0, wl0, wa0, wb0, wc0);
-    walk_fetch(1, wl1, wa1, wb1, wc1);
+    if constexpr (WALK) {
+        walk_fetch(0, wl0, wa0, wb0, wc0);
+        walk_fetch(1, wl1, wa1, wb1, wc1);
+    } else {
+        if (counts && lane == 0) {
+            counts[0] = nDE;
+            counts[1] = nWK;
+        }
+    }
     // -- phase N: Box-Muller blocks, dense
 #pragma unroll 1
     for (int e = lane; e < ((KABL & 8) ? 0 : nN); e += kWave) {
@@ -510,14 +526,16 @@ __device__ __forceinline__ void produce_substep(const AisArgs& A, const uint64_t
             R.zs[si][wk][l] = z0 * (va - Xs) + z1 * (vb - Xs) + z2 * (vc - Xs);
         }
     };
-    if (nWK > 0) walk_finish(wl0, wa0, wb0, wc0);
-    if (nWK > kWPP) walk_finish(wl1, wa1, wb1, wc1);
+    if constexpr (WALK) {
+        if (nWK > 0) walk_finish(wl0, wa0, wb0, wc0);
+        if (nWK > kWPP) walk_finish(wl1, wa1, wb1, wc1);
 #pragma unroll 1
-    for (int pass = 2; pass * kWPP < nWK; ++pass) {
-        int l;
-        double va, vb, vc;
-        walk_fetch(pass, l, va, vb, vc);
-        walk_finish(l, va, vb, vc);
+        for (int pass = 2; pass * kWPP < nWK; ++pass) {
+            int l;
+            double va, vb, vc;
+            walk_fetch(pass, l, va, vb, vc);
+            walk_finish(l, va, vb, vc);
+        }
     }
 }
 

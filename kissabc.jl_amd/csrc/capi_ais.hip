@@ -11,6 +11,7 @@
 
 #include "ais_aux_kernels.hpp"
 #include "ais_dyn_kernels.hpp"
+#include "ais_small_kernel.hpp"
 #include "host_common.hpp"
 #include "plugin_registry.hpp"
 
@@ -18,10 +19,13 @@ namespace kabc {
 
 // (three translation units per cost, csrc/Makefile: dimensions 1..7 of the NORMAL prior class,
 // 1..7 of the other classes, 8..KABC_MAX_DIM)
-#define KABC_DECL_COST(id)                                     \
-    AisLaunchFn find_ais_kernel_cost_##id(int D, int pc);      \
-    AisLaunchFn find_ais_kernel_cost_##id##_nrm(int D, int pc); \
-    AisLaunchFn find_ais_kernel_cost_##id##_hi(int D, int pc);
+#define KABC_DECL_COST(id)                                                \
+    AisLaunchFn find_ais_kernel_cost_##id(int D, int pc);                 \
+    AisLaunchFn find_ais_kernel_cost_##id##_nrm(int D, int pc);           \
+    AisLaunchFn find_ais_kernel_cost_##id##_hi(int D, int pc);            \
+    AisSmallLaunchFn find_ais_small_kernel_cost_##id(int D, int pc);      \
+    AisSmallLaunchFn find_ais_small_kernel_cost_##id##_nrm(int D, int pc); \
+    AisSmallLaunchFn find_ais_small_kernel_cost_##id##_hi(int D, int pc);
 KABC_DECL_COST(1)
 KABC_DECL_COST(2)
 KABC_DECL_COST(3)
@@ -62,6 +66,37 @@ AisLaunch find_ais_kernel(int cost_id, int D, int pc) {
             return nullptr;
         }
     }
+}
+
+// the one-workgroup kernel of small ensembles (ais_small_kernel.hpp); pcx's prior class is BOX,
+// NORMAL or GENERAL (small_class below)
+static AisSmallLaunchFn ais_small_pick(int D, int pc, AisSmallLaunchFn (*lo)(int, int), AisSmallLaunchFn (*nrm)(int, int),
+                                       AisSmallLaunchFn (*hi)(int, int)) {
+    if (D > kAisInstSplit) return hi(D, pc);
+    return (pc % kPriorClasses) == kPriorNormal ? nrm(D, pc) : lo(D, pc);
+}
+AisSmallLaunch find_ais_small_kernel(int cost_id, int D, int pc) {
+#define KABC_SMALL_CASE(id) \
+    case id: return AisSmallLaunch(ais_small_pick(D, pc, find_ais_small_kernel_cost_##id, find_ais_small_kernel_cost_##id##_nrm, find_ais_small_kernel_cost_##id##_hi));
+    switch (cost_id) {
+        KABC_SMALL_CASE(1)
+        KABC_SMALL_CASE(2)
+        KABC_SMALL_CASE(3)
+        KABC_SMALL_CASE(4)
+        KABC_SMALL_CASE(5)
+        KABC_SMALL_CASE(6)
+        KABC_SMALL_CASE(7)
+        KABC_SMALL_CASE(8)
+        KABC_SMALL_CASE(9)
+        KABC_SMALL_CASE(10)
+        KABC_SMALL_CASE(11)
+        default: {
+            const PluginKernel k = plugin_kernel(find_plugin(cost_id), kPfAisSmall, D, pc);
+            if (k.mod) return AisSmallLaunch(k.mod, &ais_small_geom, (unsigned)kAisSmallBlock);
+            return AisSmallLaunch();
+        }
+    }
+#undef KABC_SMALL_CASE
 }
 
 template <int D>
@@ -148,7 +183,15 @@ struct kabc_ais {
     PriorDev* d_prior;            // [KABC_MAX_DIM] prepared components
     uint64_t seed, t;
     int32_t rank, world;
-    AisLaunch launch;
+    AisLaunch launch;      // half-generation kernel (a small-ensemble handle resolves it at first need)
+    int32_t pc;            // its prior class
+    // the one-workgroup driver of small ensembles (ais_small_kernel.hpp): kabc_ais_advance runs every
+    // generation of a call in ONE launch; spec_state / spec_variant then describe THIS kernel
+    bool small_ok;
+    AisSmallLaunch small;
+    int32_t small_pcx;     // the prebuilt table's variant (prior class BOX / NORMAL / GENERAL + posterior kind)
+    double* d_strace;      // its device trace buffer
+    size_t strace_cap;     // bytes
     ModelUnit* unit;       // run-time compiled unit (user prior families / specialised model), else NULL
     // the model's own kernels (the default, non-blocking specialisation: plugin_registry.hpp)
     int32_t spec_state;    // KABC_SPEC_*
@@ -256,6 +299,35 @@ static kabc_status_t ais_alloc(kabc_ais_t* h, const kabc_model_t* m, void* ext0,
     KABC_HIP_CHECK(dev_malloc(&h->d_slots, sizeof(unsigned long long) * kCounterSlots * 8));
     KABC_HIP_CHECK(hipMemsetAsync(h->d_slots, 0, sizeof(unsigned long long) * kCounterSlots * 8, s));
     KABC_HIP_CHECK(hipStreamSynchronize(s));
+    return KABC_OK;
+}
+
+// the half-generation kernel of a handle: the unit's (user prior families; a specialisation that is
+// there already), else the prebuilt one of the prior's class
+static kabc_status_t ais_resolve_half(kabc_ais_t* h) {
+    if (h->dyn) return KABC_OK;
+    const bool track = !h->small_ok;  // (a small-ensemble handle's spec_state describes its small kernel)
+    AisLaunch fn;
+    const int pk_off = kPriorClasses * (h->posterior - 1);
+    if (h->unit) {
+        int st = KABC_SPEC_NONE;
+        PluginKernel uk;
+        if (track || unit_required(h->unit)) uk = unit_kernel(h->unit, kPfAis, h->D, h->spec_variant, &st);
+        if (uk.mod) fn = AisLaunch(uk.mod, &ais_half_geom, (unsigned)kAisBlock);
+        if (track) h->spec_state = st;
+        // user families: there are no other kernels (message set by the compilation / load)
+        if (!fn && unit_required(h->unit)) return KABC_ERR_DEVICE;
+    }
+    if (!fn) {  // (no unit, or a specialisation that is not there (yet): the prebuilt kernels)
+        fn = find_ais_kernel(h->cost_id, h->D, h->pc + pk_off);
+        if (!fn && h->pc == kPriorNormal)  // plugins instantiate SIMPLE only
+            fn = find_ais_kernel(h->cost_id, h->D, kPriorSimple + pk_off);
+    }
+    if (!fn) {
+        if (!get_error()[0]) set_error("no gfx950 kernel instantiated for cost id %d, D = %d", h->cost_id, h->D);
+        return KABC_ERR_UNSUPPORTED;
+    }
+    h->launch = fn;
     return KABC_OK;
 }
 
@@ -374,24 +446,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
             return KABC_ERR_UNSUPPORTED;
         }
     }
-    AisLaunch fn;
-    int spec_state = KABC_SPEC_NONE;
     const int spec_variant = kPriorGeneral + kPriorClasses * (m->posterior - 1);
-    if (unit && !dyn) {
-        const PluginKernel uk = unit_kernel(unit, kPfAis, m->D, spec_variant, &spec_state);
-        if (uk.mod) fn = AisLaunch(uk.mod, &ais_half_geom, (unsigned)kAisBlock);
-        // user families: there are no other kernels (message set by the compilation / load)
-        if (!fn && unit_required(unit)) return KABC_ERR_DEVICE;
-    }
-    if (!fn) {  // (no unit, or a specialisation that is not there (yet): the prebuilt kernels)
-        fn = dyn ? AisLaunch() : find_ais_kernel(m->cost.id, m->D, pc + kPriorClasses * (m->posterior - 1));
-        if (!fn && !dyn && pc == kPriorNormal)  // plugins instantiate SIMPLE only
-            fn = find_ais_kernel(m->cost.id, m->D, kPriorSimple + kPriorClasses * (m->posterior - 1));
-    }
-    if (!fn && !dyn) {
-        set_error("no gfx950 kernel instantiated for cost id %d, D = %d", m->cost.id, m->D);
-        return KABC_ERR_UNSUPPORTED;
-    }
     kabc_ais_t* h = new kabc_ais_t();
     h->ctx = ctx;
     h->D = m->D;
@@ -400,7 +455,6 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->eps = m->eps;
     std::memset(h->raw, 0, sizeof h->raw);
     std::memset(&h->prior, 0, sizeof h->prior);
-    h->dyn = dyn_fn;
     h->d_raw = nullptr;
     h->d_scratch = nullptr;
     bool prior_ok = true;
@@ -418,12 +472,55 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
         set_error("invalid prior parameters");
         return KABC_ERR_INVALID_ARG;
     }
-    h->launch = fn;
     h->unit = unit;
-    h->spec_state = spec_state;
+    h->pc = pc;
+    h->spec_state = KABC_SPEC_NONE;
     h->spec_variant = spec_variant;
     h->launches = 0;
-    h->spec_switch_at = spec_state == KABC_SPEC_ACTIVE ? 0 : -1;
+    h->small_ok = false;
+    h->d_strace = nullptr;
+    h->strace_cap = 0;
+    // Small ensembles (both halves fit one workgroup's LDS, ais_small_kernel.hpp): one workgroup per
+    // chain runs every generation of a kabc_ais_advance call in one launch.  Not for sharded handles,
+    // caller-lent halves, the run-time-dimension kernels, nor a cost with a grid-wide pre-pass
+    // (ais_aux_kernels.hpp); KABC_AIS_SMALL=0 keeps the launch per half-generation.
+    {
+        const char* e = std::getenv("KABC_AIS_SMALL");
+        const bool off = e && e[0] == '0';
+        if (!off && !dyn && !comm && world == 1 && ext0 == nullptr &&
+            (n_total + 1) / 2 <= (int64_t)ais_small_rmax(m->D) && aux_prepass_words(m->cost.id) == 0) {
+            const int pk_off = kPriorClasses * (m->posterior - 1);
+            // prebuilt classes of the small kernel: BOX, NORMAL up to kAisInstSplit parameters (the two
+            // the default path never specialises), GENERAL for everything else -- same bits
+            const bool plug = m->cost.id >= KABC_COST_USER;
+            const int spc = isbox ? kPriorBox : (allnormal && m->D <= kAisInstSplit && !plug) ? kPriorNormal : kPriorGeneral;
+            h->small_pcx = spc + pk_off;
+            AisSmallLaunch sfn;
+            int st = KABC_SPEC_NONE;
+            if (unit) {
+                const PluginKernel uk = unit_kernel(unit, kPfAisSmall, m->D, spec_variant, &st);
+                if (uk.mod) sfn = AisSmallLaunch(uk.mod, &ais_small_geom, (unsigned)kAisSmallBlock);
+            }
+            if (!sfn && !(unit && unit_required(unit))) sfn = find_ais_small_kernel(m->cost.id, m->D, h->small_pcx);
+            if (sfn) {
+                h->small = sfn;
+                h->small_ok = true;
+                h->spec_state = st;
+            } else {
+                set_error("%s", "");  // (no small kernel for this model: the launch per half-generation serves)
+            }
+        }
+    }
+    h->dyn = dyn_fn;
+    if (!h->small_ok || (m->cost.id < KABC_COST_USER && !(unit && unit_required(unit)))) {
+        // (a small-ensemble handle of a user cost / user prior families compiles its half-generation
+        // kernel only when somebody asks for one: kabc_ais_half_generation)
+        if (kabc_status_t st = ais_resolve_half(h)) {
+            delete h;
+            return st;
+        }
+    }
+    h->spec_switch_at = h->spec_state == KABC_SPEC_ACTIVE ? 0 : -1;
     // BOX class: logpdf inside the box = c0_1 + ... + c0_D, summed left to right
     // exactly as logpdf(d::Factored, x) does (src/priors.jl:30-36)
     h->box_lp = h->prior.c[0].c0;
@@ -792,9 +889,10 @@ static void ais_poll_spec(kabc_ais_t* h) {
     if (now < h->spec_next_poll) return;
     h->spec_next_poll = now + std::chrono::milliseconds(2);
     int st = KABC_SPEC_NONE;
-    const PluginKernel k = unit_kernel(h->unit, kPfAis, h->D, h->spec_variant, &st);
+    const PluginKernel k = unit_kernel(h->unit, h->small_ok ? kPfAisSmall : kPfAis, h->D, h->spec_variant, &st);
     if (st == KABC_SPEC_ACTIVE && k.mod) {
-        h->launch = AisLaunch(k.mod, &ais_half_geom, (unsigned)kAisBlock);
+        if (h->small_ok) h->small = AisSmallLaunch(k.mod, &ais_small_geom, (unsigned)kAisSmallBlock);
+        else h->launch = AisLaunch(k.mod, &ais_half_geom, (unsigned)kAisBlock);
         h->spec_state = KABC_SPEC_ACTIVE;
         h->spec_switch_at = h->launches;
     } else if (st == KABC_SPEC_FAILED) {
@@ -807,7 +905,9 @@ static kabc_status_t launch_half_seg(kabc_ais_t* h, int32_t half, const kabc_ais
                                      int32_t ntransitions, double* dev_trace_rows) {
     if (sg.count == 0) return KABC_OK;
     hipStream_t s = h->ctx->stream;
-    if (h->spec_state == KABC_SPEC_PENDING) ais_poll_spec(h);
+    if (h->spec_state == KABC_SPEC_PENDING && !h->small_ok) ais_poll_spec(h);
+    if (!h->launch && !h->dyn)
+        if (kabc_status_t st = ais_resolve_half(h)) return st;
     h->launches++;
     // debug records: layout [N_owned][nt][6] in the order of the owned rows (half 0 first)
     int32_t* dbg = nullptr;
@@ -952,6 +1052,91 @@ kabc_status_t kabc_ais_end_generation(kabc_ais_t* h, int32_t ntransitions) {
     return KABC_OK;
 }
 
+}  // extern "C"
+
+// units (batch, sub-step) of one generation a consumer of the small kernel may have to count
+static int64_t ais_small_units_per_gen(const kabc_ais_t* h, int32_t ntransitions) {
+    return ((h->rows[0] + kBatch - 1) / kBatch + (h->rows[1] + kBatch - 1) / kBatch) * (int64_t)ntransitions;
+}
+
+// `ngenerations` generations of a small ensemble: one launch of one workgroup per chain
+// (ais_small_kernel.hpp) per block of generations -- a block ends where the device trace buffer
+// (64 MiB) or the kernel's 32-bit unit counters would.  Enqueued on the handle's stream; the trace
+// block is copied to out_samples behind its launch.
+static kabc_status_t ais_small_run(kabc_ais_t* h, int64_t ngenerations, int32_t ntransitions, double* out_samples) {
+    hipStream_t s = h->ctx->stream;
+    const int64_t gen_elems = h->N * h->D * h->nchains;  // [chain][N][D] per generation
+    const size_t gen_bytes = sizeof(double) * (size_t)gen_elems;
+    int64_t block = (1ll << 30) / ais_small_units_per_gen(h, ntransitions);
+    if (out_samples) {
+        size_t target = (size_t)64 << 20;
+        if (const char* e = std::getenv("KABC_TRACE_CHUNK_MIB")) {  // tuning / tests: force several blocks
+            const long mib = std::atol(e);
+            if (mib > 0) target = (size_t)mib << 20;
+        }
+        const int64_t fit = (int64_t)(target / gen_bytes);
+        if (fit < block) block = fit;
+    }
+    if (block < 1) block = 1;
+    if (block > ngenerations) block = ngenerations;
+    if (out_samples && gen_bytes * (size_t)block > h->strace_cap) {
+        if (h->d_strace) {
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+            KABC_HIP_CHECK(hipFree(h->d_strace));
+            h->d_strace = nullptr;
+            h->strace_cap = 0;
+        }
+        KABC_HIP_CHECK(dev_malloc(&h->d_strace, gen_bytes * (size_t)block));
+        h->strace_cap = gen_bytes * (size_t)block;
+    }
+    for (int64_t g0 = 0; g0 < ngenerations; g0 += block) {
+        const int64_t gc = ngenerations - g0 < block ? ngenerations - g0 : block;
+        if (h->spec_state == KABC_SPEC_PENDING) ais_poll_spec(h);
+        h->launches++;
+        AisSmallArgs a;
+        std::memset(&a, 0, sizeof a);
+        for (int hf = 0; hf < 2; ++hf) {
+            a.x[hf] = h->d_half[hf];
+            a.lp[hf] = h->d_lp[hf];
+            a.ll[hf] = h->d_ll[hf];
+            a.rows[hf] = (int32_t)h->rows[hf];
+            a.id_base[hf] = h->id_base[hf];
+        }
+        a.trace = out_samples ? h->d_strace : nullptr;
+        // debug records: [N][nt][6] in walker order (those of the block's last generation remain)
+        a.dbg = (h->d_dbg && h->N * (int64_t)ntransitions * 6 <= h->dbg_cap) ? h->d_dbg : nullptr;
+        a.counters = h->d_counters;
+        a.slots = h->d_slots;
+        a.cost_params = h->d_cost_params;
+        a.cost_data = h->d_cost_data;
+        a.cost_ndata = h->cost_ndata;
+        a.seed = h->seed;
+        a.t0 = h->t;
+        a.nt = ntransitions;
+        a.ngen = (int32_t)gc;
+        a.trace_from = 0;
+        a.nchains = h->nchains;
+        a.eps = h->eps;
+        a.reps = (h->posterior == KABC_POSTERIOR_COMMON) ? 1.0 : 1.0 / h->eps;
+        a.box_lp = h->box_lp;
+        a.prior = h->d_prior;
+        a.seeds = h->d_seeds;
+        const bool t_on = h->timing && (h->ev_used + 2 <= h->ev.size());
+        if (t_on && h->open_count == 0) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
+        h->small(a, s);
+        if (t_on && ++h->open_count >= h->timing_stride)
+            if (kabc_status_t st = timing_close_pair(h)) return st;
+        KABC_HIP_CHECK(hipGetLastError());
+        if (out_samples)
+            KABC_HIP_CHECK(hipMemcpyAsync(out_samples + g0 * gen_elems, h->d_strace, gen_bytes * (size_t)gc,
+                                          hipMemcpyDeviceToHost, s));
+        h->t += (uint64_t)gc * (uint64_t)ntransitions;
+    }
+    return KABC_OK;
+}
+
+extern "C" {
+
 kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntransitions,
                                double* out_samples, kabc_stats_t* stats) {
     if (check_handle(h)) return KABC_ERR_INVALID_ARG;
@@ -992,7 +1177,9 @@ kabc_status_t kabc_ais_advance(kabc_ais_t* h, int64_t ngenerations, int32_t ntra
             std::snprintf(local_msg, sizeof local_msg, "%s", get_error());
         }
     };
-    if (!out_samples || ngenerations == 0) {
+    if (h->small_ok && ngenerations > 0 && ais_small_units_per_gen(h, ntransitions) <= (1ll << 30)) {
+        if (kabc_status_t st = ais_small_run(h, ngenerations, ntransitions, out_samples)) return st;
+    } else if (!out_samples || ngenerations == 0) {
         for (int64_t g = 0; g < ngenerations; ++g) {
             for (int hf = 0; hf < 2; ++hf) {
                 // exchange diagnostics: this half-generation is timed while entries are left
@@ -1357,6 +1544,8 @@ kabc_status_t kabc_ais_get_stats(kabc_ais_t* h, kabc_stats_t* stats) {
     return check_device_error(h, c);
 }
 
+int32_t kabc_ais_driver(const kabc_ais_t* h) { return (h && h->small_ok) ? 1 : 0; }
+
 int64_t kabc_ais_owned(const kabc_ais_t* h, int32_t half) {
     if (!h || (half != 0 && half != 1)) return -1;
     return h->rows_owned[half];
@@ -1546,6 +1735,7 @@ kabc_status_t kabc_ais_destroy(kabc_ais_t* h) {
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->d_dbg) (void)hipFree(h->d_dbg);
     if (h->d_aux) (void)hipFree(h->d_aux);
+    if (h->d_strace) (void)hipFree(h->d_strace);
     for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
     for (kabc_ais::XT& x : h->xt) {
         (void)hipEventDestroy(x.e0);

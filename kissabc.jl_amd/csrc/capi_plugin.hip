@@ -830,6 +830,14 @@ static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int 
             k.mod = rtc_kernel(R, head, "ais_kernels.hpp", true, {half, ais_init}, half);
             break;
         }
+        case kPfAisSmall: {
+            const int pc = variant % kPriorClassesRt, pk = variant / kPriorClassesRt + 1;
+            if (!((pk_mask >> (pk - 1)) & 1) || pc == 3 || pc == 1) return k;  // (BOX and GENERAL: capi_ais.hip small_class)
+            const std::string n = "kabc::ais_small_kernel<" + d + ", " + u + ", " + std::to_string(pc) + ", " +
+                                  std::to_string(pk) + ">";
+            k.mod = rtc_kernel(R, head, "ais_small_kernel.hpp", true, {n}, n);
+            break;
+        }
         case kPfAisInit: k.mod = rtc_kernel(R, head, "ais_kernels.hpp", true, {ais_init}, ais_init); break;
         case kPfSmcInit: {
             // (requested before the pass kernels of the same run: compile for the class it will use)
@@ -1211,7 +1219,8 @@ extern "C" kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family,
         set_error("kabc_plugin_precompile: %d is not a registered user cost", cost_id);
         return KABC_ERR_INVALID_ARG;
     }
-    if (family < kPfAis || (family > kPfAttempt && family != kPfSmcSmall && family != kPfAisDyn && family != kPfSmcDyn)) {
+    if (family < kPfAis || (family > kPfAttempt && family != kPfSmcSmall && family != kPfAisDyn && family != kPfSmcDyn &&
+                            family != kPfAisSmall)) {
         set_error("kabc_plugin_precompile: unknown kernel family %d", family);
         return KABC_ERR_INVALID_ARG;
     }
@@ -1315,6 +1324,12 @@ static std::vector<SpecReq> spec_requests(const kabc_model_t* model, int familie
         const int pk_hi = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 3;
         for (int pk = pk_lo; pk <= pk_hi; ++pk)
             if ((pk_mask >> (pk - 1)) & 1) reqs.push_back({kPfAis, 2 + kPriorClassesRt * (pk - 1)});
+    }
+    if ((families & KABC_FAMILY_AIS_SMALL) && D <= KABC_MAX_DIM) {  // (the one-workgroup driver of small ensembles)
+        const int pk_lo = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 1;
+        const int pk_hi = (model->posterior >= 1 && model->posterior <= 3) ? model->posterior : 3;
+        for (int pk = pk_lo; pk <= pk_hi; ++pk)
+            if ((pk_mask >> (pk - 1)) & 1) reqs.push_back({kPfAisSmall, 2 + kPriorClassesRt * (pk - 1)});
     }
     if (families & KABC_FAMILY_SMC) reqs.push_back({kPfSmcLoop, simple ? 1 : 0});
     if (families & KABC_FAMILY_ABCDE) reqs.push_back({kPfAbcdeGen, 0});

@@ -37,7 +37,9 @@ enum PluginFamily {
     // (hipRTC units) the run-time-dimension kernels, length(prior) > KABC_MAX_DIM: variant 0 the
     // half-generation / propose+accept kernel, 1 the init kernel (ais_dyn_kernels.hpp, smc_dyn_kernels.hpp);
     // ABCDE / pfilter beyond KABC_MAX_DIM: their own families, instantiated with D = 0
-    kPfAisDyn, kPfSmcDyn
+    kPfAisDyn, kPfSmcDyn,
+    // (hipRTC units) the one-workgroup AIS driver of small ensembles (ais_small_kernel.hpp); variant = AIS pcx
+    kPfAisSmall
 };
 struct PluginKernel {
     void* host = nullptr;

@@ -49,11 +49,20 @@ NAMES = ["C3_rosenbrock_d8", "C2_gauss_d2", "threshold_d2", "odd_N_d3", "d1_dira
          "d5_general_mixed", "d16_hier_sim", "d16_box", "d2_wiener", "d2_banana_inf"]
 
 
-@pytest.mark.parametrize("name", NAMES)
-def test_ais_generation_bit_exact(k, orc, gpu_ctx, name):
+# the cases that fit the one-workgroup driver of small ensembles (csrc/ais_small_kernel.hpp: N <= 512,
+# <= 256 from nine parameters on, no grid-wide pre-pass) run on BOTH drivers
+SMALL = ["d1_dirac_kernelized", "d1_mixture_threshold", "d2_discrete_threshold", "d2_general_negbin_beta",
+         "d5_general_mixed", "d16_box", "d2_wiener", "d2_banana_inf"]
+CASES = [(n, "halves") for n in NAMES] + [(n, "small") for n in SMALL]
+
+
+@pytest.mark.parametrize("name,driver", CASES)
+def test_ais_generation_bit_exact(k, orc, gpu_ctx, monkeypatch, name, driver):
     model, N = _models(k)[name]
     nt, gens, seed = (1 if name == "d1_dirac_kernelized" else 5), 4, 11
+    monkeypatch.setenv("KABC_AIS_SMALL", "1" if driver == "small" else "0")
     ens = k.AisEnsemble(model, N, seed=seed).init()
+    assert ens.driver == driver
     o = orc.OracleAIS(model, N, seed=seed).init()
     # init parity (step(init), src/KissABC.jl:35-64)
     x0, lp0, ll0, _ = ens.state()
