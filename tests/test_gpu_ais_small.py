@@ -164,7 +164,7 @@ def test_batched_chains(k, orc, gpu_ctx):
         o.generations_sync(3, 1, collect=False)
         assert np.array_equal(got[:, c], o.generations_sync(6, 2)), f"chain {c}"
     out = k.sample(model, k.AIS(13), k.MCMCThreads(), 30, 4, seed=2, discard_initial=26, return_array=True)
-    for c, sd in enumerate(k.chain_seeds(2, 4)):
+    for c, sd in enumerate(k.api.chain_seeds(2, 4)):
         o = orc.OracleAIS(model, 13, seed=sd).init()
         o.generations_sync(2, 1, collect=False)
         assert np.array_equal(out[c * 30:(c + 1) * 30], o.generations_sync(3, 1).reshape(-1, 8)[:30])
