@@ -107,6 +107,37 @@ def prior_class_problems(k):
     ]
 
 
+class _env:
+    """set an environment variable for a block and put back what was there (or remove it)"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = os.environ.get(self.name)
+        if self.value is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.value
+
+    def __exit__(self, *exc):
+        if self.prev is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.prev
+
+
+# sample() calls shaped like the reference's own tests and examples (test/runtests.jl:82-131,177-198,
+# examples/example_n1.jl:40; src/KissABC.jl:71: ntransitions = 1 is the default): (walkers, samples,
+# discard_initial, ntransitions) on the C2 model
+REFERENCE_SHAPES = [(12, 500, 1000, 1), (100, 1000, 10000, 1), (50, 100, 50000, 1), (20, 100, 2000, 40),
+                    (10, 10000, 0, 50)]
+
+
+def _shape_key(w, ns, disc, nt):
+    return f"AIS({w}) samples={ns} discard_initial={disc} ntransitions={nt}"
+
+
 def _cpu_chain(args):
     """One independent serial chain (the MCMCThreads analogue, src/KissABC.jl:108)."""
     nwalkers, seed, budget_s = args
@@ -191,6 +222,23 @@ def cpu_baseline(k, budget_s, with_smc):
                                f"ntransitions=100 in {w:.1f}s"}
     except Exception as e:
         out["readme_c1"] = {"error": repr(e)}
+    try:  # the reference's own sample() shapes: the same number of step() calls, serial schedule, one core
+        from oracle import oracle as orc
+        rs = {}
+        for w_, ns_, disc_, nt_ in REFERENCE_SHAPES:
+            gens = -(-disc_ // w_) + max(1, -(-ns_ // w_))
+            ws = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                o = orc.OracleAIS(c2_problem(k), w_, seed=1).init()
+                o.steps_serial(gens * w_, nt_, collect=True)   # one device generation = N step() calls
+                ws.append(time.perf_counter() - t0)
+            rs[_shape_key(w_, ns_, disc_, nt_)] = {"wall_ms": sorted(ws)[1] * 1e3, "step_calls": gens * w_}
+        out["reference_shapes"] = {"cores": 1, "kind": "port", "shapes": rs,
+                                   "sample": "oracle ref_serial: init + ceil(discard/N)*N + ceil(Ns/N)*N step() "
+                                             "calls on the C2 model (median of 3)"}
+    except Exception as e:
+        out["reference_shapes"] = {"error": repr(e)}
     try:  # the "next" rows (ABCDE, pfilter): the oracle on the same runs as the device legs
         from oracle import oracle as orc
         n2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
@@ -250,7 +298,7 @@ def _pmc_table():
         return None, {}
 
 
-def spawn_ranks(n, argv, stub=None, timeout=None):
+def spawn_ranks(n, argv, stub=None, timeout=3600.0):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per
     GPU, BEFORE this process has made any GPU call (the children are fresh interpreters; nothing
     is exec'ed after a GPU initialisation).  The ranks get the variables a launcher would set
@@ -258,6 +306,7 @@ def spawn_ranks(n, argv, stub=None, timeout=None):
     rank 0's stdout is relayed with its JSON line LAST, and the exit code is non-zero when any
     rank failed (the others are ended: a rank that lost its peers would wait in a collective).
     Returns (exit code, the JSON line or None)."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as sk:   # a free rendezvous port (it names the unique-id file, comm.py)
@@ -266,35 +315,64 @@ def spawn_ranks(n, argv, stub=None, timeout=None):
     import tempfile
     out_f = tempfile.TemporaryFile(mode="w+")   # (a pipe would fill up: the line is tens of KB)
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        if stub is not None:
-            env["KABC_BENCH_STUB_RANK"] = stub
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
-                                      stdout=out_f if r == 0 else subprocess.DEVNULL))
-    t0, rc = time.time(), 0
-    live = set(range(n))
-    while live:
-        for r in sorted(live):
-            c = procs[r].poll()
-            if c is not None:
-                live.discard(r)
-                if c != 0:
-                    rc = rc or c
-                    print(f"[bench] rank {r} exited with code {c}", file=sys.stderr, flush=True)
-        if (rc or (timeout and time.time() - t0 > timeout)) and live:
-            rc = rc or 124
-            for r in live:
-                procs[r].terminate()
-            for r in live:
+
+    def end_children():
+        """every rank that still runs: SIGTERM to its process group, SIGKILL after 10 s"""
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            try:
+                os.killpg(p.pid, signal.SIGTERM)   # (each rank leads a session of its own: start_new_session)
+            except OSError:
+                pass
+        for p in alive:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
                 try:
-                    procs[r].wait(10)
-                except subprocess.TimeoutExpired:
-                    procs[r].kill()
-            live.clear()
-        if live:
-            time.sleep(0.05)
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+
+    def on_signal(signum, frame):   # the launcher is told to stop: so are its ranks (a peer in a collective never exits)
+        raise KeyboardInterrupt(f"signal {signum}")
+
+    old_handlers = {}
+    for sg in (signal.SIGTERM, signal.SIGINT):
+        try:
+            old_handlers[sg] = signal.signal(sg, on_signal)
+        except ValueError:   # (not the main thread: tests)
+            pass
+    t0, rc = time.time(), 0
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            if stub is not None:
+                env["KABC_BENCH_STUB_RANK"] = stub
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                          stdout=out_f if r == 0 else subprocess.DEVNULL, start_new_session=True))
+        live = set(range(n))
+        while live:
+            for r in sorted(live):
+                c = procs[r].poll()
+                if c is not None:
+                    live.discard(r)
+                    if c != 0:
+                        rc = rc or c
+                        print(f"[bench] rank {r} exited with code {c}", file=sys.stderr, flush=True)
+            if (rc or (timeout and time.time() - t0 > timeout)) and live:
+                rc = rc or 124
+                end_children()
+                live.clear()
+            if live:
+                time.sleep(0.05)
+    except KeyboardInterrupt as e:
+        print(f"[bench] launcher interrupted ({e}): ending the ranks", file=sys.stderr, flush=True)
+        rc = rc or 130
+    finally:
+        end_children()   # (no rank outlives the launcher, whatever ended the loop)
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
     out_f.seek(0)
     out0 = out_f.read()
     out_f.close()
@@ -361,11 +439,10 @@ def cold_spec_child():
         ctx.synchronize()
         return e, (time.perf_counter() - t0) * 1e3
     for name, m, Nm, Dm in probs:
-        os.environ["KABC_SPECIALIZE"] = "0"
-        first_call(m, Nm)[0].close()     # (the prebuilt kernel's code object is loaded by its first launch)
-        e0, ms0 = first_call(m, Nm)
-        e0.close()
-        os.environ.pop("KABC_SPECIALIZE")
+        with _env("KABC_SPECIALIZE", "0"):
+            first_call(m, Nm)[0].close()     # (the prebuilt kernel's code object is loaded by its first launch)
+            e0, ms0 = first_call(m, Nm)
+            e0.close()
         t_create = time.perf_counter()
         e, ms1 = first_call(m, Nm)
         res[name] = {"first_call_ms_prebuilt_only": ms0, "first_call_ms_default": ms1,
@@ -683,12 +760,54 @@ def main():
             extra["next_rows"] = nr
         except Exception as e:  # informational legs: never fail the bench on them
             extra["next_rows"] = {"error": repr(e)}
-        # BASELINE.json configs[1]
-        os.environ["KABC_SPECIALIZE"] = "0"
+        # sample() calls shaped like the reference's own tests (REFERENCE_SHAPES): small ensembles, the
+        # default ntransitions = 1, long burn-ins -- on the one-workgroup driver (every generation of an
+        # advance call in ONE launch: csrc/ais_small_kernel.hpp; the default) and with a launch per
+        # half-generation (KABC_AIS_SMALL=0), the oracle's one-core wall for the same step() calls beside
         try:
+            m2 = c2_problem(k)
+            shapes = {}
+            cpu_rs = (cpu or {}).get("reference_shapes", {}).get("shapes", {}) if cpu else {}
+            for w_, ns_, disc_, nt_ in REFERENCE_SHAPES:
+                kw_s = dict(ntransitions=nt_, discard_initial=disc_, seed=1, ctx=ctx, return_array=True)
+                gens = -(-disc_ // w_) + max(1, -(-ns_ // w_))
+                ent = {"generations": gens}
+                for drv in ("small", "halves"):
+                    with _env("KABC_AIS_SMALL", "1" if drv == "small" else "0"):
+                        k.sample(m2, k.AIS(w_), ns_, **kw_s)
+                        ws = []
+                        for _ in range(5):
+                            t0 = time.perf_counter()
+                            k.sample(m2, k.AIS(w_), ns_, **kw_s)
+                            ws.append(time.perf_counter() - t0)
+                    wm = sorted(ws)[2]
+                    ent[drv] = {"wall_ms": wm * 1e3, "us_per_half_generation": wm * 1e6 / (2 * gens),
+                                "transitions_per_s": gens * w_ * nt_ / wm}
+                key = _shape_key(w_, ns_, disc_, nt_)
+                if key in cpu_rs:
+                    ent["cpu_port_1core_wall_ms"] = cpu_rs[key]["wall_ms"]
+                    ent["vs_cpu_port_1core"] = cpu_rs[key]["wall_ms"] / ent["small"]["wall_ms"]
+                if w_ == 12:   # 50 chains of AIS(12) in one handle (test/runtests.jl:88-104): chain = workgroup
+                    k.sample(m2, k.AIS(w_), k.MCMCThreads(), ns_, 50, **kw_s)
+                    ws = []
+                    for _ in range(5):
+                        t0 = time.perf_counter()
+                        k.sample(m2, k.AIS(w_), k.MCMCThreads(), ns_, 50, **kw_s)
+                        ws.append(time.perf_counter() - t0)
+                    ent["small_50_chains_wall_ms"] = sorted(ws)[2] * 1e3
+                shapes[key] = ent
+            extra["reference_shapes"] = {
+                "workload": "sample(model, AIS(N), Ns; discard_initial, ntransitions) on the C2 model (Normal(0,5)^2, "
+                            "gauss_dist, scale 0.1), wall clock of the whole call incl. handle creation, init, the "
+                            "trace copy and the Python wrapper; median of 5",
+                "drivers": {"small": "one workgroup per chain, one launch per advance call (default, N <= 512)",
+                            "halves": "one launch per half-generation (KABC_AIS_SMALL=0)"},
+                "shapes": shapes}
+        except Exception as e:   # informational
+            extra["reference_shapes"] = {"error": repr(e)}
+        # BASELINE.json configs[1]
+        with _env("KABC_SPECIALIZE", "0"):
             c2_pre = kernel_leg(c2_problem(k), 4096, 2, nts=(NT_HEADLINE,))
-        finally:
-            os.environ.pop("KABC_SPECIALIZE", None)
         extra["c2"] = dict(kernel_leg(c2_problem(k), 4096, 2, nts=(NT_HEADLINE, 16)), prebuilt=c2_pre,
                            workload="C2: AIS 4096 walkers, D=2, Normal(0,5)^2, gauss_dist, scale 0.1 "
                                     "(BASELINE.json configs[1]); 32 workgroups: bound by the latency of "
@@ -714,11 +833,8 @@ def main():
         # its own kernels, launches that ran before.  Same bits on every path.
         bpc = {}
         for name, m, Nm, Dm in prior_class_problems(k):
-            os.environ["KABC_SPECIALIZE"] = "0"
-            try:
+            with _env("KABC_SPECIALIZE", "0"):
                 pre = kernel_leg(m, Nm, Dm)
-            finally:
-                os.environ.pop("KABC_SPECIALIZE", None)
             cur = kernel_leg(m, Nm, Dm)
             entry = dict(cur, N=Nm, D=Dm, prebuilt=pre,
                          kernel={"active": "the model's own (default path, k.AisEnsemble only)",
@@ -879,6 +995,15 @@ def main():
                                        f"half-generation issued by libkabc_hip (no torch.distributed)"
                                        if world > 1 else "single GPU"),
                        **({"emulated_ranks": emulate} if emulate else {})},
+            # SURVEY 8d quotes C3 at ntransitions in {1, 16}: the same run's figures at 16, on the first screen
+            **({"value_survey_8d": {"ntransitions": 16, "value": by_nt["16"]["value"], "unit": "evals/s",
+                                    "roofline_frac": by_nt["16"]["roofline_frac"],
+                                    "kernel_avg_us": by_nt["16"]["kernel_avg_us"],
+                                    "ntransitions_1": {"value": by_nt["1"]["value"],
+                                                       "roofline_frac": by_nt["1"]["roofline_frac"],
+                                                       "kernel_avg_us": by_nt["1"]["kernel_avg_us"]}
+                                    if "1" in by_nt else None}} if "16" in by_nt else {}),
+            "kabc_specialize_env": os.environ.get("KABC_SPECIALIZE"),
             "cost_evals_per_s": h["cost_evals_per_s"], "accept_rate": h["accept_rate"],
             "roofline": {"bound": "hbm", "achieved": h["roofline_achieved_GBps"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": h["roofline_frac"],

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KABC_VERSION 310 /* 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
+#define KABC_VERSION 320 /* 0.3.2: kabc_ais_driver, kabc_set_specialize, kabc_rtc_cache_dir; 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
 /* AIS, smc, ABCDE and pfilter accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM
  * run-time-dimension kernels keep the walker / particle rows in memory (several times slower per
@@ -273,6 +273,24 @@ kabc_status_t kabc_model_release(int32_t handle);
  * kabc_compile_model) to the worker unless they are in the cache already.  A no-op for models
  * that are not eligible. */
 kabc_status_t kabc_prefetch_model(const kabc_model_t* model, int32_t families);
+/* The same switch for a host application that embeds the library and must not have it fork
+ * compiler processes (or must not depend on its environment): process-wide, takes effect for the
+ * models seen from now on.  _ENV: KABC_SPECIALIZE decides (the default); _OFF: never specialise,
+ * never start the worker (registered kabc_compile_model units are ignored too); _BLOCKING: compile
+ * at first sight in the calling thread; _BACKGROUND: the worker process, whatever the environment
+ * says.  The code-object cache the worker fills lives in a directory only this user can write to
+ * (owned by the effective user, no group / world write permission, not a symbolic link:
+ * KABC_RTC_CACHE_DIR, else <library directory>/rtc_cache, $XDG_CACHE_HOME/kabc_rtc_cache or
+ * ~/.cache/kabc_rtc_cache, $TMPDIR/kabc_rtc_cache_<uid>); a directory that fails the test is not used,
+ * and a cache file is loaded only when the digest of its unit and the checksum of its code match. */
+#define KABC_SPECIALIZE_ENV (-1)
+#define KABC_SPECIALIZE_OFF 0
+#define KABC_SPECIALIZE_BLOCKING 1
+#define KABC_SPECIALIZE_BACKGROUND 2
+kabc_status_t kabc_set_specialize(int32_t mode);
+/* the code-object cache directory in use ("" and 0: none -- disabled, or no candidate passed the
+ * trust test): copies at most cap - 1 characters + NUL into out, returns the full length */
+int32_t kabc_rtc_cache_dir(char* out, int32_t cap);
 #define KABC_SPEC_NONE 0    /* prebuilt kernels: model not eligible, specialisation off or unavailable */
 #define KABC_SPEC_PENDING 1 /* prebuilt (or generic) kernels while the worker compiles              */
 #define KABC_SPEC_ACTIVE 2  /* the model's own kernels                                              */

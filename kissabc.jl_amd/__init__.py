@@ -8,7 +8,7 @@ from . import costs
 from ._cdefs import KABC_MAX_DIM
 from ._lib import Context, KabcError, LIB_PATH, default_context
 from .api import (ABCDE, AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPosterior, CommonLogDensity,
-                  MCMCThreads, compile_model, pfilter,
+                  MCMCThreads, compile_model, pfilter, set_specialize,
                   Particles, sample, smc)
 from . import comm
 from .comm import Comm, EnsembleGroup
@@ -25,5 +25,5 @@ __all__ = [
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
     "Exponential", "Gamma", "LogNormal", "Product", "MvNormal", "MultivariateNormal", "Context", "KabcError", "default_context", "LIB_PATH",
     "KABC_MAX_DIM", "comm", "Comm", "EnsembleGroup", "UserInit", "InitFromSnippet",
-    "UserPrior", "Poisson", "Laplace", "TruncatedGamma", "compile_model",
+    "UserPrior", "Poisson", "Laplace", "TruncatedGamma", "compile_model", "set_specialize",
 ]

@@ -7,7 +7,7 @@ import ctypes as C
 
 KABC_MAX_DIM = 16
 KABC_MAX_DIM_DYN = 256   # AIS only: run-time-dimension kernels beyond KABC_MAX_DIM
-KABC_VERSION = 310   # include/kabc.h
+KABC_VERSION = 320   # include/kabc.h
 KABC_COMM_ID_BYTES = 128
 KABC_MAX_EXCHANGE_CHUNKS = 16
 KABC_COMM_MAX_WORLD = 16
@@ -131,6 +131,8 @@ PROTOTYPES = {
     "kabc_model_release": (C.c_int, [C.c_int32]),
     "kabc_prefetch_model": (C.c_int, [C.POINTER(Model), C.c_int32]),
     "kabc_spec_counters": (C.c_int, [C.POINTER(C.c_uint64)]),
+    "kabc_set_specialize": (C.c_int, [C.c_int32]),
+    "kabc_rtc_cache_dir": (C.c_int32, [C.c_char_p, C.c_int32]),
     "kabc_rtc_worker_main": (C.c_int32, [C.c_char_p]),
     "kabc_ais_spec_state": (C.c_int, [VP, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
     "kabc_ais_driver": (C.c_int32, [VP]),

@@ -137,6 +137,13 @@ def compile_model(model_or_prior, cost=None, families=0):
     return int(h.value)
 
 
+def set_specialize(mode):
+    """kabc_set_specialize: "env" (KABC_SPECIALIZE decides), "off" (never specialise, never start the
+    compiler worker process), "blocking" (compile at first sight), "background" (the worker)."""
+    m = {"env": -1, "off": 0, "blocking": 1, "background": 2}[mode]
+    _lib.check(_lib.load().kabc_set_specialize(m))
+
+
 class AIS:
     """AIS(nparticles) -- src/KissABC.jl:21-23"""
 
@@ -367,18 +374,23 @@ def sample(model, spl, *args, ntransitions=1, discard_initial=0, retry_sampling=
     N = spl.nparticles
     ens = AisEnsemble(model, N, seed=seed, ctx=ctx)
     gk = max(1, -(-Ns // N))
+    shape = (gk, N, len(model))
     # the page-locked trace buffer is allocated on a helper thread (pinning costs
-    # ~40 us per MiB) while init and the discarded generations run on the device
-    pool = concurrent.futures.ThreadPoolExecutor(1)
-    buf = pool.submit(_lib.pinned_empty, (gk, N, len(model)))
+    # ~40 us per MiB) while init and the discarded generations run on the device; a small
+    # trace (the reference's own test shapes) is not worth a thread: 0.1-0.2 ms of a 0.5 ms call
+    big = gk * N * len(model) * 8 > (1 << 20)
+    pool = concurrent.futures.ThreadPoolExecutor(1) if big else None
+    buf = pool.submit(_lib.pinned_empty, shape) if big else None
     try:
         ens.init(retry_sampling)
         gd = -(-int(discard_initial) // N)
         if gd:
             ens.advance(gd, ntransitions)
-        out = ens.advance(gk, ntransitions, out=buf.result()).reshape(gk * N, len(model))[:Ns]
+        out = ens.advance(gk, ntransitions, out=buf.result() if big else _lib.pinned_empty(shape))
+        out = out.reshape(gk * N, len(model))[:Ns]
     finally:
-        pool.shutdown(wait=True)
+        if pool is not None:
+            pool.shutdown(wait=True)
         ens.close()
     return out if return_array else _bundle(out, model.scalar)
 

@@ -426,13 +426,13 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     if (dyn) {
         if (unit) {
             const PluginKernel kh = unit_kernel(unit, kPfAisDyn, m->D, 0), ki = unit_kernel(unit, kPfAisDyn, m->D, 1);
-            dyn_fn = AisDynLaunch(kh.mod, ki.mod);
+            dyn_fn = AisDynLaunch(kh.mod, unit_kernel(unit, kPfAisDyn, m->D, 2).mod, unit_kernel(unit, kPfAisDyn, m->D, 3).mod, ki.mod);
             if (!dyn_fn) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
         } else if (m->cost.id >= KABC_COST_USER) {
             const CostPlugin* pl = find_plugin(m->cost.id);
             if (pl && pl->rtc) {
                 const PluginKernel kh = plugin_kernel(pl, kPfAisDyn, m->D, 0), ki = plugin_kernel(pl, kPfAisDyn, m->D, 1);
-                dyn_fn = AisDynLaunch(kh.mod, ki.mod);
+                dyn_fn = AisDynLaunch(kh.mod, plugin_kernel(pl, kPfAisDyn, m->D, 2).mod, plugin_kernel(pl, kPfAisDyn, m->D, 3).mod, ki.mod);
             } else if (pl && pl->ais_dyn) {
                 dyn_fn = AisDynLaunch((AisDynLaunchFn)pl->ais_dyn());
             }

@@ -144,6 +144,7 @@ static std::vector<std::string> rtc_include_dirs() {
 struct RtcAsyncJob {
     enum State { kDeferred, kPending, kFailed } state = kPending;  // deferred: the workers are busy, ask again
     std::string cpath;
+    uint64_t digest = 0;
     std::chrono::steady_clock::time_point t_spawn, t_poll;
     std::string why;  // (failed)
 };
@@ -305,41 +306,99 @@ static std::string lib_dir() {
     return std::string();
 }
 
-// KABC_RTC_CACHE_DIR, else <library directory>/rtc_cache, else (a read-only install)
-// /tmp/kabc_rtc_cache_<uid>; "" or "0" disables
+// A cache directory is TRUSTED when nobody but this user can have put a file into it: a real directory
+// (not a symbolic link), owned by the effective user, without group / world write permission.  Code
+// objects found there are handed to hipModuleLoadData and run on the GPU of THIS process, and the
+// names are computable (a hash of the unit's text), so a directory another local user may write to
+// -- a pre-created /tmp/kabc_rtc_cache_<uid>, a 0777 directory -- is never used.
+static bool cache_dir_trusted(const std::string& d) {
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+// creates `d` (0700) when it is missing; true: trusted, writable and searchable
+static bool cache_dir_usable(const std::string& d) {
+    if (d.empty()) return false;
+    (void)mkdir(d.c_str(), 0700);  // (EEXIST: judged by what is there)
+    return cache_dir_trusted(d) && access(d.c_str(), W_OK | X_OK) == 0;
+}
+
+// KABC_RTC_CACHE_DIR, else <library directory>/rtc_cache, else (a read-only install, or a tree that
+// belongs to somebody else) $XDG_CACHE_HOME/kabc_rtc_cache or ~/.cache/kabc_rtc_cache, else
+// $TMPDIR/kabc_rtc_cache_<uid> (/tmp without TMPDIR); every candidate must be trusted (above), the first that is serves;
+// "" or "0" disables.  No trusted directory: no cache, no worker -- the prebuilt kernels stay.
 static std::string rtc_cache_dir() {
     if (const char* e = std::getenv("KABC_RTC_CACHE_DIR")) {
         const std::string v(e);
-        return (v.empty() || v == "0") ? std::string() : v;
+        if (v.empty() || v == "0") return std::string();
+        return cache_dir_usable(v) ? v : std::string();
     }
     static std::string dir;
     static std::once_flag once;
     std::call_once(once, [] {
+        std::vector<std::string> cand;
         const std::string ld = lib_dir();
-        if (!ld.empty()) {
-            const std::string d = ld + "/rtc_cache";
-            (void)mkdir(d.c_str(), 0777);
-            if (access(d.c_str(), W_OK | X_OK) == 0) {
-                dir = d;
-                return;
+        if (!ld.empty()) cand.push_back(ld + "/rtc_cache");
+        if (const char* x = std::getenv("XDG_CACHE_HOME")) {
+            if (x[0] == '/') cand.push_back(std::string(x) + "/kabc_rtc_cache");
+        } else if (const char* hm = std::getenv("HOME")) {
+            if (hm[0] == '/') {
+                (void)mkdir((std::string(hm) + "/.cache").c_str(), 0700);
+                cand.push_back(std::string(hm) + "/.cache/kabc_rtc_cache");
             }
         }
-        const std::string t = "/tmp/kabc_rtc_cache_" + std::to_string((long long)getuid());
-        (void)mkdir(t.c_str(), 0700);
-        if (access(t.c_str(), W_OK | X_OK) == 0) dir = t;
+        const char* td = std::getenv("TMPDIR");
+        cand.push_back(std::string(td && td[0] == '/' ? td : "/tmp") + "/kabc_rtc_cache_" + std::to_string((long long)geteuid()));
+        for (const std::string& c : cand)
+            if (cache_dir_usable(c)) {
+                dir = c;
+                return;
+            }
     });
     return dir;
 }
 
-static bool cache_load(const std::string& path, size_t nnames, std::vector<char>* code,
+// FNV-1a of a byte range with a second offset basis: the check words inside a cache file
+static uint64_t fnv1a(const void* data, size_t n, uint64_t h);
+static uint64_t code_checksum(const std::vector<char>& code) { return fnv1a(code.data(), code.size(), 0x84222325cbf29ce4ull); }
+
+// a regular file of ours, opened without following a symbolic link
+static FILE* open_cache_file_read(const std::string& path) {
+    const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid()) {
+        close(fd);
+        return nullptr;
+    }
+    FILE* f = fdopen(fd, "rb");
+    if (!f) close(fd);
+    return f;
+}
+// a NEW file of ours (0600): never through a link somebody planted, never on top of an existing file
+static FILE* open_cache_file_new(const std::string& path) {
+    const int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return nullptr;
+    FILE* f = fdopen(fd, "wb");
+    if (!f) close(fd);
+    return f;
+}
+
+// File: "KABCRTC2", key digest (of the unit's text, names and options: what the file's NAME is a hash
+// of, with another basis), checksum of the code bytes, the lowered names, the code object.  A file
+// whose digest is not the expected one, whose checksum does not match its bytes, that is truncated,
+// not a regular file of this user or reached through a link is not loaded (the caller compiles, or
+// stays on the prebuilt kernels).
+static bool cache_load(const std::string& path, size_t nnames, uint64_t key_digest, std::vector<char>* code,
                        std::vector<std::string>* lowered) {
-    FILE* f = std::fopen(path.c_str(), "rb");
+    FILE* f = open_cache_file_read(path);
     if (!f) return false;
     bool ok = false;
     char magic[8];
     uint32_t n = 0;
-    if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "KABCRTC1", 8) == 0 &&
-        std::fread(&n, 4, 1, f) == 1 && n == nnames) {
+    uint64_t dg = 0, ck = 0;
+    if (std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "KABCRTC2", 8) == 0 && std::fread(&dg, 8, 1, f) == 1 &&
+        dg == key_digest && std::fread(&ck, 8, 1, f) == 1 && std::fread(&n, 4, 1, f) == 1 && n == nnames) {
         ok = true;
         for (uint32_t i = 0; i < n && ok; ++i) {
             uint32_t len = 0;
@@ -352,7 +411,7 @@ static bool cache_load(const std::string& path, size_t nnames, std::vector<char>
         ok = ok && std::fread(&cs, 8, 1, f) == 1 && cs > 0 && cs < (1ull << 31);
         if (ok) {
             code->resize((size_t)cs);
-            ok = std::fread(code->data(), 1, (size_t)cs, f) == (size_t)cs;
+            ok = std::fread(code->data(), 1, (size_t)cs, f) == (size_t)cs && code_checksum(*code) == ck;
         }
     }
     std::fclose(f);
@@ -367,6 +426,18 @@ static bool cache_load(const std::string& path, size_t nnames, std::vector<char>
 // the oldest ones go until it fits -- a service that sees thousands of distinct models (every
 // distinct prior tuple is a unit of its own) must not fill the disk.  Leftovers of workers that died
 // (lock / job files older than ten minutes) go on the same occasion.
+// a negative entry (<code object>.err: the compiler's message) counts for an hour
+static constexpr time_t kErrTtlSeconds = 3600;
+static bool fresh_err_file(const std::string& p) {
+    struct stat st;
+    if (lstat(p.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    if (time(nullptr) - st.st_mtime > kErrTtlSeconds) {
+        (void)unlink(p.c_str());
+        return false;
+    }
+    return true;
+}
+
 static void cache_trim(const std::string& dir, size_t incoming) {
     double cap_mb = 512.0;
     if (const char* e = std::getenv("KABC_RTC_CACHE_MB")) cap_mb = std::atof(e);
@@ -382,7 +453,7 @@ static void cache_trim(const std::string& dir, size_t incoming) {
             if (n.size() < 6 || n.compare(0, 5, "kabc_") != 0) continue;
             const std::string p = dir + "/" + n;
             struct stat st;
-            if (stat(p.c_str(), &st) != 0) continue;
+            if (lstat(p.c_str(), &st) != 0 || !S_ISREG(st.st_mode)) continue;
             const bool is_co = n.size() > 3 && n.compare(n.size() - 3, 3, ".co") == 0;
             if (is_co) {
                 co.push_back({p, st.st_mtime, (double)st.st_size});
@@ -391,6 +462,8 @@ static void cache_trim(const std::string& dir, size_t incoming) {
                        (n.find(".lock") != std::string::npos || n.find(".job") != std::string::npos ||
                         n.find(".tmp") != std::string::npos)) {
                 (void)unlink(p.c_str());
+            } else if (now - st.st_mtime > kErrTtlSeconds && n.size() > 4 && n.compare(n.size() - 4, 4, ".err") == 0) {
+                (void)unlink(p.c_str());  // (a failure of long ago is not a verdict: out of memory, a missing hipRTC ...)
             }
         }
         closedir(d);
@@ -403,23 +476,29 @@ static void cache_trim(const std::string& dir, size_t incoming) {
     }
 }
 
-static void cache_store(const std::string& dir, const std::string& path, const std::vector<char>& code,
-                        const std::vector<std::string>& lowered) {
-    (void)mkdir(dir.c_str(), 0777);
+static bool cache_store(const std::string& dir, const std::string& path, uint64_t key_digest,
+                        const std::vector<char>& code, const std::vector<std::string>& lowered) {
+    if (!cache_dir_usable(dir)) return false;
     cache_trim(dir, code.size());
     const std::string tmp = path + "." + std::to_string((long long)getpid()) + ".tmp";
-    FILE* f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return;  // (a read-only install: compile every time)
+    (void)unlink(tmp.c_str());  // (a leftover of an earlier process with this pid)
+    FILE* f = open_cache_file_new(tmp);
+    if (!f) return false;  // (a read-only install: compile every time)
     const uint32_t n = (uint32_t)lowered.size();
-    const uint64_t cs = code.size();
-    bool ok = std::fwrite("KABCRTC1", 1, 8, f) == 8 && std::fwrite(&n, 4, 1, f) == 1;
+    const uint64_t cs = code.size(), ck = code_checksum(code);
+    bool ok = std::fwrite("KABCRTC2", 1, 8, f) == 8 && std::fwrite(&key_digest, 8, 1, f) == 1 &&
+              std::fwrite(&ck, 8, 1, f) == 1 && std::fwrite(&n, 4, 1, f) == 1;
     for (const std::string& s : lowered) {
         const uint32_t len = (uint32_t)s.size();
         ok = ok && std::fwrite(&len, 4, 1, f) == 1 && (len == 0 || std::fwrite(s.data(), 1, len, f) == len);
     }
     ok = ok && std::fwrite(&cs, 8, 1, f) == 1 && std::fwrite(code.data(), 1, code.size(), f) == code.size();
     ok = (std::fclose(f) == 0) && ok;
-    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) {
+        (void)std::remove(tmp.c_str());
+        return false;
+    }
+    return true;
 }
 
 // everything that determines a code object: the unit's text, the compiler options, the cache path
@@ -427,6 +506,7 @@ struct RtcJob {
     std::string text;
     std::vector<std::string> opt;
     std::string cdir, cpath;  // on-disk cache (empty: disabled)
+    uint64_t digest = 0;      // of text + names + options (stored inside the cache file, checked at load)
 };
 
 static void rtc_prepare(const std::string& head, const char* header, bool fma_c_vgpr,
@@ -449,6 +529,10 @@ static void rtc_prepare(const std::string& head, const char* header, bool fma_c_
             h2 = fnv1a(n.data(), n.size() + 1, h2);
         }
         for (const std::string& o : J->opt) h = fnv1a(o.data(), o.size() + 1, h);
+        uint64_t dg = fnv1a(J->text.data(), J->text.size(), 0x6c62272e07bb0142ull ^ toolchain_fingerprint());
+        for (const std::string& n : names) dg = fnv1a(n.data(), n.size() + 1, dg);
+        for (const std::string& o : J->opt) dg = fnv1a(o.data(), o.size() + 1, dg);
+        J->digest = dg;
         char nm[64];
         std::snprintf(nm, sizeof nm, "/kabc_%016llx%016llx.co", (unsigned long long)h, (unsigned long long)h2);
         J->cpath = J->cdir + nm;
@@ -507,9 +591,9 @@ static kabc_status_t rtc_compile(const std::string& head, const char* header, bo
                                  std::vector<std::string>* lowered, const std::vector<std::string>* extra_opt = nullptr) {
     RtcJob J;
     rtc_prepare(head, header, fma_c_vgpr, names, code != nullptr, &J, extra_opt);
-    if (!J.cpath.empty() && cache_load(J.cpath, names.size(), code, lowered)) return KABC_OK;
+    if (!J.cpath.empty() && cache_load(J.cpath, names.size(), J.digest, code, lowered)) return KABC_OK;
     if (kabc_status_t st = rtc_compile_text(J.text, J.opt, names, code, lowered)) return st;
-    if (code && !J.cpath.empty()) cache_store(J.cdir, J.cpath, *code, *lowered);
+    if (code && !J.cpath.empty()) (void)cache_store(J.cdir, J.cpath, J.digest, *code, *lowered);
     return KABC_OK;
 }
 
@@ -625,14 +709,16 @@ static int max_workers() {
 // writes the job file and starts the worker; false: could not (message in *why)
 static bool spawn_worker(const RtcJob& J, const std::vector<std::string>& names, std::string* why) {
     const std::string lock = J.cpath + ".lock";
-    const int lfd = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY | O_CLOEXEC, 0666);
+    const int lflags = O_CREAT | O_EXCL | O_WRONLY | O_CLOEXEC | O_NOFOLLOW;
+    const int lfd = open(lock.c_str(), lflags, 0600);
     if (lfd < 0) {
         struct stat st;
-        if (errno == EEXIST && stat(lock.c_str(), &st) == 0 && time(nullptr) - st.st_mtime < 600)
+        if (errno == EEXIST && lstat(lock.c_str(), &st) == 0 && time(nullptr) - st.st_mtime < 600)
             return true;  // another process (or handle) is compiling exactly this unit: wait for its result
         (void)unlink(lock.c_str());  // (a worker that died)
-        const int l2 = open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY | O_CLOEXEC, 0666);
+        const int l2 = open(lock.c_str(), lflags, 0600);
         if (l2 < 0) {
+            if (errno == EEXIST) return true;  // (somebody else replaced the stale lock first: theirs to compile)
             *why = "cannot create " + lock + ": " + std::strerror(errno);
             return false;
         }
@@ -641,10 +727,12 @@ static bool spawn_worker(const RtcJob& J, const std::vector<std::string>& names,
         close(lfd);
     }
     const std::string job = J.cpath + ".job";
-    FILE* f = std::fopen(job.c_str(), "wb");
+    (void)unlink(job.c_str());  // (the lock is ours: a job file of this name is a leftover)
+    FILE* f = open_cache_file_new(job);
     bool ok = f != nullptr;
     if (ok) {
-        std::string hd = "KABCJOB1\n" + J.cpath + "\n" + std::to_string(J.opt.size()) + "\n";
+        std::string hd = "KABCJOB2\n" + J.cpath + "\n" + std::to_string((unsigned long long)J.digest) + "\n" +
+                         std::to_string(J.opt.size()) + "\n";
         for (const std::string& o : J.opt) hd += o + "\n";
         hd += std::to_string(names.size()) + "\n";
         for (const std::string& n : names) hd += n + "\n";
@@ -655,6 +743,7 @@ static bool spawn_worker(const RtcJob& J, const std::vector<std::string>& names,
     }
     if (!ok) {
         *why = "cannot write " + job;
+        (void)unlink(job.c_str());
         (void)unlink(lock.c_str());
         return false;
     }
@@ -720,7 +809,7 @@ static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* he
         if (job.state == RtcAsyncJob::kDeferred) {  // the workers were busy: look again, start it if there is room
             RtcJob J;
             rtc_prepare(head, header, fma_c_vgpr, names, true, &J, ais_opt);
-            if (file_exists(J.cpath) || file_exists(J.cpath + ".err") || file_exists(J.cpath + ".lock")) {
+            if (file_exists(J.cpath) || fresh_err_file(J.cpath + ".err") || file_exists(J.cpath + ".lock")) {
                 job.state = RtcAsyncJob::kPending;  // (somebody else took it meanwhile)
             } else if (workers_in_flight(J.cdir) < max_workers()) {
                 job.t_spawn = now;
@@ -736,7 +825,7 @@ static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* he
         }
         std::vector<char> code;
         std::vector<std::string> lowered;
-        if (file_exists(job.cpath) && cache_load(job.cpath, names.size(), &code, &lowered)) {
+        if (file_exists(job.cpath) && cache_load(job.cpath, names.size(), job.digest, &code, &lowered)) {
             void* fn = rtc_load(R, dev, code, names, lowered, want);
             if (fn) {
                 g_spec_counters.loaded++;
@@ -744,7 +833,7 @@ static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* he
             }
             job.state = RtcAsyncJob::kFailed;
             job.why = get_error();
-        } else if (file_exists(job.cpath + ".err")) {
+        } else if (fresh_err_file(job.cpath + ".err")) {
             job.state = RtcAsyncJob::kFailed;
             job.why = read_small_file(job.cpath + ".err");
         } else if (now - job.t_spawn > std::chrono::seconds(900)) {
@@ -762,6 +851,7 @@ static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* he
     rtc_prepare(head, header, fma_c_vgpr, names, true, &J, ais_opt);
     RtcAsyncJob job;
     job.cpath = J.cpath;
+    job.digest = J.digest;
     job.t_spawn = job.t_poll = now;
     if (J.cpath.empty()) {
         job.state = RtcAsyncJob::kFailed;
@@ -769,14 +859,14 @@ static void* rtc_kernel_try(RtcCache* R, const std::string& head, const char* he
     } else {
         std::vector<char> code;
         std::vector<std::string> lowered;
-        if (cache_load(J.cpath, names.size(), &code, &lowered)) {
+        if (cache_load(J.cpath, names.size(), J.digest, &code, &lowered)) {
             if (void* fn = rtc_load(R, dev, code, names, lowered, want)) {
                 g_spec_counters.cache_hits++;
                 return fn;
             }
             job.state = RtcAsyncJob::kFailed;
             job.why = get_error();
-        } else if (file_exists(J.cpath + ".err")) {
+        } else if (fresh_err_file(J.cpath + ".err")) {
             job.state = RtcAsyncJob::kFailed;
             job.why = read_small_file(J.cpath + ".err");
         } else if (!file_exists(J.cpath + ".lock") && workers_in_flight(J.cdir) >= max_workers()) {
@@ -873,9 +963,13 @@ static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int 
             break;
         }
         case kPfAisDyn: {
-            const std::vector<std::string> n = {"kabc::ais_dyn_half_kernel<" + udyn + ">",
-                                                "kabc::ais_dyn_init_kernel<" + udyn + ">"};
-            k.mod = rtc_kernel(R, head, "ais_dyn_kernels.hpp", false, n, n[variant ? 1 : 0]);
+            // variants: 0 / 2 / 3 the half-generation kernel with teams of 16 / 8 / 64 lanes per walker, 1 init
+            const std::vector<std::string> n = {"kabc::ais_dyn_half_kernel<" + udyn + ", 16>",
+                                                "kabc::ais_dyn_init_kernel<" + udyn + ">",
+                                                "kabc::ais_dyn_half_kernel<" + udyn + ", 8>",
+                                                "kabc::ais_dyn_half_kernel<" + udyn + ", 64>"};
+            if (variant < 0 || variant > 3) return k;
+            k.mod = rtc_kernel(R, head, "ais_dyn_kernels.hpp", false, n, n[(size_t)variant]);
             break;
         }
         case kPfSmcDyn: {
@@ -1011,11 +1105,17 @@ static kabc_status_t unit_head(const kabc_prior_t* prior, int D, int cost_id, bo
 // KABC_SPECIALIZE: unset -- every entry point specialises on its own WITHOUT waiting (worker
 // process, see rtc_kernel_try); 1 -- the same, compiling at first sight (blocking: tests, warm-up
 // scripts); 0 -- never (registered kabc_compile_model units are ignored too)
+// kabc_set_specialize: the embedding host's own word (-1: the environment decides, as above)
+static std::atomic<int> g_spec_mode{-1};
 static bool specialize_env() {
+    const int m = g_spec_mode.load();
+    if (m >= 0) return m == KABC_SPECIALIZE_BLOCKING;
     const char* e = std::getenv("KABC_SPECIALIZE");
     return e && *e && *e != '0';
 }
 static bool specialize_off() {
+    const int m = g_spec_mode.load();
+    if (m >= 0) return m == KABC_SPECIALIZE_OFF;
     const char* e = std::getenv("KABC_SPECIALIZE");
     return e && *e == '0';
 }
@@ -1157,8 +1257,11 @@ bool cost_dim_ok_rt(int cost_id, int D) {
 }
 
 hipError_t rtc_launch(void* fn, dim3 grid, dim3 block, const void* args, hipStream_t s) {
+    return rtc_launch_lds(fn, grid, block, args, s, 0u);
+}
+hipError_t rtc_launch_lds(void* fn, dim3 grid, dim3 block, const void* args, hipStream_t s, unsigned lds_bytes) {
     void* params[] = {const_cast<void*>(args)};
-    return hipModuleLaunchKernel((hipFunction_t)fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, s,
+    return hipModuleLaunchKernel((hipFunction_t)fn, grid.x, grid.y, grid.z, block.x, block.y, block.z, lds_bytes, s,
                                  params, nullptr);
 }
 
@@ -1428,6 +1531,21 @@ extern "C" kabc_status_t kabc_model_release(int32_t handle) {
     return KABC_ERR_INVALID_ARG;
 }
 
+extern "C" int32_t kabc_rtc_cache_dir(char* out, int32_t cap) {
+    const std::string d = rtc_cache_dir();
+    if (out && cap > 0) std::snprintf(out, (size_t)cap, "%s", d.c_str());
+    return (int32_t)d.size();
+}
+
+extern "C" kabc_status_t kabc_set_specialize(int32_t mode) {
+    if (mode < KABC_SPECIALIZE_ENV || mode > KABC_SPECIALIZE_BACKGROUND) {
+        set_error("kabc_set_specialize: mode is KABC_SPECIALIZE_ENV (-1), _OFF (0), _BLOCKING (1) or _BACKGROUND (2)");
+        return KABC_ERR_INVALID_ARG;
+    }
+    g_spec_mode.store(mode);
+    return KABC_OK;
+}
+
 extern "C" kabc_status_t kabc_spec_counters(uint64_t out[4]) {
     if (!out) {
         set_error("kabc_spec_counters: NULL argument");
@@ -1453,10 +1571,11 @@ extern "C" int32_t kabc_rtc_worker_main(const char* jobfile) {
         while ((c = std::fgetc(f)) != EOF && c != '\n') out->push_back((char)c);
         return c != EOF || !out->empty();
     };
-    std::string magic, cpath, n;
+    std::string magic, cpath, n, dg;
     std::vector<std::string> opt, names;
     std::string text;
-    bool ok = line(&magic) && magic == "KABCJOB1" && line(&cpath) && line(&n);
+    bool ok = line(&magic) && magic == "KABCJOB2" && line(&cpath) && line(&dg) && line(&n);
+    const bool have_path = ok;  // (from here on a failure can be reported where the parent looks)
     for (long i = 0, m = ok ? std::atol(n.c_str()) : 0; i < m && ok; ++i) {
         std::string o;
         ok = line(&o);
@@ -1475,27 +1594,36 @@ extern "C" int32_t kabc_rtc_worker_main(const char* jobfile) {
     }
     std::fclose(f);
     int rc = 0;
+    // every exit that delivers no code object leaves <cache path>.err (what the waiting handles poll
+    // for -- without it they would look every 2 ms for 900 s) and takes the lock away
+    auto fail = [&cpath](const char* msg) {
+        const std::string tmp = cpath + ".err." + std::to_string((long long)getpid()) + ".tmp";
+        (void)unlink(tmp.c_str());
+        if (FILE* e = open_cache_file_new(tmp)) {
+            std::fwrite(msg, 1, std::strlen(msg), e);
+            std::fclose(e);
+            if (std::rename(tmp.c_str(), (cpath + ".err").c_str()) != 0) (void)unlink(tmp.c_str());
+        }
+    };
     if (!ok) {
         rc = 2;
+        if (have_path) fail("the compilation worker could not read its job file");
     } else {
         std::vector<char> code;
         std::vector<std::string> lowered;
         const size_t sl = cpath.rfind('/');
         const std::string cdir = sl == std::string::npos ? std::string(".") : cpath.substr(0, sl);
         if (rtc_compile_text(text, opt, names, &code, &lowered) == KABC_OK && !code.empty()) {
-            cache_store(cdir, cpath, code, lowered);
+            if (!cache_store(cdir, cpath, std::strtoull(dg.c_str(), nullptr, 10), code, lowered)) {
+                rc = 3;
+                fail("the compilation worker could not store the code object (cache directory full, gone or not trusted)");
+            }
         } else {
             rc = 1;
-            const std::string tmp = cpath + ".err.tmp";
-            if (FILE* e = std::fopen(tmp.c_str(), "wb")) {
-                const char* msg = get_error();
-                std::fwrite(msg, 1, std::strlen(msg), e);
-                std::fclose(e);
-                (void)std::rename(tmp.c_str(), (cpath + ".err").c_str());
-            }
+            fail(get_error());
         }
-        (void)unlink((cpath + ".lock").c_str());
     }
+    if (have_path) (void)unlink((cpath + ".lock").c_str());
     (void)unlink(jobfile);
     return rc;
 }

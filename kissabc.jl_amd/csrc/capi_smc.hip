@@ -166,7 +166,9 @@ struct DevBufs {
         }();
         return cap;
     }
-    ~DevBufs() {
+    ~DevBufs() { release(); }
+    // hands every buffer back (to the context's cache, else to the driver); the owner's pointers dangle
+    void release() {
         for (auto& e : held) {
             if (!e.second) continue;
             if (ctx) {
@@ -179,6 +181,7 @@ struct DevBufs {
             }
             (void)hipFree(e.second);
         }
+        held.clear();
     }
     template <class T>
     hipError_t alloc(T** p, size_t n) {
@@ -334,7 +337,15 @@ kabc_status_t kabc_smc_run_dist_mode(kabc_comm_t* comm, const kabc_prior_t* prio
         return KABC_ERR_UNSUPPORTED;
     }
     tl_smc_dist_mode = mode;
+    // The select grid's "ordinary launch, bounded barrier wait, repeat cooperatively" turn is decided by
+    // one rank from its own GPU: a rank that took it alone would restart from the initial exchange while
+    // its peers go on with pass exchanges -- mismatched collectives.  A sharded run therefore launches
+    // its selections cooperatively from the start (co-residency asserted by the runtime, ~21 us per
+    // launch: nothing beside the host round trip per pass this mode already has).
+    const bool was_coop = tl_smc_force_coop;
+    tl_smc_force_coop = true;
     const kabc_status_t st = smc_run_impl(comm->ctx, comm, prior, D, cost, o, res);
+    tl_smc_force_coop = was_coop;
     tl_smc_dist_mode = 0;
     return st;
 }
@@ -1112,13 +1123,19 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     if (!looped && !select_cooperative() && hc.error == 0 && std::getenv("KABC_SMC_SELECT_TIME_OUT")) hc.error = 3;
     if (hc.error == 3 && !looped && !select_cooperative()) {
         // an ordinary launch of the select grid did not become co-resident within 0.2 s: the same run
-        // with cooperative launches (co-residency asserted by the runtime; ~21 us per launch dearer)
+        // with cooperative launches (co-residency asserted by the runtime; ~21 us per launch dearer).
+        // Single-rank runs only: a sharded run launches cooperatively from its first selection (below),
+        // so no rank can take this turn on its own while its peers go on exchanging passes.
+        (void)hipStreamSynchronize(s);
+        bufs.release();  // (the repetition allocates its own; the first run's go back to the cache first)
         tl_smc_force_coop = true;
         const kabc_status_t st2 = smc_run_impl(ctx, comm, prior, D, cost, o, res);
         tl_smc_force_coop = false;
         return st2;
     }
     if (hc.error == 4 && looped && !tl_smc_no_loop) {
+        (void)hipStreamSynchronize(s);
+        bufs.release();
         tl_smc_no_loop = true;
         const kabc_status_t st2 = kabc_smc_run(ctx, prior, D, cost, o, res);
         tl_smc_no_loop = false;

@@ -15,6 +15,8 @@ namespace kabc {
 // hipModuleLaunchKernel / hipModuleLaunchCooperativeKernel of a kernel that takes ONE by-value
 // argument struct (every kernel of this library does)
 hipError_t rtc_launch(void* fn, dim3 grid, dim3 block, const void* args, hipStream_t s);
+// the same with dynamic LDS (the run-time-dimension kernels keep their walkers' rows there)
+hipError_t rtc_launch_lds(void* fn, dim3 grid, dim3 block, const void* args, hipStream_t s, unsigned lds_bytes);
 // cooperative launch of G workgroups after an occupancy check (all co-resident or an error)
 hipError_t rtc_launch_cooperative(void* fn, unsigned G, unsigned block, const void* args, hipStream_t s);
 

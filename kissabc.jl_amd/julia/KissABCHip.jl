@@ -700,6 +700,17 @@ function prefetch_model(model::DeviceModel; families::Integer = 0)
         check(ccall((:kabc_prefetch_model, libkabc), Cint, (Ref{KabcModel}, Int32), cm, Int32(families)))
     end
 end
+"""
+    set_specialize(mode)
+
+`:env` (KABC_SPECIALIZE decides), `:off` (never specialise, never start the compiler worker),
+`:blocking` (compile at first sight), `:background` (the worker process) -- `kabc_set_specialize`.
+"""
+function set_specialize(mode::Symbol)
+    m = mode === :env ? -1 : mode === :off ? 0 : mode === :blocking ? 1 : mode === :background ? 2 :
+        error("set_specialize: :env, :off, :blocking or :background")
+    check(ccall((:kabc_set_specialize, libkabc), Cint, (Int32,), Int32(m)))
+end
 "(started, loaded, failed, cache_hits): process-wide counters of the background specialisations"
 function spec_counters()
     out = zeros(UInt64, 4)
@@ -707,7 +718,7 @@ function spec_counters()
     (started = out[1], loaded = out[2], failed = out[3], cache_hits = out[4])
 end
 
-export DeviceCost, UserCost, UserPrior, compile_model, release_model, prefetch_model, spec_counters, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
+export DeviceCost, UserCost, UserPrior, compile_model, release_model, prefetch_model, spec_counters, set_specialize, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
        AbsDiff, NormShell, NoisyQuadDU, Mixture, NoisyBanana, WienerRms, sample_sharded, unique_id,
        comm_init_rank
 end # module
