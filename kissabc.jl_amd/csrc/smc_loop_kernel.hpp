@@ -44,6 +44,14 @@ namespace kabc {
 #ifndef KABC_LOOP_BLOCK
 #define KABC_LOOP_BLOCK 256
 #endif
+// The phase stamps (KABC_SMC_STAMPS: s_memrealtime sums per phase, tools/smc_wall_probe.py) exist in the
+// PROBES build of the library only (make PROBES=1 -> libkabc_hip_probes.so): their 24 accumulators are
+// loop-carried 64-bit values -- compiled in, they took 78 of the kernel's 440 registers (round 6).
+#ifdef KABC_PROBES
+#define KABC_STAMPS_ON 1
+#else
+#define KABC_STAMPS_ON 0
+#endif
 constexpr int kLoopBlock = KABC_LOOP_BLOCK;
 constexpr int kLoopWaves = kLoopBlock / kWave;
 constexpr int kLoopMaxG = 256;              // N <= 65 536 (the mask lives in LDS)
@@ -447,12 +455,12 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
     // not occupy twenty scalar registers; csrc/ais_kernels.hpp does the same)
     uint64_t seed_v = A.seed;
     asm volatile("" : "+v"(seed_v));
-    unsigned long long t_prev = (A.stamps && bid == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long t_prev = (KABC_STAMPS_ON && A.stamps && bid == 0) ? __builtin_amdgcn_s_memrealtime() : 0ull;
     // phase times are accumulated in registers and written once at the end (a global
     // read-modify-write per stamp cost more than the phases it measured)
     unsigned long long st_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define KABC_LSTAMP(slot)                                                      \
-    if (A.stamps && bid == 0) {                                                \
+    if (KABC_STAMPS_ON && A.stamps && bid == 0) {                                                \
         const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();     \
         st_acc[slot] += t_now - t_prev;                                        \
         t_prev = t_now;                                                        \
@@ -994,7 +1002,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
             n_alive_now = resampled ? N : ess;
             remap_pass = resampled;
             KABC_LSTAMP(6)
-            if (A.stamps && bid == 0) {
+            if (KABC_STAMPS_ON && A.stamps && bid == 0) {
                 st_acc[8] += 1;
                 st_acc[9] += nc;
                 st_acc[10] += pred ? 1 : 0;
@@ -1053,12 +1061,12 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                         prop[k] = th[k] + W;
                     }
                     n_prop = 1;
-                    if (A.stamps) {
+                    if (KABC_STAMPS_ON && A.stamps) {
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         KABC_LSTAMP(18)
                     }
                     const double lpp = factored_logpdf_push<D, SIMPLE, false>(s_prior, prop, xp, s_logtab);
-                    if (A.stamps) {
+                    if (KABC_STAMPS_ON && A.stamps) {
                         asm volatile("" :: "v"(lpp));
                         KABC_LSTAMP(19)
                     }
@@ -1080,7 +1088,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
                         }
                     }
                 }
-                if (A.stamps) {
+                if (KABC_STAMPS_ON && A.stamps) {
                     asm volatile("" :: "v"(Xn));
                     KABC_LSTAMP(20)
                 }
@@ -1093,7 +1101,7 @@ __global__ void __launch_bounds__(kLoopBlock) smc_loop_kernel(const SmcLoopArgs 
         KABC_LSTAMP(7)
     }
 
-    if (A.stamps && bid == 0 && tid == 0)
+    if (KABC_STAMPS_ON && A.stamps && bid == 0 && tid == 0)
         for (int j = 0; j < 24; ++j) A.stamps[j] = st_acc[j];
     // ================= epilogue: the final alive mask and the control record
     if (in) A.alive[i] = alive_i ? 1 : 0;
