@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KABC_VERSION 320 /* 0.3.2: kabc_ais_driver, kabc_set_specialize, kabc_rtc_cache_dir; 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
+#define KABC_VERSION 320 /* 0.3.2: kabc_ais_driver, kabc_set_specialize, kabc_rtc_cache_dir, kabc_compile_mvprior_plugin; 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
 /* AIS, smc, ABCDE and pfilter accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM
  * run-time-dimension kernels keep the walker / particle rows in memory (several times slower per
@@ -234,6 +234,25 @@ kabc_status_t kabc_plugin_precompile(int32_t cost_id, int32_t family, int32_t D,
  * cache of code objects: KABC_RTC_CACHE_DIR, default next to the library) -- the way a user
  * cost does.  length(prior) <= KABC_MAX_DIM for such priors. */
 kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32_t* out_kind);
+
+/* ---- joint (multivariate) user priors ---------------------------------------------
+ * The reference hands ANY Distribution to rand / logpdf as the prior -- a multivariate one as well
+ * (src/types.jl:30,34-35,52: unconditional_sample = rand(rng, prior), loglike calls logpdf(prior, x);
+ * src/smc.jl:92-93).  A joint density that is not a product of univariate ones (a Dirichlet, an AR(1)
+ * process, a copula) is a C snippet defining
+ *   KABC_HD double kabc_user_mvprior_logpdf(const double* x, int D, const double* p, int pstride,
+ *                                           const double* tab);
+ *   KABC_HD void   kabc_user_mvprior_rand(double* out, int D, const double* p, int pstride,
+ *                                         const kabc_slotwin_t* w);
+ * x: the whole parameter vector (a joint prior is continuous: push_p is the identity); component k's
+ * parameters are p[k * pstride + 0..2] = kabc_prior_t.p[0..2] of component k (p[3] belongs to the
+ * library); -Inf outside the support; tab as for the univariate families.  rand fills out[0..D) from
+ * the walker's window w: kabc_slot(w, j), j < D * KABC_SLOTS_PER_DIM, and the helpers of
+ * kabc_sampling_base.h.  *out_kind (>= KABC_PRIOR_USER) goes into the kind of ALL D components of the
+ * prior (it does not mix with other components).  Everything else is as for the univariate user
+ * families: compiled at once by hipRTC, no prebuilt kernels, the kernel families of a (prior, cost)
+ * pair compiled at first use and cached; length(prior) up to KABC_MAX_DIM_DYN. */
+kabc_status_t kabc_compile_mvprior_plugin(const char* src, int32_t* out_kind);
 
 /* ---- kernels specialised for ONE model ------------------------------------------
  * Compiles the kernel families of `families` (bit 0 AIS, 1 smc, 2 ABCDE, 3 pfilter, 4 AIS of small

@@ -96,6 +96,20 @@ KABC_HD double kabc_sample_prior(const kabc_prior_t* pr, const kabc_slotwin_t* w
         default:
             /* a user family (kind >= KABC_PRIOR_USER): kabc_user_prior_rand of its snippet, compiled
              * into this translation unit in front of this header (capi_plugin.hip: model units) */
+#ifdef KABC_USER_MVPRIOR_RAND
+            /* a JOINT user prior (kabc_compile_mvprior_plugin): all D components carry its kind and the
+             * draw is one function of the whole vector.  `pr` is a RESOLVED component of a contiguous array
+             * (p[3] = D), `w` its window (base = k * KABC_SLOTS_PER_DIM): coordinate k of the draw the
+             * snippet makes from the walker's window at base 0 -- the same vector for every k. */
+            if (pr->kind >= KABC_PRIOR_USER && KABC_USER_PRIOR_IS_JOINT(pr->kind)) {
+                const int k = (int)(w->base / KABC_SLOTS_PER_DIM), D = (int)pr->p[3];
+                double tmp[KABC_MAX_DIM_DYN];
+                kabc_slotwin_t w0 = *w;
+                w0.base = 0u;
+                KABC_USER_MVPRIOR_RAND(pr->kind, tmp, D, (pr - k)->p, (int)(sizeof(kabc_prior_t) / sizeof(double)), &w0);
+                return tmp[k];
+            }
+#endif
 #ifdef KABC_USER_PRIOR_RAND
             if (pr->kind >= KABC_PRIOR_USER) return KABC_USER_PRIOR_RAND(pr->kind, pr->p, w);
 #endif

@@ -13,10 +13,10 @@ from .api import (ABCDE, AIS, AisEnsemble, ApproxKernelizedPosterior, ApproxPost
 from . import comm
 from .comm import Comm, EnsembleGroup
 from .costs import DeviceCost
-from .distributions import (Beta, DiscreteUniform, Exponential, Factored, Gamma, InitFromSnippet,
+from .distributions import (Ar1Normal, Beta, Dirichlet, DiscreteUniform, Exponential, Factored, Gamma, InitFromSnippet,
                             LogNormal, MultivariateNormal, MvNormal, NegativeBinomial, Normal, Product,
                             Laplace, Poisson, Truncated, TruncatedGamma, TruncatedNormal, Uniform, UserInit,
-                            UserPrior, truncated)
+                            UserMvPrior, UserPrior, truncated)
 
 __all__ = [
     "ABCDE", "AIS", "AisEnsemble", "ApproxKernelizedPosterior", "ApproxPosterior", "CommonLogDensity",
@@ -25,5 +25,5 @@ __all__ = [
     "Truncated", "truncated", "TruncatedNormal", "Beta", "DiscreteUniform", "NegativeBinomial",
     "Exponential", "Gamma", "LogNormal", "Product", "MvNormal", "MultivariateNormal", "Context", "KabcError", "default_context", "LIB_PATH",
     "KABC_MAX_DIM", "comm", "Comm", "EnsembleGroup", "UserInit", "InitFromSnippet",
-    "UserPrior", "Poisson", "Laplace", "TruncatedGamma", "compile_model", "set_specialize",
+    "UserPrior", "UserMvPrior", "Dirichlet", "Ar1Normal", "Poisson", "Laplace", "TruncatedGamma", "compile_model", "set_specialize",
 ]

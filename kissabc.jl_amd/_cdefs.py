@@ -127,6 +127,7 @@ PROTOTYPES = {
     "kabc_compile_cost_plugin": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
                                          C.POINTER(C.c_int32)]),
     "kabc_compile_prior_plugin": (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_int32)]),
+    "kabc_compile_mvprior_plugin": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "kabc_compile_model": (C.c_int, [C.POINTER(Model), C.c_int32, C.POINTER(C.c_int32)]),
     "kabc_model_release": (C.c_int, [C.c_int32]),
     "kabc_prefetch_model": (C.c_int, [C.POINTER(Model), C.c_int32]),

@@ -355,17 +355,20 @@ def sample(model, spl, *args, ntransitions=1, discard_initial=0, retry_sampling=
         seeds = chain_seeds(seed, Nc)
         ens = AisEnsemble(model, N, ctx=ctx, seeds=seeds)
         gk = max(1, -(-Ns // N))
-        pool = concurrent.futures.ThreadPoolExecutor(1)
-        buf = pool.submit(_lib.pinned_empty, (gk, Nc, N, D))
+        big = gk * Nc * N * D * 8 > (1 << 20)   # (a small trace is not worth a helper thread: see below)
+        pool = concurrent.futures.ThreadPoolExecutor(1) if big else None
+        buf = pool.submit(_lib.pinned_empty, (gk, Nc, N, D)) if big else None
         try:
             ens.init(retry_sampling)
             gd = -(-int(discard_initial) // N)
             if gd:
                 ens.advance(gd, ntransitions)
-            tr = ens.advance(gk, ntransitions, out=buf.result())        # [gk][Nc][N][D]
+            tr = ens.advance(gk, ntransitions,
+                             out=buf.result() if big else _lib.pinned_empty((gk, Nc, N, D)))   # [gk][Nc][N][D]
             chains = np.ascontiguousarray(tr.transpose(1, 0, 2, 3)).reshape(Nc, gk * N, D)[:, :Ns]
         finally:
-            pool.shutdown(wait=True)
+            if pool is not None:
+                pool.shutdown(wait=True)
             ens.close()
         stacked = chains.reshape(Nc * Ns, D)  # chainsstack, src/KissABC.jl:96-104
         return stacked if return_array else _bundle(stacked, model.scalar)

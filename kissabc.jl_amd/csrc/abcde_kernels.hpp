@@ -99,7 +99,7 @@ __device__ __forceinline__ double logpdf_push_n(const PriorSet& P, const PriorDe
             const double l = comp_logpdf_general_body(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, v);
             s = (k == 0) ? l : s + l;
         }
-        return s;
+        return joint_logpdf_or(s, dP[0].kind, xp, n, dP, kabc_log_tab);
     }
 }
 
@@ -143,8 +143,9 @@ __global__ void __launch_bounds__(kAbcdeBlock) abcde_init_kernel(const AbcdeArgs
         for (int k = 0; k < D; ++k) {
             kabc_slotwin_t win = {A.seed, (uint64_t)attempt, (uint32_t)i, A.dom_init,
                                   (uint32_t)k * KABC_SLOTS_PER_DIM};
-            const kabc_prior_t pr = DT ? A.raw[k] : A.draw[k];
-            x[k] = kabc_sample_prior(&pr, &win);
+            // (a pointer INTO the components' array: a joint prior's sampler reaches component 0 from component k)
+            const kabc_prior_t* pr = DT ? &A.raw[k] : &A.draw[k];
+            x[k] = kabc_sample_prior(pr, &win);
         }
         lp = logpdf_push_n<DT>(A.prior, A.dprior, D, x, xp);
         kabc_cost_rng_t rng = {A.seed, (uint64_t)attempt, (uint32_t)i, A.dom_init_cost, 0u};

@@ -66,7 +66,7 @@ __device__ __forceinline__ void dyn_loglike(const AisDynArgs& A, const double* y
         const double l = comp_logpdf_general_body(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, v);
         s = (k == 0) ? l : s + l;
     }
-    lp = s;
+    lp = joint_logpdf_or(s, A.prior[0].kind, xp, D, A.prior, kabc_log_tab);
     ev = kabc_isfinite(lp);
     if (A.posterior == KABC_POSTERIOR_KERNELIZED) {
         ll = lp;
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(kWave) ais_dyn_half_kernel(const AisDynArgs A)
                 } else {
                     double sm = lk[0];  // left to right, as logpdf(d::Factored, x) sums (src/priors.jl:30-36)
                     for (int k = 1; k < D; ++k) sm = sm + lk[k];
-                    nlp = sm;
+                    nlp = joint_logpdf_or(sm, sp[0].kind, xp, D, sp, kabc_log_tab);
                     ev = kabc_isfinite(nlp);
                     if (A.posterior == KABC_POSTERIOR_KERNELIZED) {
                         nll = nlp;
@@ -350,8 +350,7 @@ __global__ void __launch_bounds__(kWave) ais_dyn_init_kernel(const AisDynArgs A)
     while (true) {
         for (int k = 0; k < D; ++k) {
             kabc_slotwin_t win = {A.seed, attempt, w, KABC_DOM_AIS_INIT, (uint32_t)k * KABC_SLOTS_PER_DIM};
-            const kabc_prior_t pr = A.raw[k];
-            x[k] = kabc_sample_prior(&pr, &win);
+            x[k] = kabc_sample_prior(&A.raw[k], &win);  // (a pointer INTO the array: joint priors, kabc_sampling.h)
         }
         kabc_cost_rng_t rng = {A.seed, attempt, w, KABC_DOM_AIS_INIT_COST, 0u};
         bool ev;

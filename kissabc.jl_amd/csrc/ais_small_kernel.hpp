@@ -281,9 +281,19 @@ __global__ void __launch_bounds__(kAisSmallBlock) ais_small_kernel(const AisSmal
         const bool trace_on = __builtin_amdgcn_readfirstlane(A.trace != nullptr ? 1 : 0) != 0;
         // a stochastic cost reads its slot's variates while it is evaluated: the slot goes back late
         constexpr bool kLateRelease = kPre > 0 || kAuxW > 0;
-        constexpr int kWPP = kWave / D;  // walk lanes per pass of the dense displacement
-        const int wq = lane / D, wk = lane - wq * D;
 
+        // the NEXT unit's record (and, within a batch, its partner rows), requested one sub-step ahead: the hand-over
+        // words, the record and the rows are three dependent LDS round trips -- at ntransitions >= 2 on a few walkers
+        // they were a third of a sub-step
+        // (up to eight parameters: beyond, the second register set does not fit beside the rows)
+        constexpr bool kPrefetch = D <= 8;
+        constexpr bool kPrefetchRows = kPrefetch;
+        uint32_t n_mva = 0, n_bb = 0, n_cc = 0;
+        double n_logu = 0.0;
+        constexpr int kZ = D + 1 > 3 ? D + 1 : 3;  // DE: gamma + D normals; walk: three normals (D = 1: more than D + 1)
+        double n_zs[kPrefetch ? kZ : 1];
+        double n_pa[kPrefetchRows ? D : 1], n_pb[kPrefetchRows ? D : 1], n_pc[kPrefetchRows ? D : 1];
+        bool have_nxt = false, have_rows = false;
         unsigned int n_eval = 0, n_acc = 0;
         int err = 0;
         uint32_t u = 0;  // this consumer's unit counter
@@ -314,53 +324,91 @@ __global__ void __launch_bounds__(kAisSmallBlock) ais_small_kernel(const AisSmal
 #pragma unroll 1
                     for (int s = 0; s < nt; ++s) {
                         Slot& SL = ring[c * S + slot];
-                        while (lds_word_peek(&s_full[c * S + slot]) != u + 1u) __builtin_amdgcn_s_sleep(1);
-                        lds_acquire();
                         const uint64_t t = A.t0 + (uint64_t)g * (uint64_t)nt + (uint64_t)s;
-                        // -- ais_walk_propose (src/transition.jl:24-43): Xs = (a + (b + c)) / 3,
-                        //    W = z1 (a - Xs) + z2 (b - Xs) + z3 (c - Xs), formed here from the frozen half as
-                        //    dense (walk lane, coordinate) items; W_k overwrites the walk lane's normals
-                        //    (every item of a pass reads them before any item writes: one wavefront, in order)
-                        const int nDE = __builtin_amdgcn_readfirstlane(SL.counts[0]);
-                        const int nWK = __builtin_amdgcn_readfirstlane(SL.counts[1]);
-#pragma unroll 1
-                        for (int pass = 0; pass * kWPP < nWK; ++pass) {
-                            const int qw = pass * kWPP + wq;
-                            if (wq < kWPP && qw < nWK) {
-                                const int l = SL.listB[nDE + qw];
-                                const uint32_t ra = SL.rec.mva[0][l] & 0x3fffffffu, rb = SL.rec.bb[0][l],
-                                               rc = SL.rec.cc[0][l];
-                                const double va = xc[ra * D + wk], vb = xc[rb * D + wk], vc = xc[rc * D + wk];
-                                const double z0 = SL.rec.zs[0][0][l], z1 = SL.rec.zs[0][1][l], z2 = SL.rec.zs[0][2][l];
-                                const double Xs = kabc_div_rc(va + (vb + vc), 3.0, 1.0 / 3.0);
-                                SL.rec.zs[0][wk][l] = z0 * (va - Xs) + z1 * (vb - Xs) + z2 * (vc - Xs);
-                            }
-                        }
-                        if (nWK > 0) wave_lds_fence();
-                        if (active) {
-                        // -- the record and the partner rows
-                        const uint32_t mva = SL.rec.mva[0][lane];
-                        const uint32_t bbv = SL.rec.bb[0][lane];
-                        const uint32_t ccv = SL.rec.cc[0][lane];
-                        const double logu = SL.rec.logu[0][lane];
-                        double zs[D + 1];
+                        // -- the unit's record: the registers requested during the previous sub-step, else
+                        //    wait for the slot's FULL word and read it now
+                        uint32_t mva, bbv, ccv;
+                        double logu;
+                        double zs[kZ];
+                        if (kPrefetch && have_nxt) {
+                            mva = n_mva;
+                            bbv = n_bb;
+                            ccv = n_cc;
+                            logu = n_logu;
+                            if constexpr (kPrefetch) {
 #pragma unroll
-                        for (int j = 0; j < D + 1; ++j) zs[j] = SL.rec.zs[0][j][lane];
-                        double pa[D], pb[D];
-                        load_row<D>(&xc[(mva & 0x3fffffffu) * D], pa);
-                        load_row<D>(&xc[bbv * D], pb);
+                                for (int j = 0; j < kZ; ++j) zs[j] = n_zs[j];
+                            }
+                        } else {
+                            while (lds_word_peek(&s_full[c * S + slot]) != u + 1u) __builtin_amdgcn_s_sleep(1);
+                            lds_acquire();
+                            mva = SL.rec.mva[0][lane];
+                            bbv = SL.rec.bb[0][lane];
+                            ccv = SL.rec.cc[0][lane];
+                            logu = SL.rec.logu[0][lane];
+#pragma unroll
+                            for (int j = 0; j < kZ; ++j) zs[j] = SL.rec.zs[0][j][lane];
+                        }
+                        // -- the partner rows (a; b of DE / walk; c of walk -- b and c default to a: every lane
+                        //    reads three valid rows, no divergence around the loads), requested during the previous
+                        //    sub-step when that one worked on the same batch (the complementary half is frozen)
+                        double pa[D], pb[D], pc[D];
+                        if (kPrefetchRows && have_rows) {
+                            if constexpr (kPrefetchRows) {
+#pragma unroll
+                                for (int k = 0; k < D; ++k) {
+                                    pa[k] = n_pa[k];
+                                    pb[k] = n_pb[k];
+                                    pc[k] = n_pc[k];
+                                }
+                            }
+                        } else {
+                            load_row<D>(&xc[(mva & 0x3fffffffu) * D], pa);
+                            load_row<D>(&xc[bbv * D], pb);
+                            if constexpr (kPrefetch) load_row<D>(&xc[ccv * D], pc);  // (beyond: read by the walk lanes, below)
+                        }
+                        // is the NEXT unit's record there already?  (The producers run ahead: it usually is.)
+                        const int nslot = slot + 1 == S ? 0 : slot + 1;
+                        uint32_t nfull = 0u;
+                        if constexpr (kPrefetch) nfull = lds_word_peek(&s_full[c * S + nslot]);
                         if constexpr (!kLateRelease) {
-                            lds_word_publish(&s_done[c], u + 1u, lane);
+                            lds_word_publish(&s_done[c], u + 1u, lane);  // (this slot's words are in registers)
+                        }
+                        have_rows = false;
+                        if constexpr (kPrefetch) {
+                            have_nxt = __builtin_amdgcn_readfirstlane((int)nfull) == (int)(u + 2u);
+                            if (have_nxt) {  // its words fly while this sub-step computes
+                                lds_acquire();
+                                const Slot& SN = ring[c * S + nslot];
+                                n_mva = SN.rec.mva[0][lane];
+                                n_bb = SN.rec.bb[0][lane];
+                                n_cc = SN.rec.cc[0][lane];
+                                n_logu = SN.rec.logu[0][lane];
+#pragma unroll
+                                for (int j = 0; j < kZ; ++j) n_zs[j] = SN.rec.zs[0][j][lane];
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         const uint32_t move = mva >> 30;
                         double y[D];
                         double corr = 0.0;
-#pragma unroll
-                        for (int k = 0; k < D; ++k) y[k] = x[k] + zs[k];  // walk (every lane; others overwrite)
                         double xa[D];
+                        bool acc = false, ev = false;
+                        if (active) {
 #pragma unroll
                         for (int k = 0; k < D; ++k) xa[k] = x[k] - pa[k];
+                        if (move == 3u) {
+                            if constexpr (!kPrefetch) load_row<D>(&xc[ccv * D], pc);
+                            // ais_walk_propose  src/transition.jl:24-43: Xs = (a + (b + c)) / 3,
+                            // W = z1 (a - Xs) + z2 (b - Xs) + z3 (c - Xs); the displacement depends on the ensemble,
+                            // so it is formed here, not by the producers that run ahead of the half-steps
+#pragma unroll
+                            for (int k = 0; k < D; ++k) {
+                                const double Xs = kabc_div_rc(pa[k] + (pb[k] + pc[k]), 3.0, 1.0 / 3.0);
+                                const double W = zs[0] * (pa[k] - Xs) + zs[1] * (pb[k] - Xs) + zs[2] * (pc[k] - Xs);
+                                y[k] = x[k] + W;
+                            }
+                        }
                         if (move == 1u) {
                             // stretch_propose  src/transition.jl:51-59
                             const double Z = zs[0];
@@ -382,7 +430,18 @@ __global__ void __launch_bounds__(kAisSmallBlock) ais_small_kernel(const AisSmal
                                 y[k] = x[k] + Wk + Tk;
                             }
                         }
+                        }  // (active: the proposal)
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (kPrefetchRows) {
+                            // the next sub-step of THIS batch: its partner rows come from the same frozen half
+                            if (have_nxt && s + 1 < nt) {
+                                load_row<D>(&xc[(n_mva & 0x3fffffffu) * D], n_pa);
+                                load_row<D>(&xc[n_bb * D], n_pb);
+                                load_row<D>(&xc[n_cc * D], n_pc);
+                                have_rows = true;
+                            }
+                        }
+                        if (active) {
                         // ld = loglike(density, push_p(density, p))   src/transition.jl:75
                         kabc_cost_rng_t rng = {seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u, 0u, nullptr, slogtab};
                         if constexpr (kAuxW > 0) {
@@ -395,18 +454,13 @@ __global__ void __launch_bounds__(kAisSmallBlock) ais_small_kernel(const AisSmal
                             rng.pre_stride = (uint32_t)kBatch;
                         }
                         double nlp, nll;
-                        bool ev;
                         loglike<D, COST, PC>(sprior, box, gbox, PK, A.eps, A.reps, y, cparams, A.cost_data, A.cost_ndata,
                                              &rng, nlp, nll, ev, slogtab, kNbTabs > 0 ? snb : nullptr);
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (kLateRelease) {
-                            lds_word_publish(&s_done[c], u + 1u, lane);
-                        }
                         n_eval += ev ? 1u : 0u;
                         // accept(...)  src/types.jl:62-75, :96-104 (as ais_half_kernel's consumer)
                         const bool valid = ev && ld_valid(PK, nlp, nll);
                         const double e = -logu;  // randexp(rng)
-                        bool acc;
                         if (PK == KABC_POSTERIOR_KERNELIZED) {
                             const double lW = corr + (nlp + nll) - (lp + ll);
                             acc = valid && (-e <= lW);
@@ -439,6 +493,9 @@ __global__ void __launch_bounds__(kAisSmallBlock) ais_small_kernel(const AisSmal
                             d[5] = ev ? 1 : 0;
                         }
                         }  // (active)
+                        if constexpr (kLateRelease) {
+                            lds_word_publish(&s_done[c], u + 1u, lane);  // (the cost has read the slot's variates)
+                        }
                         ++u;
                         slot = slot + 1 == S ? 0 : slot + 1;
                     }

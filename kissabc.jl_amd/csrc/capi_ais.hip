@@ -319,7 +319,11 @@ static kabc_status_t ais_resolve_half(kabc_ais_t* h) {
         if (!fn && unit_required(h->unit)) return KABC_ERR_DEVICE;
     }
     if (!fn) {  // (no unit, or a specialisation that is not there (yet): the prebuilt kernels)
-        fn = find_ais_kernel(h->cost_id, h->D, h->pc + pk_off);
+        int pc = h->pc;
+        // (A/B runs: what the GENERAL class costs a SIMPLE / NORMAL prior -- the classes give the same bits)
+        if (const char* e = std::getenv("KABC_PREBUILT_CLASS"))
+            if (e[0] == 'g' && pc != kPriorBox) pc = kPriorGeneral;
+        fn = find_ais_kernel(h->cost_id, h->D, pc + pk_off);
         if (!fn && h->pc == kPriorNormal)  // plugins instantiate SIMPLE only
             fn = find_ais_kernel(h->cost_id, h->D, kPriorSimple + pk_off);
     }

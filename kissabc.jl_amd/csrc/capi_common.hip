@@ -39,10 +39,24 @@ kabc_status_t resolve_priors(kabc_ctx_t* ctx, const kabc_prior_t* prior, int D, 
         set_error("invalid prior: NULL or D outside 1..%d", KABC_MAX_DIM_DYN);
         return KABC_ERR_INVALID_ARG;
     }
-    int nmv = 0;
+    int nmv = 0, njoint = 0;
     for (int k = 0; k < D; ++k) {
         out[k] = prior[k];
         nmv += prior[k].kind == KABC_PRIOR_MVNORMAL;
+        njoint += (prior[k].kind >= KABC_PRIOR_USER && user_prior_is_joint(prior[k].kind)) ? 1 : 0;
+    }
+    if (njoint) {
+        // a joint user prior (kabc_compile_mvprior_plugin) is all D components or none, one kind; p[3] is
+        // the library's: D, for the sampler that is handed one component at a time (kabc_sampling.h)
+        bool same = njoint == D;
+        for (int k = 1; k < D && same; ++k) same = prior[k].kind == prior[0].kind;
+        if (!same) {
+            set_error("a joint user prior is all D components of the prior, every one with the kind "
+                      "kabc_compile_mvprior_plugin returned; it does not mix with other components");
+            return KABC_ERR_INVALID_ARG;
+        }
+        for (int k = 0; k < D; ++k) out[k].p[3] = (double)D;
+        return KABC_OK;
     }
     if (nmv == 0) return KABC_OK;
     if (nmv != D || D > KABC_MAX_DIM) {

@@ -183,6 +183,7 @@ struct PriorPlugin {
     int32_t kind;
     int32_t discrete;
     std::string src;
+    bool joint = false;  // kabc_compile_mvprior_plugin: one density of the whole vector
 };
 static std::vector<PriorPlugin*> g_prior_plugins;  // kind = KABC_PRIOR_USER + index (g_mu)
 
@@ -198,6 +199,10 @@ bool user_prior_info(int kind, int* discrete) {
     if (discrete) *discrete = p->discrete;
     return true;
 }
+bool user_prior_is_joint(int kind) {
+    const PriorPlugin* p = find_prior_plugin(kind);
+    return p && p->joint;
+}
 
 // the prior part of a translation unit: every listed family's snippet under its own function
 // names + the dispatch the built-in switch statements fall through to (include/kabc_sampling.h
@@ -207,9 +212,24 @@ static std::string priors_head(const std::vector<int>& kinds) {
     std::string t = "#include \"kabc_sampling_base.h\"\n";
     std::string lp = "#define KABC_USER_PRIOR_LOGPDF(kind, x, p, tab) (";
     std::string rd = "#define KABC_USER_PRIOR_RAND(kind, p, w) (";
+    // joint families (kabc_compile_mvprior_plugin): one density / one draw of the whole vector
+    std::string isj = "#define KABC_USER_PRIOR_IS_JOINT(kind) (";
+    std::string jlp = "#define KABC_USER_MVPRIOR_LOGPDF(kind, x, D, p, st, tab) (";
+    std::string jrd = "#define KABC_USER_MVPRIOR_RAND(kind, out, D, p, st, w) do { ";
+    bool any_joint = false;
     for (int k : kinds) {
         const PriorPlugin* pp = find_prior_plugin(k);
         const std::string sk = std::to_string(k);
+        if (pp && pp->joint) {
+            any_joint = true;
+            t += "#define kabc_user_mvprior_logpdf kabc_user_mvprior_logpdf_" + sk +
+                 "\n#define kabc_user_mvprior_rand kabc_user_mvprior_rand_" + sk + "\n" + pp->src +
+                 "\n#undef kabc_user_mvprior_logpdf\n#undef kabc_user_mvprior_rand\n";
+            isj += "(kind) == " + sk + " || ";
+            jlp += "(kind) == " + sk + " ? kabc_user_mvprior_logpdf_" + sk + "(x, D, p, st, tab) : ";
+            jrd += "if ((kind) == " + sk + ") kabc_user_mvprior_rand_" + sk + "(out, D, p, st, w); ";
+            continue;
+        }
         t += "#define kabc_user_prior_logpdf kabc_user_prior_logpdf_" + sk +
              "\n#define kabc_user_prior_rand kabc_user_prior_rand_" + sk + "\n" + (pp ? pp->src : std::string()) +
              "\n#undef kabc_user_prior_logpdf\n#undef kabc_user_prior_rand\n";
@@ -217,6 +237,7 @@ static std::string priors_head(const std::vector<int>& kinds) {
         rd += "(kind) == " + sk + " ? kabc_user_prior_rand_" + sk + "(p, w) : ";
     }
     t += lp + "KABC_NAN)\n" + rd + "KABC_NAN)\n";
+    if (any_joint) t += isj + "0)\n" + jlp + "KABC_NAN)\n" + jrd + "} while (0)\n";
     return t;
 }
 
@@ -1053,6 +1074,7 @@ static bool spec_eligible(const kabc_prior_t* prior, int D) {
     for (int k = 0; k < D; ++k) {
         const int kd = prior[k].kind;
         if (kd == KABC_PRIOR_MVNORMAL || kd == KABC_PRIOR_USER_INIT) return false;
+        if (kd >= KABC_PRIOR_USER && user_prior_is_joint(kd)) return false;  // (one density of the vector: nothing per component to fold)
         allbox = allbox && (kd == KABC_PRIOR_UNIFORM || kd == KABC_PRIOR_DISCRETE_UNIFORM);
         allnormal = allnormal && kd == KABC_PRIOR_NORMAL;
     }
@@ -1378,6 +1400,41 @@ extern "C" kabc_status_t kabc_register_cost_plugin(const char* path, int32_t* ou
     return KABC_OK;
 }
 
+extern "C" kabc_status_t kabc_compile_mvprior_plugin(const char* src, int32_t* out_kind) {
+    if (!src || !out_kind) {
+        set_error("kabc_compile_mvprior_plugin: NULL argument");
+        return KABC_ERR_INVALID_ARG;
+    }
+    PriorPlugin* P = new PriorPlugin();
+    P->src = src;
+    P->discrete = 0;
+    P->joint = true;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (const PriorPlugin* q : g_prior_plugins)  // (the same snippet registered again is the same family)
+            if (q->joint && q->src == P->src) {
+                *out_kind = q->kind;
+                delete P;
+                return KABC_OK;
+            }
+        P->kind = KABC_PRIOR_USER + (int32_t)g_prior_plugins.size();
+        g_prior_plugins.push_back(P);
+    }
+    // the snippet alone first, with both functions called the way the kernels call them
+    const std::string sk = std::to_string(P->kind);
+    const std::string check = priors_head({P->kind}) +
+        "extern \"C\" __global__ void kabc_mvprior_check(double* o, const double* p, const kabc_slotwin_t* w) {\n"
+        "    o[0] = KABC_USER_MVPRIOR_LOGPDF(" + sk + ", o + 1, 3, p, 5, kabc_log_tab);\n"
+        "    KABC_USER_MVPRIOR_RAND(" + sk + ", o + 4, 3, p, 5, w);\n}\n";
+    if (kabc_status_t st = rtc_compile(check, nullptr, false, {}, nullptr, nullptr)) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        P->src = "#error \"this joint prior failed to compile at registration\"\n";  // (the kind stays taken)
+        return st;
+    }
+    *out_kind = P->kind;
+    return KABC_OK;
+}
+
 extern "C" kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t discrete, int32_t* out_kind) {
     if (!src || !out_kind) {
         set_error("kabc_compile_prior_plugin: NULL argument");
@@ -1390,7 +1447,7 @@ extern "C" kabc_status_t kabc_compile_prior_plugin(const char* src, int32_t disc
         std::lock_guard<std::mutex> lk(g_mu);
         // (the same snippet registered again is the same family)
         for (const PriorPlugin* q : g_prior_plugins)
-            if (q->src == P->src && q->discrete == P->discrete) {
+            if (!q->joint && q->src == P->src && q->discrete == P->discrete) {
                 *out_kind = q->kind;
                 delete P;
                 return KABC_OK;

@@ -227,6 +227,25 @@ __device__ __forceinline__ double mvn_logpdf_total(const double* blk, MvnRow<D> 
     return sm;
 }
 
+// A JOINT user prior (kabc_compile_mvprior_plugin, include/kabc.h: any multivariate Distribution as the
+// prior -- src/types.jl:30,34-35,52, src/smc.jl:92-93): every component carries its kind, and the
+// log-density of the push_p'ed VECTOR replaces the sum over components (NaN for such a kind).  P: the
+// prepared components (component k's parameters at P[k].p[0..2]); a unit without joint families compiles
+// this to `return s`.
+__device__ __forceinline__ double joint_logpdf_or(double s, int kind0, const double* xp, int D,
+                                                  const PriorDev* P, const double* tab) {
+#ifdef KABC_USER_MVPRIOR_LOGPDF
+    if (kind0 >= KABC_PRIOR_USER && KABC_USER_PRIOR_IS_JOINT(kind0))
+        return KABC_USER_MVPRIOR_LOGPDF(kind0, xp, D, &P[0].p[0], (int)(sizeof(PriorDev) / sizeof(double)), tab);
+#endif
+    (void)kind0;
+    (void)xp;
+    (void)D;
+    (void)P;
+    (void)tab;
+    return s;
+}
+
 // host-side classification used to pick the kernel variant
 inline bool prior_is_simple(int kind) {
     return kind == KABC_PRIOR_UNIFORM || kind == KABC_PRIOR_NORMAL ||
@@ -334,6 +353,7 @@ __device__ __forceinline__ double factored_logpdf_push(const PriorDev* __restric
         }
     }
 #endif
+    if constexpr (!SIMPLE) s = joint_logpdf_or(s, kind0, xp, D, P, tab);
     return s;
 }
 template <int D, bool SIMPLE = false>

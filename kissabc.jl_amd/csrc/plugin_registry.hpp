@@ -50,6 +50,8 @@ PluginKernel plugin_kernel(const CostPlugin* p, int family, int D, int variant);
 // ---- user prior families + model units (capi_plugin.hip) ------------------------------------
 // is `kind` a registered user family (kabc_compile_prior_plugin)?  *discrete: push_p rounds it
 bool user_prior_info(int kind, int* discrete);
+// a JOINT family (kabc_compile_mvprior_plugin): all D components of a prior carry it
+bool user_prior_is_joint(int kind);
 
 // A MODEL UNIT is the recipe of a run-time compiled translation unit for a (prior, cost) pair:
 //   * the cost's snippet when the cost is a user cost (hipRTC form),

@@ -42,7 +42,8 @@ __global__ void __launch_bounds__(256) prior_logpdf_kernel(const PriorUtilArgs A
             s = (k == 0) ? l : s + l;
         }
     }
-    if (A.mode == 0) A.out[i] = s;
+    // (a joint user prior: the log-density of the row as given)
+    if (A.mode == 0) A.out[i] = joint_logpdf_or(s, A.prior[0].kind, A.x + i * A.D, A.D, A.prior, kabc_log_tab);
 }
 
 __global__ void __launch_bounds__(256) prior_rand_kernel(const PriorUtilArgs A) {
@@ -51,8 +52,7 @@ __global__ void __launch_bounds__(256) prior_rand_kernel(const PriorUtilArgs A) 
     for (int k = 0; k < A.D; ++k) {
         kabc_slotwin_t win = {A.seed, A.attempt, A.first_walker + (uint32_t)i, A.domain,
                               (uint32_t)k * KABC_SLOTS_PER_DIM};
-        const kabc_prior_t pr = A.raw[k];
-        A.out[i * A.D + k] = kabc_sample_prior(&pr, &win);
+        A.out[i * A.D + k] = kabc_sample_prior(&A.raw[k], &win);  // (a pointer INTO the array: joint priors)
     }
 }
 

@@ -47,7 +47,7 @@ __device__ __forceinline__ double smc_dyn_logpdf_push(const SmcDynArgs& A, const
         const double l = comp_logpdf_general_body(q.kind, q.p[0], q.p[1], q.p[2], q.p[3], q.c0, q.c1, q.rb, v);
         s = (k == 0) ? l : s + l;
     }
-    return s;
+    return joint_logpdf_or(s, A.prior[0].kind, xp, A.D, A.prior, kabc_log_tab);
 }
 
 template <int COST>
@@ -60,8 +60,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_dyn_init_kernel(const SmcDynArg
         double* xp = A.scratch + (i * 2) * D;
         for (int k = 0; k < D; ++k) {
             kabc_slotwin_t win = {A.seed, 0ull, (uint32_t)i, KABC_DOM_SMC_INIT, (uint32_t)k * KABC_SLOTS_PER_DIM};
-            const kabc_prior_t pr = A.raw[k];
-            x[k] = kabc_sample_prior(&pr, &win);
+            x[k] = kabc_sample_prior(&A.raw[k], &win);  // (a pointer INTO the array: joint priors, kabc_sampling.h)
         }
         const double lp = smc_dyn_logpdf_push(A, x, xp);
         kabc_cost_rng_t rng = {A.seed, 0ull, (uint32_t)i, KABC_DOM_SMC_INIT_COST, 0u};

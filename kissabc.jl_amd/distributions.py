@@ -556,6 +556,134 @@ class MvNormal(Product):
 MultivariateNormal = MvNormal
 
 
+_user_mv_kinds = {}
+
+
+class _JointComponent(UnivariateDistribution):
+    """component k of a joint user prior: the family's kind and the component's (at most three) parameters"""
+
+    def __init__(self, kind, params, source):
+        self.kind, self._params, self.joint_source = int(kind), tuple(float(v) for v in params), source
+
+    def params(self):
+        return self._params
+
+
+class UserMvPrior(Factored):
+    """A JOINT prior from a C snippet -- the device-path counterpart of handing any multivariate
+    `Distribution` to ApproxKernelizedPosterior / ApproxPosterior / smc (the reference calls
+    rand(rng, prior) and logpdf(prior, x) on whatever it is given: src/types.jl:30,34-35,52;
+    src/smc.jl:92-93).  `source` defines
+
+        KABC_HD double kabc_user_mvprior_logpdf(const double* x, int D, const double* p, int pstride,
+                                                const double* tab);
+        KABC_HD void   kabc_user_mvprior_rand(double* out, int D, const double* p, int pstride,
+                                              const kabc_slotwin_t* w);
+
+    x: the whole vector; component k's parameters: p[k * pstride + 0..2] (`params`: D rows of at most
+    three doubles); -Inf outside the support; rand fills out[0..D) from the walker's window
+    (kabc_slot(w, j), j < D * KABC_SLOTS_PER_DIM; helpers of include/kabc_sampling_base.h).
+    kabc_compile_mvprior_plugin (include/kabc.h) compiles the snippet at once; the kernels of a model
+    with such a prior are compiled at first use, like those of a univariate user family."""
+
+    def __init__(self, source, params, name="user_mvprior"):
+        self.source, self.name = str(source), name
+        rows = [tuple(float(v) for v in np.atleast_1d(r)) for r in params]
+        if not rows or len(rows) > cd.KABC_MAX_DIM_DYN:
+            raise ValueError(f"a joint prior has 1..{cd.KABC_MAX_DIM_DYN} components")
+        if any(len(r) > 3 for r in rows):
+            raise ValueError("a component of a joint prior carries at most three parameters (kabc_prior_t.p[0..2])")
+        kind = _user_mv_kinds.get(self.source)
+        if kind is None:
+            out = C.c_int32()
+            _lib.check(_lib.load().kabc_compile_mvprior_plugin(self.source.encode(), C.byref(out)))
+            kind = _user_mv_kinds[self.source] = int(out.value)
+        self.kind = kind
+        super().__init__(*[_JointComponent(kind, r, self.source) for r in rows])
+
+    def __repr__(self):
+        return f"{self.name}(D={len(self)})"
+
+
+class Dirichlet(UserMvPrior):
+    """Dirichlet(alpha) of Distributions.jl as a prior: logpdf = sum (alpha_k - 1) log x_k - log B(alpha) on
+    the probability simplex (all x_k >= 0 and |sum x - 1| <= D * 2^-52 * 4, the tolerance of isprobvec's
+    isapprox at this scale), -Inf elsewhere; rand: independent Gamma(alpha_k, 1) draws, normalised.
+    p_k = (alpha_k, -, log B(alpha))."""
+    SOURCE = """
+KABC_HD double kabc_user_mvprior_logpdf(const double* x, int D, const double* p, int pstride, const double* tab) {
+    double sx = 0.0, s = 0.0;
+    for (int k = 0; k < D; ++k) {
+        if (!(x[k] >= 0.0)) return -KABC_INF;
+        sx += x[k];
+    }
+    if (!(kabc_fabs(sx - 1.0) <= (double)D * 0x1p-50)) return -KABC_INF;
+    for (int k = 0; k < D; ++k) {
+        const double a = p[k * pstride];
+        if (a != 1.0) s += (a - 1.0) * kabc_log_t(x[k], tab);
+    }
+    return s - p[2];
+}
+KABC_HD void kabc_user_mvprior_rand(double* out, int D, const double* p, int pstride, const kabc_slotwin_t* w) {
+    double sm = 0.0;
+    for (int k = 0; k < D; ++k) {
+        kabc_slotwin_t wk = *w;
+        wk.base = w->base + (uint32_t)k * KABC_SLOTS_PER_DIM;
+        out[k] = kabc_sample_gamma1(&wk, 0u, p[k * pstride]);
+        sm += out[k];
+    }
+    for (int k = 0; k < D; ++k) out[k] = out[k] / sm;
+}
+"""
+
+    def __init__(self, alpha):
+        a = [float(v) for v in np.atleast_1d(alpha)]
+        if len(a) < 2 or min(a) <= 0:
+            raise ValueError("Dirichlet(alpha): at least two positive concentrations")
+        logB = sum(math.lgamma(v) for v in a) - math.lgamma(sum(a))
+        self.alpha = np.array(a)
+        super().__init__(self.SOURCE, [(v, 0.0, logB) for v in a], name="Dirichlet")
+
+
+class Ar1Normal(UserMvPrior):
+    """A stationary Gaussian AR(1) process as a joint prior: x_1 ~ N(mu, sigma / sqrt(1 - rho^2)),
+    x_k | x_{k-1} ~ N(mu + rho (x_{k-1} - mu), sigma) -- a latent time series; not a product of
+    univariate densities.  p_k = (mu, sigma, rho)."""
+    SOURCE = """
+KABC_HD double kabc_user_mvprior_logpdf(const double* x, int D, const double* p, int pstride, const double* tab) {
+    const double mu = p[0], sg = p[1], rho = p[2];
+    const double s0 = sg / kabc_sqrt(1.0 - rho * rho);
+    double z = (x[0] - mu) / s0;
+    double s = -(z * z + KABC_LOG_2PI) / 2.0 - kabc_log_t(s0, tab);
+    const double lsg = kabc_log_t(sg, tab);
+    for (int k = 1; k < D; ++k) {
+        z = (x[k] - (mu + rho * (x[k - 1] - mu))) / sg;
+        s += -(z * z + KABC_LOG_2PI) / 2.0 - lsg;
+    }
+    (void)pstride;
+    return s;
+}
+KABC_HD void kabc_user_mvprior_rand(double* out, int D, const double* p, int pstride, const kabc_slotwin_t* w) {
+    const double mu = p[0], sg = p[1], rho = p[2];
+    double prev = 0.0;
+    for (int k = 0; k < D; ++k) {
+        const kabc_u128_t b = kabc_slot(w, (uint32_t)k * KABC_SLOTS_PER_DIM);
+        double z0, z1;
+        kabc_normal_pair(kabc_lo64(b), kabc_hi64(b), &z0, &z1);
+        prev = (k == 0) ? mu + sg / kabc_sqrt(1.0 - rho * rho) * z0 : mu + rho * (prev - mu) + sg * z0;
+        out[k] = prev;
+    }
+    (void)pstride;
+}
+"""
+
+    def __init__(self, D, mu=0.0, sigma=1.0, rho=0.5):
+        if not (sigma > 0 and abs(rho) < 1 and int(D) >= 1):
+            raise ValueError("Ar1Normal(D, mu, sigma, rho): sigma > 0, |rho| < 1")
+        self.mu, self.sigma, self.rho = float(mu), float(sigma), float(rho)
+        super().__init__(self.SOURCE, [(mu, sigma, rho)] * int(D), name="Ar1Normal")
+
+
 def as_factored(prior):
     """A bare univariate prior (e.g. Normal(1, 0.2), test/runtests.jl:78) is a
     1-component Factored on this path; Product / MvNormal already are Factored."""

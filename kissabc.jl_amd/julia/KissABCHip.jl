@@ -363,6 +363,51 @@ function lower_prior(d::AbstractMvNormal)
     end
     KabcPrior[KabcPrior(11, 0, (Float64(h), Float64(k - 1), 0.0, 0.0)) for k in 1:length(μ)]
 end
+# ---- any other multivariate Distribution: a JOINT prior compiled at run time -----------------
+# The reference hands whatever `prior` is to rand / logpdf (src/types.jl:30,34-35,52; src/smc.jl:92-93).  A
+# joint density that is not a product is a C snippet (kabc_user_mvprior_logpdf / kabc_user_mvprior_rand over
+# the whole vector, include/kabc.h "joint user priors") registered with kabc_compile_mvprior_plugin; all D
+# components of the lowered prior carry its kind, component k its (at most three) parameters.
+const user_mvprior_kinds = Dict{String,Int32}()
+function user_mvprior_kind(src::String)
+    get!(user_mvprior_kinds, src) do
+        k = Ref{Int32}(0)
+        check(ccall((:kabc_compile_mvprior_plugin, libkabc), Cint, (Cstring, Ref{Int32}), src, k))
+        k[]
+    end
+end
+"UserMvPrior(csrc, rows): KabcPrior[] of a run-time compiled joint prior (one row of at most three parameters per component)"
+UserMvPrior(src::String, rows) =
+    KabcPrior[KabcPrior(user_mvprior_kind(src), 0, ntuple(i -> i <= length(r) ? Float64(r[i]) : 0.0, 4)) for r in rows]
+# (the snippet kissabc.jl_amd/distributions.py ships: same text => same kind, same kernels)
+const DIRICHLET_SRC = """
+KABC_HD double kabc_user_mvprior_logpdf(const double* x, int D, const double* p, int pstride, const double* tab) {
+    double sx = 0.0, s = 0.0;
+    for (int k = 0; k < D; ++k) {
+        if (!(x[k] >= 0.0)) return -KABC_INF;
+        sx += x[k];
+    }
+    if (!(kabc_fabs(sx - 1.0) <= (double)D * 0x1p-50)) return -KABC_INF;
+    for (int k = 0; k < D; ++k) {
+        const double a = p[k * pstride];
+        if (a != 1.0) s += (a - 1.0) * kabc_log_t(x[k], tab);
+    }
+    return s - p[2];
+}
+KABC_HD void kabc_user_mvprior_rand(double* out, int D, const double* p, int pstride, const kabc_slotwin_t* w) {
+    double sm = 0.0;
+    for (int k = 0; k < D; ++k) {
+        kabc_slotwin_t wk = *w;
+        wk.base = w->base + (uint32_t)k * KABC_SLOTS_PER_DIM;
+        out[k] = kabc_sample_gamma1(&wk, 0u, p[k * pstride]);
+        sm += out[k];
+    }
+    for (int k = 0; k < D; ++k) out[k] = out[k] / sm;
+}
+"""
+function lower_prior(d::Dirichlet)
+    UserMvPrior(DIRICHLET_SRC, [(a, 0.0, d.lmnB) for a in d.alpha])   # lmnB = log B(alpha), kept by Distributions.jl
+end
 vector_valued(d) = d isa MultivariateDistribution && !(d isa Factored)
 
 "InitFrom(d): a `sample_init` for CommonLogDensity that is callable (reference path, src/types.jl:112-113) and lowers to a prior (device path)."
@@ -711,6 +756,12 @@ function set_specialize(mode::Symbol)
         error("set_specialize: :env, :off, :blocking or :background")
     check(ccall((:kabc_set_specialize, libkabc), Cint, (Int32,), Int32(m)))
 end
+"the code-object cache directory in use (\"\": none -- disabled, or no candidate nobody else can write to)"
+function rtc_cache_dir()
+    buf = Vector{Cchar}(undef, 4096)
+    ccall((:kabc_rtc_cache_dir, libkabc), Int32, (Ptr{Cchar}, Int32), buf, Int32(length(buf)))
+    GC.@preserve buf unsafe_string(pointer(buf))
+end
 "(started, loaded, failed, cache_hits): process-wide counters of the background specialisations"
 function spec_counters()
     out = zeros(UInt64, 4)
@@ -718,7 +769,7 @@ function spec_counters()
     (started = out[1], loaded = out[2], failed = out[3], cache_hits = out[4])
 end
 
-export DeviceCost, UserCost, UserPrior, compile_model, release_model, prefetch_model, spec_counters, set_specialize, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
+export DeviceCost, UserCost, UserPrior, compile_model, release_model, prefetch_model, spec_counters, set_specialize, rtc_cache_dir, UserMvPrior, InitFrom, InitFromSnippet, GaussDist, Rosenbrock, HierGaussSim, NormalMeanStdSim, DiracSq,
        AbsDiff, NormShell, NoisyQuadDU, Mixture, NoisyBanana, WienerRms, sample_sharded, unique_id,
        comm_init_rank
 end # module

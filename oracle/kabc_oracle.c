@@ -149,6 +149,42 @@ int32_t orc_register_user_prior(int32_t kind, void* logpdf, void* rnd, int32_t d
     g_user_prior[kind - KABC_PRIOR_USER].discrete = discrete != 0;
     return KABC_OK;
 }
+/* joint user priors (kabc_compile_mvprior_plugin, include/kabc.h): one density / one draw of the whole
+ * vector; all D components of the prior carry the kind (any Distribution as the prior: src/types.jl:30,
+ * 34-35,52; src/smc.jl:92-93) */
+typedef double (*orc_user_mvprior_logpdf_fn)(const double*, int, const double*, int, const double*);
+typedef void (*orc_user_mvprior_rand_fn)(double*, int, const double*, int, const kabc_slotwin_t*);
+static struct {
+    orc_user_mvprior_logpdf_fn logpdf;
+    orc_user_mvprior_rand_fn rand;
+} g_user_mvprior[ORC_MAX_USER_PRIORS];
+static double orc_joint_component_nan(double x, const double* p, const double* tab) {
+    (void)x;
+    (void)p;
+    (void)tab;
+    return KABC_NAN;  /* (the device's per-component value for such a kind: replaced by the joint density) */
+}
+static double orc_joint_component_rand_nan(const double* p, const kabc_slotwin_t* w) {
+    (void)p;
+    (void)w;
+    return KABC_NAN;
+}
+int32_t orc_register_user_mvprior(int32_t kind, void* logpdf, void* rnd) {
+    if (kind < KABC_PRIOR_USER || kind >= KABC_PRIOR_USER + ORC_MAX_USER_PRIORS || !logpdf || !rnd)
+        return fail(KABC_ERR_INVALID_ARG, "orc_register_user_mvprior: bad kind / NULL function");
+    g_user_mvprior[kind - KABC_PRIOR_USER].logpdf = (orc_user_mvprior_logpdf_fn)logpdf;
+    g_user_mvprior[kind - KABC_PRIOR_USER].rand = (orc_user_mvprior_rand_fn)rnd;
+    /* the univariate table knows the kind too (continuous; its component value is never used) */
+    g_user_prior[kind - KABC_PRIOR_USER].logpdf = orc_joint_component_nan;
+    g_user_prior[kind - KABC_PRIOR_USER].rand = orc_joint_component_rand_nan;
+    g_user_prior[kind - KABC_PRIOR_USER].discrete = 0;
+    return KABC_OK;
+}
+static int user_prior_joint(int kind) {
+    return kind >= KABC_PRIOR_USER && kind < KABC_PRIOR_USER + ORC_MAX_USER_PRIORS &&
+           g_user_mvprior[kind - KABC_PRIOR_USER].logpdf != 0;
+}
+
 static int user_prior_known(int kind) {
     return kind >= KABC_PRIOR_USER && kind < KABC_PRIOR_USER + ORC_MAX_USER_PRIORS &&
            g_user_prior[kind - KABC_PRIOR_USER].logpdf != 0;
@@ -277,6 +313,9 @@ static double comp_logpdf_k(const prep_t* q, int D, int k, const double* x) {
     return comp_logpdf(&q[k], x[k]);
 }
 static double factored_logpdf(const prep_t* q, int D, const double* x) {
+    if (user_prior_joint(q[0].kind))  /* logpdf(prior, x) of a joint prior: one function of the vector */
+        return g_user_mvprior[q[0].kind - KABC_PRIOR_USER].logpdf(x, D, q[0].p, (int)(sizeof(prep_t) / sizeof(double)),
+                                                                  kabc_log_tab);
     double s = comp_logpdf_k(q, D, 0, x);
     for (int k = 1; k < D; ++k) s += comp_logpdf_k(q, D, k, x);
     return s;
@@ -344,6 +383,12 @@ int32_t orc_push_p(const kabc_prior_t* prior, int32_t D, int64_t n, const double
  * (src/priors.jl:42-43, src/KissABC.jl:50) */
 static void factored_rand(const kabc_prior_t* prior, int D, uint64_t seed, uint32_t walker,
                           uint64_t attempt, uint32_t domain, double* out) {
+    if (user_prior_joint(prior[0].kind)) {  /* rand(rng, prior) of a joint prior: the whole vector at once */
+        kabc_slotwin_t w = {seed, attempt, walker, domain, 0u};
+        g_user_mvprior[prior[0].kind - KABC_PRIOR_USER].rand(out, D, prior[0].p,
+                                                               (int)(sizeof(kabc_prior_t) / sizeof(double)), &w);
+        return;
+    }
     for (int k = 0; k < D; ++k) {
         kabc_slotwin_t w = {seed, attempt, walker, domain, (uint32_t)k * KABC_SLOTS_PER_DIM};
         out[k] = user_prior_known(prior[k].kind) ? g_user_prior[prior[k].kind - KABC_PRIOR_USER].rand(prior[k].p, &w)

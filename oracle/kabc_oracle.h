@@ -70,6 +70,7 @@ double orc_cdf_g_inv(double u, double a);
 int32_t orc_register_user_cost(int32_t id, void* fn);
 /* a user prior family (kind >= KABC_PRIOR_USER): logpdf(x, p, tab), rand(p, window) of its snippet */
 int32_t orc_register_user_prior(int32_t kind, void* logpdf, void* rnd, int32_t discrete);
+int32_t orc_register_user_mvprior(int32_t kind, void* logpdf, void* rnd); /* a JOINT prior: kabc_compile_mvprior_plugin */
 int32_t orc_register_user_init(int32_t id, void* fn);
 /* MvNormal(mu, Sigma) priors (include/kabc_mvnormal.h): the oracle's registry; the components it is
  * handed are resolved by the caller: p[1] = k, p[2] = bits of orc_mvnormal_block(handle), p[3] = D */

@@ -64,6 +64,7 @@ def load():
             "orc_register_user_cost": (C.c_int32, [C.c_int32, C.c_void_p]),
             "orc_register_user_init": (C.c_int32, [C.c_int32, C.c_void_p]),
             "orc_register_user_prior": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]),
+            "orc_register_user_mvprior": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p]),
             "orc_mvnormal_register": (C.c_int32, [dp, dp, C.c_int32, C.POINTER(C.c_int32)]),
             "orc_mvnormal_block": (C.c_uint64, [C.c_int32]),
             "orc_ais_create": (C.c_int32, [C.POINTER(cd.Model), C.c_int64, C.c_uint64,
@@ -137,10 +138,41 @@ def register_user_prior(dist):
     _user_prior_done.add(dist.kind)
 
 
+def register_user_mvprior(fac):
+    """the snippet of a kissabc_jl_amd.distributions.UserMvPrior (a JOINT prior), compiled with gcc and
+    registered with the oracle under the same kind"""
+    import hashlib
+    if fac.kind in _user_prior_done:
+        return
+    text = ('#include "kabc_sampling_base.h"\n' + fac.source +
+            "\ndouble orc_user_mvprior_logpdf_entry(const double* x, int D, const double* p, int st, const double* tab) {\n"
+            "    return kabc_user_mvprior_logpdf(x, D, p, st, tab);\n}\n"
+            "void orc_user_mvprior_rand_entry(double* out, int D, const double* p, int st, const kabc_slotwin_t* w) {\n"
+            "    kabc_user_mvprior_rand(out, D, p, st, w);\n}\n")
+    tag = hashlib.sha1(text.encode()).hexdigest()[:16]
+    bdir = os.path.join(_HERE, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    so = os.path.join(bdir, f"libusermvprior_{tag}.so")
+    if not os.path.exists(so):
+        src = os.path.join(bdir, f"usermvprior_{tag}.c")
+        with open(src, "w") as f:
+            f.write(text)
+        subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fPIC", "-ffp-contract=off", "-mfma",
+                               "-I", os.path.join(os.path.dirname(_HERE), "include"), "-shared",
+                               "-o", so, src, "-lm"])
+    lib = _user_libs.get(so) or C.CDLL(so)
+    _user_libs[so] = lib
+    _check(load().orc_register_user_mvprior(fac.kind, C.cast(lib.orc_user_mvprior_logpdf_entry, C.c_void_p),
+                                            C.cast(lib.orc_user_mvprior_rand_entry, C.c_void_p)))
+    _user_prior_done.add(fac.kind)
+
+
 def _prior_c(fac):
     """kabc_prior_t[D] for the ORACLE: a full-covariance MvNormal is registered with the oracle's
     own registry and handed over resolved (p[1] = k, p[2] = the block's address as a double's
     bits, p[3] = D; include/kabc_mvnormal.h) -- the library resolves its own handles itself."""
+    if hasattr(fac, "source") and getattr(fac, "kind", 0) >= cd.PRIOR_USER:   # a joint user prior
+        register_user_mvprior(fac)
     for c in fac.p:   # user families: the oracle gets the same snippet, compiled for the host
         if hasattr(c, "source") and c.kind >= cd.PRIOR_USER:
             register_user_prior(c)

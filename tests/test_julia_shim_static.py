@@ -99,7 +99,7 @@ JL_SCALARS = {
     "Float64": ("f", 8), "Cdouble": ("f", 8), "Cint": ("i", 4), "Csize_t": ("u", 8), "Cuint": ("u", 4),
 }
 JL_PTR_TARGET = {"Float64": "double", "Int32": "int32_t", "Int64": "int64_t", "UInt64": "uint64_t",
-                 "UInt8": "uint8_t", "UInt32": "uint32_t", "Cvoid": None, "Ptr{Cvoid}": None}
+                 "UInt8": "uint8_t", "UInt32": "uint32_t", "Cchar": "char", "Cvoid": None, "Ptr{Cvoid}": None}
 JL_PTR_TARGET.update({v: k for k, v in JL_OF_STRUCT.items()})
 
 
