@@ -788,6 +788,50 @@ __global__ void __launch_bounds__(kSelBlock) smc_select_kernel(const SmcSelectAr
 }
 #endif  // KABC_SMC_SINGLE_UNIT
 
+// ---- rows gathered by lane groups (round 6; A/B: KABC_SMC_COOP_GATHER) -----------------------------------
+// A lane that fetches "its" random row with D/2 16-byte loads makes every load instruction of its wavefront
+// touch 64 different cache lines for 16 bytes each.  Here the D/2 lanes of a group fetch ONE row with one
+// instruction (a whole 8D-byte row per line request: the guide's gather recipe, MI355X_MICROARCH.md
+// "Indexed rows"), 64 / (D/2) rows per instruction, and the rows reach their owners through a wave-private
+// LDS tile (row stride 8D + 16 bytes).  idx: this lane's row; out: this lane's row.  All 64 lanes take part.
+template <int D>
+struct CoopGather {
+    static constexpr int LPR = D / 2;           // lanes per row (16 bytes each)
+    static constexpr int RPI = kWave / LPR;     // rows per load instruction
+    static constexpr int NI = kWave / RPI;      // load instructions per 64 rows (= LPR)
+    static constexpr int STRIDE = D + 2;        // doubles per tile row
+    static constexpr bool ok = (D % 2 == 0) && D >= 4 && (kWave % LPR == 0);
+    double2 v[NI];                              // chunk (lane % LPR) of row (j * RPI + lane / LPR)
+    __device__ __forceinline__ void issue(const double* __restrict__ src, int64_t idx, int lane) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int owner = j * RPI + lane / LPR;
+            const unsigned lo = (unsigned)__shfl((int)(unsigned)idx, owner, kWave);
+            const unsigned hi = (unsigned)__shfl((int)(unsigned)((uint64_t)idx >> 32), owner, kWave);
+            const int64_t r = (int64_t)(((uint64_t)hi << 32) | lo);
+            v[j] = *reinterpret_cast<const double2*>(src + r * D + 2 * (lane % LPR));
+        }
+    }
+    // through the wave's tile; the tile may be reused as soon as this returns (one wavefront: LDS in order)
+    __device__ __forceinline__ void deliver(double* tile, int lane, double* out) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+            *reinterpret_cast<double2*>(tile + (j * RPI + lane / LPR) * STRIDE + 2 * (lane % LPR)) = v[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int k = 0; k < D / 2; ++k) {
+            const double2 w = *reinterpret_cast<const double2*>(tile + lane * STRIDE + 2 * k);
+            out[2 * k] = w.x;
+            out[2 * k + 1] = w.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+
 template <int D, int COST, bool SIMPLE>
 __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A) {
     const int64_t wg = A.wg0 + (int64_t)blockIdx.x;
@@ -812,26 +856,39 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
     const double* __restrict__ lpi_src = A.lpi[cur];
     double Xfin = 0.0;
     bool alive_i = false;
-    if (i < A.N) {
+#ifdef KABC_SMC_COOP_GATHER
+    constexpr bool kCoop = CoopGather<D>::ok;
+#else
+    constexpr bool kCoop = false;
+#endif
+    // (the cooperative gather: every lane of a wavefront fetches rows for its neighbours, so a wavefront with
+    // any particle in range runs the whole body; lanes out of range work on row 0 and store nothing)
+    __shared__ __attribute__((aligned(16))) double s_tile[kCoop ? kSmcBlock / kWave : 1][kCoop ? kWave * (D + 2) : 1];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x >> 6;
+    const bool in = i < A.N;
+    if (kCoop ? (i - lane < A.N) : in) {
         // idx = repeat(idxalive, ceil(N/m))[1:N]  (src/smc.jl:146-147), evaluated on the fly
         const bool remap = gather && A.ctrl->resampled != 0;
         const unsigned ess = (unsigned)A.ctrl->ess;
-        const int64_t si = remap ? (int64_t)A.cidx[(unsigned)i % ess] : i;
+        const int64_t ii = in ? i : 0;
+        const int64_t si = remap ? (int64_t)A.cidx[(unsigned)ii % ess] : ii;
         double th[D];
-        load_row<D>(theta_src + si * D, th);
+        CoopGather<kCoop ? D : 4> gth, gta, gtb;
+        if constexpr (kCoop) gth.issue(theta_src, si, lane);
+        else load_row<D>(theta_src + si * D, th);
         double Xi = X_src[si];
         double lpi = lpi_src[si];
-        alive_i = A.alive[i] != 0;
-        if (alive_i) {
+        alive_i = in && A.alive[ii] != 0;
+        if (kCoop || alive_i) {
             const uint64_t N = (uint64_t)A.N;
-            const uint32_t w = (uint32_t)i;
+            const uint32_t w = (uint32_t)ii;
             const kabc_u128_t B0 = kabc_stream_block(A.seed, w, pass, 0u, KABC_DOM_SMC_MOVE);
             const kabc_u128_t B1 = kabc_stream_block(A.seed, w, pass, 1u, KABC_DOM_SMC_MOVE);
             const kabc_u128_t B2 = kabc_stream_block(A.seed, w, pass, 2u, KABC_DOM_SMC_MOVE);
             // while a==i ... ; while b==i || b==a ...  (src/smc.jl:163-164)
             int64_t a = (int64_t)kabc_index32(kabc_lo64(B0), (uint32_t)N - 1u);
-            a += (a >= i);
-            const int64_t lo = a < i ? a : i, hi = a < i ? i : a;
+            a += (a >= ii);
+            const int64_t lo = a < ii ? a : ii, hi = a < ii ? ii : a;
             int64_t b = (int64_t)kabc_index32(kabc_hi64(B0), (uint32_t)N - 2u);
             b += (b >= lo);
             b += (b >= hi);
@@ -841,8 +898,17 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
             const int64_t sa = remap ? (int64_t)A.cidx[(unsigned)a % ess] : a;
             const int64_t sb = remap ? (int64_t)A.cidx[(unsigned)b % ess] : b;
             double ta[D], tb[D], prop[D], xp[D];
-            load_row<D>(theta_src + sa * D, ta);
-            load_row<D>(theta_src + sb * D, tb);
+            if constexpr (kCoop) {
+                gta.issue(theta_src, sa, lane);
+                gtb.issue(theta_src, sb, lane);
+                gth.deliver(s_tile[wv], lane, th);
+                gta.deliver(s_tile[wv], lane, ta);
+                gtb.deliver(s_tile[wv], lane, tb);
+            } else {
+                load_row<D>(theta_src + sa * D, ta);
+                load_row<D>(theta_src + sb * D, tb);
+            }
+          if (alive_i) {
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 const double W = (tb[k] - ta[k]) * s;
@@ -875,11 +941,14 @@ __global__ void __launch_bounds__(kSmcBlock) smc_mcmc_kernel(const SmcMcmcArgs A
                     }
                 }
             }
+          }  // (alive_i)
         }
-        store_row<D>(A.theta[1 - cur] + i * D, th);
-        A.X[1 - cur][i] = Xi;
-        A.lpi[1 - cur][i] = lpi;
-        Xfin = Xi;
+        if (in) {
+            store_row<D>(A.theta[1 - cur] + i * D, th);
+            A.X[1 - cur][i] = Xi;
+            A.lpi[1 - cur][i] = lpi;
+            Xfin = Xi;
+        }
     }
     smc_block_stats(A.part, alive_i, Xfin, wg);
     // one counter line per workgroup (mod kSmcSlots): same-line atomics from 512
