@@ -298,6 +298,57 @@ def _pmc_table():
         return None, {}
 
 
+def latency_floor_inputs():
+    """The two inputs of smc_c4.latency_floor, measured in THIS run by child processes (before this process touches
+    the GPU): (i) the XCD-aware device-wide barrier at 128 workgroups -- tools/xcd_barrier_probe.hip (rows written,
+    barrier, random rows of other workgroups read and checked), built on first use; (ii) the propose / accept pass's
+    dependent chain from the loop kernel's phase stamps -- the PROBES build of the library (make PROBES=1), when it
+    is there.  Anything that cannot be measured here falls back to the newest committed profiles/ file and says so."""
+    import re
+    import subprocess
+    out = {}
+    try:
+        exe = os.path.join(ROOT, "tools", "_bin", "xcdbar")
+        if not os.path.exists(exe):
+            os.makedirs(os.path.dirname(exe), exist_ok=True)
+            subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "--offload-arch=gfx950",
+                            os.path.join(ROOT, "tools", "xcd_barrier_probe.hip"), "-o", exe],
+                           check=True, capture_output=True, timeout=300)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        line = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")][-1]
+        j = json.loads(line)
+        # (the kernel's barrier: release once per XCD, buffer_inv sc1 per workgroup = the probe's "xcd_release_only")
+        if j.get("xcd_release_only_errors_128", 1) == 0:
+            out["barrier_128_us"] = float(j["xcd_release_only_128"])
+            out["barrier_source"] = "measured in this run (tools/xcd_barrier_probe.hip, xcd_release_only_128)"
+    except Exception as e:
+        out["barrier_error"] = repr(e)[:200]
+    if "barrier_128_us" not in out:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_xcd_barrier.json")))[-1:]:
+            out["barrier_128_us"] = float(json.load(open(f))["xcd_release_only_128"])
+            out["barrier_source"] = os.path.basename(f) + " (xcd_release_only_128)"
+    try:
+        probes = os.path.join(ROOT, "kissabc.jl_amd", "lib", "libkabc_hip_probes.so")
+        if os.path.exists(probes):
+            env = dict(os.environ, KABC_PROBES="1", KABC_SMC_STAMPS="1", KABC_SPECIALIZE="0")
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "smc_c4_probe.py")], env=env,
+                               capture_output=True, text=True, timeout=300)
+            m = None
+            for ln in r.stderr.splitlines():
+                mm = re.search(r"mcmc split: philox\+select (\d+) issue\+pre (\d+) wait (\d+) logpdf (\d+) cost\+accept (\d+) tail (\d+)", ln)
+                if mm:
+                    m = mm
+            if m:
+                out["pass_chain_us"] = sum(int(v) for v in m.groups()) / 100.0   # 10 ns ticks
+                out["pass_chain_source"] = "measured in this run (phase stamps of libkabc_hip_probes.so, tools/smc_c4_probe.py)"
+    except Exception as e:
+        out["pass_chain_error"] = repr(e)[:200]
+    if "pass_chain_us" not in out:
+        out["pass_chain_us"] = 7.2
+        out["pass_chain_source"] = "profiles/r04_smc_c4.txt (phase stamps; no PROBES build of the library in this tree)"
+    return out
+
+
 def spawn_ranks(n, argv, stub=None, timeout=3600.0):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per
     GPU, BEFORE this process has made any GPU call (the children are fresh interpreters; nothing
@@ -513,6 +564,10 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         import kissabc_jl_amd as k0
         cpu = cpu_baseline(k0, args.cpu_seconds, with_smc=not args.no_smc)
+
+    floor_in = None
+    if world == 1 and not emulate and not args.no_smc:
+        floor_in = latency_floor_inputs()
 
     # ... and so does the cold-cache leg of the default specialisation path (its own process: the
     # code-object cache must be empty and no unit loaded)
@@ -882,12 +937,16 @@ def main():
         # fraction of this workload cannot move (a pass is 17.9 MB = 2.2 us at 8 TB/s);
         # latency_floor_frac = floor / measured is the number that can.
         it_us = w * 1e6 / max(1, r.info["iterations"])
-        floor_us = 2 * 3.816 + 7.2
+        fi = floor_in or {"barrier_128_us": 3.745, "barrier_source": "profiles/r03_xcd_barrier.json",
+                          "pass_chain_us": 7.2, "pass_chain_source": "profiles/r04_smc_c4.txt"}
+        floor_us = 2 * fi["barrier_128_us"] + fi["pass_chain_us"]
         smc["iteration_us"] = it_us
         smc["latency_floor_us"] = floor_us
         smc["latency_floor_frac"] = floor_us / it_us
-        smc["latency_floor_formula"] = ("2 x XCD-aware barrier at 128 workgroups (3.816 us, r03_xcd_barrier.json) + "
-                                        "the pass's dependent chain (7.2 us, r04_smc_c4.txt phase stamps)")
+        smc["latency_floor_inputs"] = fi
+        smc["latency_floor_formula"] = (f"2 x XCD-aware barrier at 128 workgroups ({fi['barrier_128_us']:.3f} us: "
+                                        f"{fi['barrier_source']}) + the pass's dependent chain "
+                                        f"({fi['pass_chain_us']:.2f} us: {fi['pass_chain_source']})")
         # HBM bytes of the loop kernel (one launch = the whole run) from the committed PMC passes
         for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_smc_loop.json"))):
             tj = json.load(open(tf))
