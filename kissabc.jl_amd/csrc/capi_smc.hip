@@ -951,12 +951,12 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                 if (la.stamps && hipMemcpy(st, la.stamps, 192, hipMemcpyDeviceToHost) == hipSuccess && st[8])
                     fprintf(stderr, "[kabc smc loop, 10 ns ticks per iteration] publish (records %.0f + next draws %.0f + sync,arrive %.0f) B1 %.0f fold %.0f "
                             "rounds %.0f gather %.0f B2 %.0f eps+mask %.0f mcmc %.0f | iterations %llu "
-                            "cand/iter %.1f predicted %llu barriers %.2f/iter | eps+mask split: loads+fold %.0f rank %.0f patch+scan %.0f | mcmc split: philox+select %.0f issue+pre %.0f wait %.0f logpdf %.0f cost+accept %.0f tail %.0f\n",
+                            "cand/iter %.1f predicted %llu one-barrier %llu barriers %.2f/iter | eps+mask split: loads+fold %.0f rank %.0f patch+scan %.0f | mcmc split: philox+select %.0f issue+pre %.0f wait %.0f logpdf %.0f cost+accept %.0f tail %.0f\n",
                             (double)st[21] / st[8], (double)st[22] / st[8],
                             (double)st[0] / st[8], (double)st[1] / st[8], (double)st[2] / st[8],
                             (double)st[3] / st[8], (double)st[4] / st[8], (double)st[5] / st[8],
                             (double)st[6] / st[8], (double)st[7] / st[8], st[8], (double)st[9] / st[8],
-                            st[10], (double)st[11] / st[8] / ((double)st[8] + 1) * 2.0, (double)st[12] / st[8],
+                            st[10], st[15], (double)st[11] / st[8] / ((double)st[8] + 1) * 2.0, (double)st[12] / st[8],
                             (double)st[13] / st[8], (double)st[14] / st[8], (double)st[16] / st[8], (double)st[17] / st[8],
                             (double)st[18] / st[8], (double)st[19] / st[8], (double)st[20] / st[8], (double)st[7] / st[8]);
             } else if (le != hipErrorCooperativeLaunchTooLarge) {
