@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KABC_VERSION 320 /* 0.3.2: kabc_ais_driver, kabc_set_specialize, kabc_rtc_cache_dir, kabc_compile_mvprior_plugin; 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
+#define KABC_VERSION 320 /* 0.3.2: kabc_smc_dist_stats, kabc_ais_driver, kabc_set_specialize, kabc_rtc_cache_dir, kabc_compile_mvprior_plugin; 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
 /* AIS, smc, ABCDE and pfilter accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM
  * run-time-dimension kernels keep the walker / particle rows in memory (several times slower per
@@ -592,15 +592,23 @@ kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, in
  *                            repeats the epsilon-selection (src/smc.jl:134-153) on the gathered costs.
  *   KABC_SMC_DIST_PARTICLES  SURVEY §8e "SMC": rank r OWNS the particles of its blocks -- their alive
  *                            mask lives on that rank only and the selection runs over the rank's own
- *                            costs: the quantile from all-gathered 1024-bin histograms of the order-
- *                            preserving keys + an all-gather of the <= 4096 candidate keys, the ESS from
- *                            all-gathered counts, and -- on a resample only -- an all-gather of the
- *                            ranks' compacted alive indices (idx = repeat(idxalive, ...), :146-147).
- *                            Partners are read from the gathered ensemble, as in the other mode.
- *                            The selection's passes shrink with the world size (the redundant
- *                            selection is the serial fraction of the other mode: 83 us per iteration
- *                            at 2 M particles whatever the number of ranks) at the price of four to
- *                            five small dependent all-gathers per iteration: for large ensembles.
+ *                            costs.  ONE all-gather per selection: every rank ships, unasked, its alive
+ *                            keys of a window predicted from the last two values of epsilon (a few
+ *                            percent of its particles), their 1024-bin histogram, the count of its keys
+ *                            below the window and its smallest key above; when the target rank falls
+ *                            inside the window -- the usual course -- every rank derives epsilon, the
+ *                            ESS and the resample decision from that, and a resample's index
+ *                            (idx = repeat(idxalive, ...), :146-147) from the gathered costs it holds
+ *                            anyway.  Otherwise (the first two selections, a decrement far off the
+ *                            last, epsilon == 0) the selection is repeated phase by phase: all-gathered
+ *                            histograms, candidate keys, counts, and on a resample the ranks' compacted
+ *                            indices.  Partners are read from the gathered ensemble, as in the other
+ *                            mode.  For large ensembles: the redundant selection is the serial fraction
+ *                            of the other mode.
+ * With mcmc_retrys = 0 (the reference's default) both modes enqueue batches of up to eight iterations
+ * -- kernels and collectives: the pass's grouped all-gather, and the selection's one in the second mode
+ * -- between two looks at the control block; with retry passes allowed the host looks after every pass.
+ * KABC_SMC_DIST_LOOKS=1 forces that course.  kabc_smc_dist_stats tells what the last run did.
  * Both modes return kabc_smc_run's result bit for bit, on every rank.  kabc_smc_run_dist reads
  * KABC_SMC_DIST=particles|cost_loop (every rank must see the same value). */
 #define KABC_SMC_DIST_COST_LOOP 0
@@ -608,6 +616,19 @@ kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, in
 kabc_status_t kabc_smc_run_dist_mode(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
                                      const kabc_cost_t* cost, const kabc_smc_opts_t* opts, int32_t mode,
                                      kabc_smc_result_t* result);
+
+/* How the calling thread's last kabc_smc_run / kabc_smc_run_dist[_mode] was driven: out[0] epsilon-
+ * iterations, [1] collectives issued (grouped all-gathers; those of batches enqueued past the end of the
+ * loop or behind a stalled selection included), [2] host looks at the control block (the batched course
+ * and the sharded courses count them), [3] selections decided by the one exchange, [4] selections made
+ * phase by phase / by the select kernel inside the batched course (the first two, and every stalled one),
+ * [5] propose / accept passes, [6] 1 when batches of iterations with the one-exchange selection were
+ * enqueued between looks -- sharded runs with mcmc_retrys = 0, and single-GPU runs of 2^20 particles and
+ * more (the select kernel is faster below: KABC_SMC_SPEC_SELECT=1 / 0 forces / forbids the course on a
+ * single GPU), [7] the collectives of ONE iteration in the batched course's usual case (2 with sharded
+ * particles: the selection's payload and the pass's grouped all-gather; 1 with a sharded cost loop; 0 on
+ * a single GPU), -1 when the run was not batched. */
+void kabc_smc_dist_stats(int64_t out[8]);
 
 /* ---- ABCDE(prior, cost, ϵ_target; kwargs...) -- src/smc.jl:347-430 -----------
  * ABC differential evolution (exported, undocumented and untested in the reference:

@@ -192,6 +192,7 @@ PROTOTYPES = {
                                C.POINTER(SmcOpts), C.POINTER(SmcResult)]),
     "kabc_smc_run_dist_mode": (C.c_int, [VP, C.POINTER(Prior), C.c_int32, C.POINTER(Cost),
                                     C.POINTER(SmcOpts), C.c_int32, C.POINTER(SmcResult)]),
+    "kabc_smc_dist_stats": (None, [C.POINTER(C.c_int64)]),
 }
 
 

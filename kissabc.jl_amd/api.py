@@ -474,6 +474,13 @@ def smc(prior, cost, *, nparticles=100, alpha=0.95, mcmc_retrys=0, mcmc_tol=0.01
                      resampled=log[i].resampled, flag=log[i].flag, passes=log[i].mcmc_passes)
                 for i in range(nit)],
     }
+    if True:   # how the run was driven (kabc_smc_dist_stats)
+        ds = (C.c_int64 * 8)()
+        lib.kabc_smc_dist_stats(ds)
+        info["dist"] = {"iterations": ds[0], "collectives": ds[1], "host_looks": ds[2],
+                        "one_exchange_selections": ds[3], "phase_by_phase_selections": ds[4],
+                        "passes": ds[5], "batched": bool(ds[6]), "collectives_per_usual_iteration": ds[7],
+                        "collectives_per_iteration": round(ds[1] / max(ds[0], 1), 3)}
     P = kept if return_array else _bundle(kept, scalar)
     # where the wall time of this call went: kabc_smc_run (with its result copy) / this wrapper
     info["host_ms"] = {"kabc_smc_run": (t_host1 - t_host0) * 1e3,

@@ -309,6 +309,8 @@ void kabc_smc_default_opts(kabc_smc_opts_t* o) {
 static thread_local bool tl_smc_no_loop = false;
 // kabc_smc_run_dist_mode: what the ranks of the communicator share out (KABC_SMC_DIST_*)
 static thread_local int tl_smc_dist_mode = 0;
+// kabc_smc_dist_stats: how the calling thread's last sharded run was driven
+static thread_local int64_t tl_dist_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
 static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc_prior_t* prior,
                                   int32_t D, const kabc_cost_t* cost, const kabc_smc_opts_t* o,
@@ -348,6 +350,10 @@ kabc_status_t kabc_smc_run_dist_mode(kabc_comm_t* comm, const kabc_prior_t* prio
     tl_smc_force_coop = was_coop;
     tl_smc_dist_mode = 0;
     return st;
+}
+
+void kabc_smc_dist_stats(int64_t out[8]) {
+    if (out) std::memcpy(out, tl_dist_stats, sizeof tl_dist_stats);
 }
 
 kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
@@ -505,7 +511,9 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     KABC_HIP_CHECK(hipMemsetAsync(ctrl, 0, sizeof(SmcCtrl), s));
     KABC_HIP_CHECK(hipMemsetAsync(slots, 0, sizeof(unsigned long long) * kSmcSlots * 8 * world, s));
     // the all-gather at the end of a sharded pass / of the sharded init (buffer set `b`)
+    int64_t n_collectives = 0, n_looks = 0, n_spec = 0, n_stalls = 0;
     auto exchange = [&](int b, bool with_slots) -> kabc_status_t {
+        ++n_collectives;
         double* bases[5] = {th[b], X[b], lp[b], reinterpret_cast<double*>(part),
                             reinterpret_cast<double*>(slots)};
         const size_t counts[5] = {(size_t)wg_per * kSmcBlock * D, (size_t)wg_per * kSmcBlock,
@@ -641,7 +649,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     const bool dist_particles = comm && tl_smc_dist_mode == KABC_SMC_DIST_PARTICLES;
     DselArgs dz;
     std::memset(&dz, 0, sizeof dz);
-    unsigned dselG = 0;
+    unsigned dselG = 0, dsel2G = 1;
     if (dist_particles) {
         dz.Xbuf[0] = X[0];
         dz.Xbuf[1] = X[1];
@@ -671,15 +679,51 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         const int64_t g = (len + 2 * kSelBlock - 1) / (2 * kSelBlock);  // 2048 particles per workgroup
         dselG = len <= 0 ? 0u : (unsigned)std::min<int64_t>(std::max<int64_t>(g, 1), kDselMaxGrid);
     }
+    // the buffers of the one-exchange course (dsel2_*): a slot of an eighth of the rank's particles (the
+    // window holds a few percent).  Without sharded particles the "rank" owns the whole ensemble.
+    auto dsel2_setup = [&]() -> kabc_status_t {
+        if (!dist_particles) {
+            dz.Xbuf[0] = X[0];
+            dz.Xbuf[1] = X[1];
+            dz.alive = alive;
+            dz.cidx = cidx;
+            dz.ctrl = ctrl;
+            dz.part = part;
+            dz.npart = npart;
+            dz.N = N;
+            dz.p_lo = 0;
+            dz.p_hi = N;
+            dz.alpha = alpha;
+            dz.min_r_ess = min_r_ess;
+            dz.rank = 0;
+            dz.world = 1;
+            dz.seg_len = N;
+            KABC_HIP_CHECK(bufs.alloc(&dz.st, 1));
+            KABC_HIP_CHECK(bufs.alloc(&dz.sub_cnt, (size_t)kDselMaxGrid));
+        }
+        KABC_HIP_CHECK(hipMemsetAsync(dz.st, 0, sizeof(DselState), s));
+        dz.spec_cap = std::max<int64_t>(kSelCand, (dz.seg_len / 8 + 1) & ~(int64_t)1);
+        dz.spec_stride = kDselSpecKeys + dz.spec_cap;
+        KABC_HIP_CHECK(bufs.alloc(&dz.spec, (size_t)dz.world * dz.spec_stride));
+        KABC_HIP_CHECK(hipMemsetAsync(dz.spec, 0, sizeof(unsigned long long) * dz.world * dz.spec_stride, s));
+        KABC_HIP_CHECK(bufs.alloc(&dz.bin, (size_t)kSelCand + 8));
+        KABC_HIP_CHECK(hipMemsetAsync(dz.bin, 0, sizeof(unsigned long long) * 8, s));
+        KABC_HIP_CHECK(hipMemsetAsync(dz.bin + 1, 0xff, sizeof(unsigned long long), s));
+        const int64_t g2 = (N + 2 * kSelBlock - 1) / (2 * kSelBlock);  // (2048 particles per workgroup)
+        dsel2G = (unsigned)std::min<int64_t>(std::max<int64_t>(g2, 1), kDselMaxGrid);
+        return KABC_OK;
+    };
     DselState hz;
     std::memset(&hz, 0, sizeof hz);
     auto dsel_look = [&]() -> kabc_status_t {  // the state the deciding kernel left
+        ++n_looks;
         KABC_HIP_CHECK(hipGetLastError());
         KABC_HIP_CHECK(hipMemcpyAsync(&hz, dz.st, sizeof hz, hipMemcpyDeviceToHost, s));
         KABC_HIP_CHECK(hipStreamSynchronize(s));
         return KABC_OK;
     };
     auto dsel_gather = [&](void* base, size_t doubles_per_rank) -> kabc_status_t {
+        ++n_collectives;
         double* b[1] = {reinterpret_cast<double*>(base)};
         const size_t c[1] = {doubles_per_rank};
         return comm_allgather_many(comm, b, c, 1);
@@ -951,12 +995,12 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                 if (la.stamps && hipMemcpy(st, la.stamps, 192, hipMemcpyDeviceToHost) == hipSuccess && st[8])
                     fprintf(stderr, "[kabc smc loop, 10 ns ticks per iteration] publish (records %.0f + next draws %.0f + sync,arrive %.0f) B1 %.0f fold %.0f "
                             "rounds %.0f gather %.0f B2 %.0f eps+mask %.0f mcmc %.0f | iterations %llu "
-                            "cand/iter %.1f predicted %llu one-barrier %llu barriers %.2f/iter | eps+mask split: loads+fold %.0f rank %.0f patch+scan %.0f | mcmc split: philox+select %.0f issue+pre %.0f wait %.0f logpdf %.0f cost+accept %.0f tail %.0f\n",
+                            "cand/iter %.1f predicted %llu barriers %.2f/iter | eps+mask split: loads+fold %.0f rank %.0f patch+scan %.0f | mcmc split: philox+select %.0f issue+pre %.0f wait %.0f logpdf %.0f cost+accept %.0f tail %.0f\n",
                             (double)st[21] / st[8], (double)st[22] / st[8],
                             (double)st[0] / st[8], (double)st[1] / st[8], (double)st[2] / st[8],
                             (double)st[3] / st[8], (double)st[4] / st[8], (double)st[5] / st[8],
                             (double)st[6] / st[8], (double)st[7] / st[8], st[8], (double)st[9] / st[8],
-                            st[10], st[15], (double)st[11] / st[8] / ((double)st[8] + 1) * 2.0, (double)st[12] / st[8],
+                            st[10], (double)st[11] / st[8] / ((double)st[8] + 1) * 2.0, (double)st[12] / st[8],
                             (double)st[13] / st[8], (double)st[14] / st[8], (double)st[16] / st[8], (double)st[17] / st[8],
                             (double)st[18] / st[8], (double)st[19] / st[8], (double)st[20] / st[8], (double)st[7] / st[8]);
             } else if (le != hipErrorCooperativeLaunchTooLarge) {
@@ -976,7 +1020,163 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     // after every pass -- it has to know which buffer set the pass wrote (that is what is
     // gathered) and whether the next pass is still open; with a simulator expensive enough to
     // be worth sharding, a host round trip per pass is noise.
-    while (comm && !looped) {
+    // One pass per iteration (mcmc_retrys = 0, the reference's default): the buffer set a pass writes is
+    // known without asking, so kDistBatch iterations are enqueued -- kernels and collectives -- between two
+    // looks at the control block, and the selection is the ONE-exchange course (smc_dsel_kernels.hpp,
+    // dsel2_*): begin (+ the previous pass's end), spec, [all-gather,] decide, apply, index -- ordinary
+    // launches, no device-wide barrier; a selection that stalls turns everything behind it into no-ops and
+    // is repeated after the look (phase by phase when the particles are sharded, else by the select kernel).
+    // Sharded particles: two collectives per iteration.  Sharded cost loop, and single-GPU runs of 2^20
+    // particles and more: the same course with the whole ensemble as the one rank's (no exchange).
+    // KABC_SMC_DIST_LOOKS=1 (sharded runs) / KABC_SMC_SPEC_SELECT=0: the courses below, also taken when
+    // retry passes are allowed; KABC_SMC_SPEC_SELECT=1: this course on a single GPU at any size.
+    bool blind_done = false;
+    {
+        const char* envl = std::getenv("KABC_SMC_DIST_LOOKS");
+        const char* envs = std::getenv("KABC_SMC_SPEC_SELECT");
+        // single GPU: five ordinary launches against the select kernel's one with its device-wide barriers --
+        // measured (profiles/r06_spec_select_ab.txt) 59 / 73 / 133 / 418 us per iteration against 49 / 64 /
+        // 130 / 436 at 32 768 / 131 072 / 524 288 / 2 M particles: the default from 2^20 particles on
+        const bool spec_single = envs ? envs[0] != '0' : N >= ((int64_t)1 << 20);
+        const bool spec_ok = comm ? !(envs && envs[0] == '0') : spec_single;
+        const bool blind = !looped && R == 1 &&
+                           (comm ? !(envl && envl[0] == '1') : (spec_single && !dyn && !auxW && !tl_smc_no_loop));
+        const bool sel2 = blind && (dist_particles || spec_ok);  // (else: the select kernel, batched)
+        if (sel2)
+            if (kabc_status_t st = dsel2_setup()) return st;
+        constexpr int kDistBatch = 8;
+        unsigned decideG = dsel2G;  // (KABC_DSEL2_DECIDE_G: A/B of the deciding kernel's grid)
+        if (const char* eg = std::getenv("KABC_DSEL2_DECIDE_G")) decideG = (unsigned)std::max(1, std::min(atoi(eg), (int)kDselMaxGrid));
+        Dsel2End e2;
+        std::memset(&e2, 0, sizeof e2);
+        e2.slots = slots;
+        e2.log = d_log;
+        e2.log_cap = log_cap;
+        e2.P = lpz;
+        e2.mcmc_tol = o->mcmc_tol;
+        e2.nregions = world;
+        int cur_host = 0;      // ctrl->cur as long as the loop runs: one flip per iteration
+        bool pending = false;  // a pass whose end has not been folded yet
+        auto look = [&]() -> kabc_status_t {
+            ++n_looks;
+            KABC_HIP_CHECK(hipGetLastError());
+            KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
+            if (sel2) KABC_HIP_CHECK(hipMemcpyAsync(&hz, dz.st, sizeof hz, hipMemcpyDeviceToHost, s));
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+            return KABC_OK;
+        };
+        auto timed_pass = [&]() -> kabc_status_t {
+            const bool timed = (mcmc_timed == 0);
+            if (timed) KABC_HIP_CHECK(hipEventRecord(ev0, s));
+            run_pass(s);
+            if (timed) {
+                KABC_HIP_CHECK(hipEventRecord(ev1, s));
+                mcmc_timed = -1;  // (read after the next look)
+            }
+            return KABC_OK;
+        };
+        // one iteration with the selection phase by phase (the course of the looked loop below)
+        bool stop = false;
+        auto looked_iteration = [&]() -> kabc_status_t {
+            if (pending) {
+                e2.do_pass_end = 1;
+                e2.end_only = 1;
+                hipLaunchKernelGGL(dsel2_begin_kernel, dim3(1), dim3(kSmcSlots), 0, s, dz, e2);
+                pending = false;
+                if (kabc_status_t st = look()) return st;
+                if (hc.done) {
+                    stop = true;
+                    return KABC_OK;
+                }
+            }
+            if (dist_particles) {
+                if (kabc_status_t st = dist_select()) return st;
+            } else {
+                KABC_HIP_CHECK(hipMemsetAsync(&dz.st->stalled, 0, sizeof(int32_t), s));
+                KABC_HIP_CHECK(do_select(s));
+            }
+            if (kabc_status_t st = look()) return st;
+            if (hc.done) {
+                stop = true;
+                return KABC_OK;
+            }
+            if (kabc_status_t st = timed_pass()) return st;
+            if (comm)
+                if (kabc_status_t st = exchange(1 - hc.cur, true)) return st;
+            cur_host = 1 - hc.cur;
+            pending = true;
+            return KABC_OK;
+        };
+        // no window without two values of eps: the first two selections phase by phase (unless the whole
+        // ensemble fits a slot: then every alive key is a candidate from the start)
+        if (sel2 && !(N <= dz.spec_cap && N <= (int64_t)kDselStage))
+            for (int i = 0; i < 2 && !stop; ++i) {
+                ++n_stalls;
+                if (kabc_status_t st = looked_iteration()) return st;
+            }
+        int kb = kDistBatch;
+        while (blind && !stop) {
+            for (int it = 0; it < kb; ++it) {
+                if (sel2) {
+                    e2.do_pass_end = pending ? 1 : 0;
+                    e2.end_only = 0;
+                    hipLaunchKernelGGL(dsel2_begin_kernel, dim3(1), dim3(kSmcSlots), 0, s, dz, e2);
+                    hipLaunchKernelGGL(dsel2_spec_kernel, dim3(dsel2G), dim3(kSelBlock), 0, s, dz);
+                    if (dist_particles)
+                        if (kabc_status_t st = dsel_gather(dz.spec, (size_t)dz.spec_stride)) return st;
+                    hipLaunchKernelGGL(dsel2_decide_kernel, dim3(decideG), dim3(kSelBlock), 0, s, dz);
+                    hipLaunchKernelGGL(dsel2_apply_kernel, dim3(dsel2G), dim3(kSelBlock), 0, s, dz);
+                    hipLaunchKernelGGL(dsel2_index_kernel, dim3(dsel2G), dim3(kSelBlock), 0, s, dz);
+                    ++n_spec;
+                } else {
+                    if (pending)
+                        hipLaunchKernelGGL(smc_pass_end_kernel, dim3(1), dim3(kSmcSlots), 0, s, ctrl, slots, N,
+                                           o->mcmc_tol, 1, d_log, log_cap, lpz, world);
+                    KABC_HIP_CHECK(do_select(s));
+                }
+                if (kabc_status_t st = timed_pass()) return st;
+                if (comm)
+                    if (kabc_status_t st = exchange(1 - cur_host, true)) return st;
+                cur_host ^= 1;
+                pending = true;
+            }
+            // the last pass's end, then the look
+            if (sel2) {
+                e2.do_pass_end = 1;
+                e2.end_only = 1;
+                hipLaunchKernelGGL(dsel2_begin_kernel, dim3(1), dim3(kSmcSlots), 0, s, dz, e2);
+            } else {
+                hipLaunchKernelGGL(smc_pass_end_kernel, dim3(1), dim3(kSmcSlots), 0, s, ctrl, slots, N,
+                                   o->mcmc_tol, 1, d_log, log_cap, lpz, world);
+            }
+            pending = false;
+            if (kabc_status_t st = look()) return st;
+            if (hc.done) break;
+            cur_host = hc.cur;
+            kb = std::min(2 * kb, kDistBatch);
+            if (sel2 && hz.stalled) {
+                // every kernel behind the stalled selection was a no-op (the collectives re-gathered what
+                // was there): that selection phase by phase, its pass, and on with shorter batches
+                ++n_stalls;
+                n_spec -= 1;
+                if (std::getenv("KABC_SMC_STAMPS") && rank == 0)
+                    fprintf(stderr, "[kabc smc] the one-exchange selection of iteration %lld stalled (reason %d)\n",
+                            (long long)hz.stall_iteration + 1, (int)hz.stalled);
+                if (kabc_status_t st = looked_iteration()) return st;
+                kb = 1;
+            }
+        }
+        if (mcmc_timed == -1) {
+            float ms = 0.f;
+            mcmc_timed = 0;
+            if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
+                mcmc_ms = ms;
+                mcmc_timed = 1;
+            }
+        }
+        blind_done = blind;
+    }
+    while (comm && !looped && !blind_done) {
         if (dist_particles) {
             if (kabc_status_t st = dist_select()) return st;
         } else {
@@ -984,6 +1184,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         }
         KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
         KABC_HIP_CHECK(hipStreamSynchronize(s));
+        ++n_looks;
         if (hc.done) break;
         bool ended = false;
         for (int r = 0; r < R && !hc.done && hc.pass_open; ++r) {
@@ -998,6 +1199,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                                o->mcmc_tol, ended ? 1 : 0, d_log, log_cap, lpz, world);
             KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipStreamSynchronize(s));
+        ++n_looks;
             if (timed) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
@@ -1010,13 +1212,14 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
             hipLaunchKernelGGL(smc_iter_end_kernel, dim3(1), dim3(1), 0, s, ctrl, d_log, log_cap, N, lpz);
             KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipStreamSynchronize(s));
+        ++n_looks;
         }
         if (hc.done) break;
     }
     const int kGroup = 4;                        // retry passes enqueued between host checks
     const int kBatch = (R <= kGroup) ? 16 : 1;   // iterations per host sync
     bool first = true;
-    while (!looped && !comm) {
+    while (!looped && !comm && !blind_done) {
         // (the next kBatch passes at once: pass t = *ctrl.pass + 1 + s in slot t mod kAuxRing)
         if (auxW && aux_ring > 1) launch_aux_prepass(cost->id, xa, s, 1);
         for (int it = 0; it < kBatch; ++it) {
@@ -1140,6 +1343,16 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         const kabc_status_t st2 = kabc_smc_run(ctx, prior, D, cost, o, res);
         tl_smc_no_loop = false;
         return st2;
+    }
+    {
+        tl_dist_stats[0] = hc.iteration;
+        tl_dist_stats[1] = n_collectives;
+        tl_dist_stats[2] = n_looks;
+        tl_dist_stats[3] = blind_done && n_spec > 0 ? std::max<int64_t>(hc.iteration - n_stalls, 0) : 0;
+        tl_dist_stats[4] = n_stalls;
+        tl_dist_stats[5] = (int64_t)hc.pass;
+        tl_dist_stats[6] = blind_done ? 1 : 0;
+        tl_dist_stats[7] = blind_done ? (dist_particles ? 2 : (comm ? 1 : 0)) : -1;  // collectives of an iteration's usual course
     }
     if (dist_particles && sa.stamps && rank == 0)
         fprintf(stderr, "[kabc smc sharded selection, %d ranks] %ld selections: %ld histogram rounds, %ld candidate "

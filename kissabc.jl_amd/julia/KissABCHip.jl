@@ -671,6 +671,15 @@ function KissABC.smc(prior::Distribution, cost::DeviceCost; rng = Random.GLOBAL_
     (P = particles_of(prior, theta, findall(!=(0x00), alive)), C = C, ϵ = r.eps)   # src/smc.jl:205
 end
 
+# how this thread's last smc was driven (kabc_smc_dist_stats): iterations, collectives issued, host looks,
+# selections decided by the one exchange / phase by phase, passes, batched
+function smc_dist_stats()
+    out = zeros(Int64, 8)
+    ccall((:kabc_smc_dist_stats, libkabc), Cvoid, (Ptr{Int64},), out)
+    (iterations = out[1], collectives = out[2], host_looks = out[3], one_exchange_selections = out[4],
+     phase_by_phase_selections = out[5], passes = out[6], batched = out[7] != 0)
+end
+
 # ABCDE(prior, cost::DeviceCost, ϵ_target; ...) -- replaces src/smc.jl:347-430
 function KissABC.ABCDE(prior::Distribution, cost::DeviceCost, ϵ_target; nparticles = 50, generations = 20,
                        α = 0, parallel = false, earlystop = false, verbose = true,

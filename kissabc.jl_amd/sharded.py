@@ -243,3 +243,83 @@ def sharded_select(X_own, alive_own, lo, N, alpha, min_r_ess, all_gather, cand_c
                               for s in all_gather(lo + np.flatnonzero(new_alive))])
         new_alive = np.ones_like(new_alive)
     return eps, flag, ESS, bool(resample), new_alive, idx
+
+
+def sharded_select_one_exchange(X_own, alive_own, lo, N, alpha, min_r_ess, all_gather, window, X_all,
+                                slot_cap=None, cand_cap=4096):
+    """Host mirror of the ONE-exchange course of csrc/smc_dsel_kernels.hpp (dsel2_*): the rank ships,
+    unasked, its alive keys inside `window` = (lo value, hi value) -- on the device predicted from the
+    last two values of eps -- with their 1024-bin histogram, the count of its alive keys below the
+    window, its smallest alive key above, and count / key range of its alive costs: ONE all_gather,
+    after which every rank decides for itself.
+    `X_all`: the costs of the whole ensemble (every rank holds them: the pass's all-gather delivered
+    them), used for a resample's index only.  Returns sharded_select's tuple, or None where the device
+    stalls (the target rank outside the window, a slot or the bin too full, eps == 0): the selection is
+    then repeated phase by phase (sharded_select)."""
+    import numpy as np
+    X_own = np.asarray(X_own, dtype=np.float64)
+    alive_own = np.asarray(alive_own, dtype=bool)
+    keys = _keys_of(X_own[alive_own])
+    wlo = int(_keys_of(np.array([window[0]]))[0]) if np.isfinite(window[0]) else 0
+    whi = int(_keys_of(np.array([window[1]]))[0]) if np.isfinite(window[1]) else 2**64 - 1
+    if wlo > whi:
+        return None
+    shift = max((whi - wlo).bit_length() - 10, 0)
+    inside = keys[(keys >= np.uint64(wlo)) & (keys <= np.uint64(whi))]
+    above = keys[keys > np.uint64(whi)]
+    hist = np.bincount(((inside - np.uint64(wlo)) >> np.uint64(shift)).astype(np.int64), minlength=1024)
+    H = 6
+    head = np.array([int((keys < np.uint64(wlo)).sum()), inside.size,
+                     int(above.min()) if above.size else 2**64 - 1,
+                     keys.size, int(keys.min()) if keys.size else 2**64 - 1,
+                     int(keys.max()) if keys.size else 0], dtype=np.uint64)
+    parts = all_gather(np.concatenate([head, hist.astype(np.uint64), inside]))      # THE exchange
+    n = sum(int(p[3]) for p in parts)
+    if n == 0:
+        raise ValueError("collection must be non-empty")
+    kmin = min(int(p[4]) for p in parts)
+    mn = _val_of(kmin)
+    aleph = n * alpha + (1.0 - alpha)
+    j = min(max(int(aleph), 1), n - 1) if n > 1 else 1
+    gq = min(max(aleph - j, 0.0), 1.0)
+    below = sum(int(p[0]) for p in parts)
+    if slot_cap is not None and any(int(p[1]) > slot_cap for p in parts):
+        return None
+    cand_all = np.concatenate([p[H + 1024:H + 1024 + int(p[1])] for p in parts])
+    kg_above = min(int(p[2]) for p in parts)
+    kt = j - 1 - below
+    if kt < 0 or kt >= cand_all.size:
+        return None
+    c = sum(np.asarray(p[H:H + 1024], dtype=np.int64) for p in parts)
+    before = np.concatenate([[0], np.cumsum(c)[:-1]])
+    b = int(np.flatnonzero((c > 0) & (kt >= before) & (kt < before + c))[0])
+    if c[b] > cand_cap:
+        return None
+    blo = wlo + (b << shift)
+    bhi = min(blo + (1 << shift) - 1, whi)
+    cand = np.sort(cand_all[(cand_all >= np.uint64(blo)) & (cand_all <= np.uint64(bhi))])
+    kt2 = kt - int(before[b])
+    ka = int(cand[kt2])
+    if kt2 + 1 < cand.size:
+        kb = int(cand[kt2 + 1])
+    else:   # the smallest alive key above the bin: among the window's keys, else above the window
+        up = cand_all[cand_all > np.uint64(bhi)]
+        kb = min(int(up.min()) if up.size else 2**64 - 1, kg_above)
+    a = _val_of(ka)
+    bb = a if n == 1 else _val_of(kb)
+    eps = a + gq * (bb - a) if (np.isfinite(a) and np.isfinite(bb)) else (1.0 - gq) * a + gq * bb
+    if eps == 0.0:
+        return None      # (+0 and -0: two keys, one value)
+    flag = 0 if eps > mn else 1
+    vals = np.array([_val_of(int(kk)) for kk in cand])
+    ESS = below + int(before[b]) + int(((vals <= eps) if flag else (vals < eps)).sum())
+    resample = alpha * ESS <= N * min_r_ess
+    new_alive = (X_own <= eps) if flag else (X_own < eps)
+    idx = None
+    if resample:
+        if ESS == 0:
+            raise ValueError("collection must be non-empty")
+        X_all = np.asarray(X_all, dtype=np.float64)
+        idx = np.flatnonzero((X_all <= eps) if flag else (X_all < eps))   # no exchange
+        new_alive = np.ones_like(new_alive)
+    return eps, flag, ESS, bool(resample), new_alive, idx

@@ -389,6 +389,59 @@ def test_smc_sharded_particles_equals_oracle(k, orc, gpu_ctx, world, name):
         c.close()
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_smc_sharded_particles_one_exchange_course(k, orc, gpu_ctx, world, monkeypatch):
+    """the ONE-exchange selection (csrc/smc_dsel_kernels.hpp dsel2_*): batches of iterations enqueued between
+    two looks, two collectives per iteration in the usual course (the selection's payload + the pass's grouped
+    all-gather), the first two selections and every stalled one phase by phase; KABC_SMC_DIST_LOOKS=1 is the
+    phase-by-phase course throughout.  Same bits either way (and the oracle's)."""
+    from test_gpu_smc_parity import _cases
+    prior, cost, _ = _cases(k)["C4_hier16_small"]
+    kw = dict(nparticles=40000, alpha=0.95, epstol=0.3)
+    ref = orc.smc(prior, cost, seed=5, **kw)
+    res = {}
+    for looks in ("0", "1"):
+        monkeypatch.setenv("KABC_SMC_DIST_LOOKS", looks)
+        comms = k.comm.init_all([0] * world, "p2p")
+        res[looks] = _run_ranks(k, comms, lambda c: k.smc(prior, cost, seed=5, return_array=True, comm=c,
+                                                          shard="particles", **kw))
+        for c in comms:
+            c.close()
+    for looks, out in res.items():
+        for got in out:
+            assert got.info["log"] == ref["log"] and got.eps == ref["eps"], looks
+            assert np.array_equal(got.info["theta_all"], ref["theta_all"]) and np.array_equal(got.C, ref["C"]), looks
+            assert np.array_equal(got.info["alive"], ref["alive"]), looks
+    it = ref["iterations"]
+    d0, d1 = res["0"][0].info["dist"], res["1"][0].info["dist"]
+    assert d0["batched"] and not d1["batched"] and d0["iterations"] == d1["iterations"] == it
+    assert d0["collectives_per_usual_iteration"] == 2 and d1["collectives_per_usual_iteration"] == -1
+    assert d1["one_exchange_selections"] == 0 and d1["host_looks"] > 2 * it and d1["collectives"] >= 4 * it
+    # usual course: most selections decided by the one exchange; what the batches enqueue past the end of
+    # the loop and behind a stalled selection is counted too
+    assert d0["one_exchange_selections"] + d0["phase_by_phase_selections"] == it
+    assert d0["one_exchange_selections"] >= 0.75 * it, d0
+    assert d0["collectives"] <= 2 * it + 6 * d0["phase_by_phase_selections"] + 2 * 8 * (d0["phase_by_phase_selections"] + 1), d0
+    assert d0["host_looks"] <= it // 2 + 8 * d0["phase_by_phase_selections"], d0
+
+
+def test_smc_sharded_cost_loop_batches(k, orc, gpu_ctx, monkeypatch):
+    """the cost-loop mode with the reference's default mcmc_retrys = 0: select, pass, all-gather, pass end
+    enqueued eight iterations at a time (one collective per iteration)"""
+    prior, cost = k.Factored(k.Normal(0, 2), k.Normal(0, 2)), k.costs.GaussDist([0.5, -0.25])
+    kw = dict(nparticles=3000, epstol=0.05, seed=8)
+    ref = orc.smc(prior, cost, **kw)
+    comms = k.comm.init_all([0] * 2, "p2p")
+    out = _run_ranks(k, comms, lambda c: k.smc(prior, cost, return_array=True, comm=c, shard="cost_loop", **kw))
+    for c in comms:
+        c.close()
+    for got in out:
+        assert got.info["log"] == ref["log"] and np.array_equal(got.info["theta_all"], ref["theta_all"])
+        d = got.info["dist"]
+        assert d["batched"] and d["iterations"] == ref["iterations"]
+        assert d["collectives"] <= ref["iterations"] + 1 + 8 and d["host_looks"] <= ref["iterations"] // 8 + 2
+
+
 def test_smc_dist_mode_argument_errors(k, gpu_ctx):
     import ctypes as C
     from kissabc_jl_amd import _cdefs as cd

@@ -39,17 +39,22 @@ def _cases(k):
     }
 
 
-@pytest.fixture(params=["loop", "kernels", "default"])
+@pytest.fixture(params=["loop", "kernels", "kernels-select", "default"])
 def smc_path(request, monkeypatch):
     """The device drivers of the ε-loop: the persistent cooperative kernel
-    (csrc/smc_loop_kernel.hpp, the default from 257 to 65 536 particles), the
-    kernel-per-phase path (KABC_SMC_LOOP=0; larger ensembles) and, with nothing selected
-    ("default"), whatever kabc_smc_run picks itself -- the one-workgroup kernel
-    (csrc/smc_small_kernel.hpp) up to 256 particles."""
+    (csrc/smc_loop_kernel.hpp, the default from 257 to 131 072 particles), the
+    kernel-per-phase path (KABC_SMC_LOOP=0; larger ensembles) -- "kernels": with mcmc_retrys = 0 its
+    selection is the speculative one-exchange course (csrc/smc_dsel_kernels.hpp dsel2_*, the select
+    kernel for the first two iterations and after a stall; KABC_SMC_SPEC_SELECT=1, the default from
+    2^20 particles on), "kernels-select" (KABC_SMC_SPEC_SELECT=0): the select kernel throughout -- and, with nothing selected ("default"), whatever kabc_smc_run picks itself
+    -- the one-workgroup kernel (csrc/smc_small_kernel.hpp) up to 256 particles."""
+    monkeypatch.delenv("KABC_SMC_SPEC_SELECT", raising=False)
     if request.param == "default":
         monkeypatch.delenv("KABC_SMC_LOOP", raising=False)
     else:
         monkeypatch.setenv("KABC_SMC_LOOP", "1" if request.param == "loop" else "0")
+        if request.param != "loop":   # (on its own the course is the default from 2^20 particles on)
+            monkeypatch.setenv("KABC_SMC_SPEC_SELECT", "0" if request.param == "kernels-select" else "1")
     return request.param
 
 
@@ -87,7 +92,7 @@ def test_smc_argument_errors_match_reference(k, gpu_ctx):
 
 
 @pytest.mark.parametrize("path,blocks", [("loop", None), ("kernels", None), ("kernels", "1"),
-                                         ("kernels", "32"), ("kernels-cooperative", "32")])
+                                         ("kernels", "32"), ("kernels-cooperative", "32"), ("spec", None)])
 def test_c4_full_size_bit_exact(k, orc, gpu_ctx, monkeypatch, path, blocks):
     """BASELINE.json configs[3] at full size (32 768 particles, D = 16, hierarchical
     Gaussian simulator, ~190 ε-iterations): θ of every particle, ε and the iteration
@@ -95,6 +100,9 @@ def test_c4_full_size_bit_exact(k, orc, gpu_ctx, monkeypatch, path, blocks):
     kernel-per-phase path with the select kernel on its default 16 workgroups, on one,
     on 32, and on 32 launched cooperatively."""
     monkeypatch.setenv("KABC_SMC_LOOP", "1" if path == "loop" else "0")
+    # ("spec": the speculative one-exchange selection, the default of the kernel-per-phase path; the
+    # "kernels" variants are about the select kernel's grid)
+    monkeypatch.setenv("KABC_SMC_SPEC_SELECT", "1" if path == "spec" else "0")
     # (the select kernel's grid: an ordinary launch that fits the device, or a cooperative one)
     monkeypatch.setenv("KABC_SMC_COOPERATIVE", "1" if path.endswith("cooperative") else "0")
     import os
@@ -121,8 +129,10 @@ def test_select_on_128_workgroups_bit_exact(k, orc, gpu_ctx, monkeypatch):
     """The kernel-per-phase path beyond the loop kernel's range, its select kernel on 128
     workgroups (what 2^21 particles and more get by default; 140 000 particles are 137 tiles, a
     ragged last slice): everything equals the oracle's bit for bit, and the default choice
-    (32 workgroups at this size) gives the same arrays."""
+    (32 workgroups at this size) gives the same arrays; so does the speculative one-exchange
+    selection (the default of this path), whose statistics say how the run was driven."""
     monkeypatch.setenv("KABC_SMC_LOOP", "0")
+    monkeypatch.setenv("KABC_SMC_SPEC_SELECT", "0")
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
@@ -133,13 +143,39 @@ def test_select_on_128_workgroups_bit_exact(k, orc, gpu_ctx, monkeypatch):
     r = k.smc(prior, cost, return_array=True, **kw)
     monkeypatch.delenv("KABC_SMC_SELECT_BLOCKS", raising=False)
     r32 = k.smc(prior, cost, return_array=True, **kw)
+    monkeypatch.setenv("KABC_SMC_SPEC_SELECT", "1")
+    rs = k.smc(prior, cost, return_array=True, **kw)
     ro = orc.smc(prior, cost, **kw)
     assert r.info["iterations"] == ro["iterations"] > 20
-    for rr in (r, r32):
+    d = rs.info["dist"]
+    assert d["batched"] and d["collectives"] == 0 and d["host_looks"] < ro["iterations"] // 2
+    assert d["one_exchange_selections"] + d["phase_by_phase_selections"] == ro["iterations"]
+    assert d["one_exchange_selections"] >= 0.8 * ro["iterations"], d
+    assert not r32.info["dist"]["batched"]
+    for rr in (r, r32, rs):
         assert rr.eps == ro["eps"] and np.array_equal(rr.info["theta_all"], ro["theta_all"])
         assert [it["eps"] for it in rr.info["log"]] == [it["eps"] for it in ro["log"]]
         assert [it["ess"] for it in rr.info["log"]] == [it["ess"] for it in ro["log"]]
         assert np.array_equal(rr.info["alive"], ro["alive"]) and np.array_equal(rr.C, ro["C"])
+
+
+def test_one_exchange_selection_is_the_default_from_2_to_the_20(k, gpu_ctx, monkeypatch):
+    """kabc_smc_run beyond 2^20 particles: batches of iterations with the speculative one-exchange selection
+    (csrc/smc_dsel_kernels.hpp dsel2_*) -- the same arrays as the select kernel in every iteration, which the
+    tests above hold against the oracle at sizes the oracle finishes in seconds."""
+    monkeypatch.delenv("KABC_SMC_LOOP", raising=False)
+    N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
+    cost = k.costs.GaussDist([1.0, -0.5])
+    kw = dict(nparticles=(1 << 20) + 777, alpha=0.9, epstol=0.3, seed=6, return_array=True)
+    monkeypatch.delenv("KABC_SMC_SPEC_SELECT", raising=False)
+    a = k.smc(N2, cost, **kw)
+    monkeypatch.setenv("KABC_SMC_SPEC_SELECT", "0")
+    b = k.smc(N2, cost, **kw)
+    assert a.info["dist"]["batched"] and not b.info["dist"]["batched"]
+    assert a.info["dist"]["one_exchange_selections"] >= a.info["iterations"] - 6 > 5
+    assert a.eps == b.eps and a.info["log"] == b.info["log"]
+    assert np.array_equal(a.info["theta_all"], b.info["theta_all"]) and np.array_equal(a.C, b.C)
+    assert np.array_equal(a.info["alive"], b.info["alive"])
 
 
 def test_loop_kernel_many_sizes(k, orc, gpu_ctx, monkeypatch):
@@ -281,8 +317,9 @@ def test_select_launch_that_times_out_is_repeated_cooperatively(k, orc, gpu_ctx,
     within 0.2 s (several large runs, another tenant holding the CUs) the kernel gives up and the SAME
     run -- every draw is counter-based -- is repeated with cooperative launches, whose co-residency
     the runtime asserts.  Forced here two ways: the test hook, and a barrier time-out of 10 ns that
-    a real 32-workgroup grid cannot meet."""
+    a real 32-workgroup grid cannot meet.  (KABC_SMC_SPEC_SELECT=0: the select kernel in every iteration.)"""
     monkeypatch.setenv("KABC_SMC_LOOP", "0")
+    monkeypatch.setenv("KABC_SMC_SPEC_SELECT", "0")
     N2 = k.Factored(k.Normal(0, 5), k.Normal(0, 5))
     cost = k.costs.GaussDist([1.0, -0.5])
     kw = dict(nparticles=140000, alpha=0.9, epstol=0.2, seed=3)

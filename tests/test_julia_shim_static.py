@@ -120,6 +120,8 @@ def jl_type(t):
         return JL_SCALARS[t]
     if t in JL_OF_STRUCT.values():
         return ("struct", {v: k for k, v in JL_OF_STRUCT.items()}[t])
+    if t == "Cvoid":                      # (a return type only: `void f(...)`)
+        return ("struct", "void")
     return ("?", t)
 
 

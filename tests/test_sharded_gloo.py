@@ -191,6 +191,30 @@ def _select_worker(rank, world, port, out_path):
                                                                 all_gather)
         full = np.concatenate(all_gather(new_own.astype(np.uint8))).astype(bool)
         res[name] = (eps, flag, ess, resample, full, idx)
+    # the ONE-exchange course (dsel2_*): a window around the answer decides alone; a window off it stalls
+    from kissabc_jl_amd.sharded import sharded_select_one_exchange
+    for name, (X, alive, alpha, mre) in _select_cases().items():
+        N = X.size
+        blocks = (N + 63) // 64
+        per = (blocks + world - 1) // world
+        lo, hi = min(rank * per * 64, N), min((rank + 1) * per * 64, N)
+        eps = res[name][0]
+        # the masks of this case's selection are the previous iteration's: dead particles cost more than
+        # every alive one in a run (they did not pass the last eps) -- the course relies on it
+        Xr = X.copy()
+        if np.isfinite(X[alive]).any():
+            Xr[~alive] = np.nanmax(X[alive][np.isfinite(X[alive])]) + 1.0
+        else:
+            Xr[~alive] = np.inf
+        spread = max(abs(eps) * 0.05, 0.05)
+        for tag, window in (("hit", (eps - spread, eps + spread)), ("miss", (eps + spread, eps + 2 * spread)),
+                            ("all", (-np.inf, np.inf))):
+            r1 = sharded_select_one_exchange(Xr[lo:hi], alive[lo:hi], lo, N, alpha, mre, all_gather, window, Xr)
+            if r1 is None:
+                res[f"{name}@{tag}"] = (np.nan, -1, -1, False, np.zeros(1, bool), None)
+            else:
+                full = np.concatenate(all_gather(r1[4].astype(np.uint8))).astype(bool)
+                res[f"{name}@{tag}"] = (r1[0], r1[1], r1[2], r1[3], full, r1[5])
     if rank == world - 1:   # (any rank: they all hold the same)
         np.savez(out_path, **{f"{n}_{i}": (np.array(-1) if v is None else np.asarray(v))
                               for n, r in res.items() for i, v in enumerate(r)})
@@ -211,3 +235,22 @@ def test_sharded_selection_equals_the_selection_on_the_whole_ensemble(tmp_path, 
         assert np.array_equal(got[f"{name}_4"], new), name
         if resample:
             assert np.array_equal(got[f"{name}_5"], idx), name
+        # one exchange: decided alone whenever it decides (a window around eps; the whole key range while
+        # the target's bin fits the LDS list), stalled (NaN) with a window off the answer or eps == 0
+        Xr = X.copy()
+        Xr[~alive] = (np.nanmax(X[alive][np.isfinite(X[alive])]) + 1.0) if np.isfinite(X[alive]).any() else np.inf
+        want = _select_direct(Xr, alive, alpha, mre)
+        decided = 0
+        for tag in ("hit", "miss", "all"):
+            e1 = float(got[f"{name}@{tag}_0"])
+            if np.isnan(e1):
+                assert tag != "hit" or want[0] == 0.0 or not np.isfinite(want[0]) or name in ("ties", "all_equal"), (name, tag)
+                continue
+            decided += 1
+            assert tag != "miss", name
+            assert e1 == want[0] and int(got[f"{name}@{tag}_1"]) == want[1], (name, tag)
+            assert int(got[f"{name}@{tag}_2"]) == want[2] and bool(got[f"{name}@{tag}_3"]) == want[3], (name, tag)
+            assert np.array_equal(got[f"{name}@{tag}_4"], want[4]), (name, tag)
+            if want[3]:
+                assert np.array_equal(got[f"{name}@{tag}_5"], want[5]), (name, tag)
+        assert decided >= 1 or name in ("ties", "all_equal") or want[0] == 0.0 or not np.isfinite(want[0]), name

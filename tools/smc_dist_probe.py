@@ -1,8 +1,8 @@
 """kabc_smc_run_dist_mode on a one-process-per-GPU RCCL communicator of world size 1 (all this pool offers):
 wall per eps-iteration of C4's model for kabc_smc_run, the cost-loop mode and the particle-sharded mode.
-At world 1 a mode's cost is its host-driven structure (a look at the control block per pass; four to five
-small all-gathers and as many looks at the selection state per iteration) -- the floor a multi-GPU run
-starts from, not a scaling figure."""
+At world 1 a mode's cost is its structure (launches, collectives, looks at the control block) -- the floor a
+multi-GPU run starts from, not a scaling figure.  KABC_SMC_DIST_LOOKS=1: the round-5 course (a look per pass and
+per selection phase, four to five small all-gathers per iteration)."""
 import json
 import os
 import sys
@@ -32,5 +32,10 @@ for N in [int(a) for a in sys.argv[1:]] or [131072, 2097152]:
             walls.append(time.perf_counter() - t0)
         row[mode or "kabc_smc_run"] = {"us_per_iteration": round(sorted(walls)[1] * 1e6 / r.info["iterations"], 1),
                                        "iterations": r.info["iterations"], "eps": r.eps}
+        if mode is not None:
+            d = r.info["dist"]
+            row[mode].update(collectives_per_iteration=d["collectives_per_iteration"], host_looks=d["host_looks"],
+                             one_exchange_selections=d["one_exchange_selections"],
+                             phase_by_phase_selections=d["phase_by_phase_selections"], batched=d["batched"])
     print(json.dumps(row), flush=True)
 comm.close()
