@@ -994,9 +994,16 @@ static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int 
             break;
         }
         case kPfSmcDyn: {
+            // variants: 0 the thread-per-particle pass, 1 init, 2 / 3 / 4 the pass with teams of 8 / 16 / 64 lanes
+            // per particle, 5 the statistics kernel behind a team pass
             const std::vector<std::string> n = {"kabc::smc_dyn_mcmc_kernel<" + udyn + ">",
-                                                "kabc::smc_dyn_init_kernel<" + udyn + ">"};
-            k.mod = rtc_kernel(R, head, "smc_dyn_kernels.hpp", false, n, n[variant ? 1 : 0]);
+                                                "kabc::smc_dyn_init_kernel<" + udyn + ">",
+                                                "kabc::smc_dyn_team_kernel<" + udyn + ", 8>",
+                                                "kabc::smc_dyn_team_kernel<" + udyn + ", 16>",
+                                                "kabc::smc_dyn_team_kernel<" + udyn + ", 64>",
+                                                "kabc::smc_dyn_part_kernel"};
+            if (variant < 0 || variant > 5) return k;
+            k.mod = rtc_kernel(R, head, "smc_dyn_kernels.hpp", false, n, n[(size_t)variant]);
             break;
         }
         case kPfPriorLogpdf:

@@ -435,13 +435,15 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
     if (dyn) {
         if (unit) {
             const PluginKernel km = unit_kernel(unit, kPfSmcDyn, D, 0), ki = unit_kernel(unit, kPfSmcDyn, D, 1);
-            dyn_fn = SmcDynLaunch(km.mod, ki.mod);
+            dyn_fn = SmcDynLaunch(km.mod, ki.mod, unit_kernel(unit, kPfSmcDyn, D, 2).mod, unit_kernel(unit, kPfSmcDyn, D, 3).mod,
+                                  unit_kernel(unit, kPfSmcDyn, D, 4).mod, unit_kernel(unit, kPfSmcDyn, D, 5).mod);
             if (!dyn_fn) return KABC_ERR_DEVICE;  // (message set by the compilation / load)
         } else if (cost->id >= KABC_COST_USER) {
             const CostPlugin* pl = find_plugin(cost->id);
             if (pl && pl->rtc) {
                 const PluginKernel km = plugin_kernel(pl, kPfSmcDyn, D, 0), ki = plugin_kernel(pl, kPfSmcDyn, D, 1);
-                dyn_fn = SmcDynLaunch(km.mod, ki.mod);
+                dyn_fn = SmcDynLaunch(km.mod, ki.mod, plugin_kernel(pl, kPfSmcDyn, D, 2).mod, plugin_kernel(pl, kPfSmcDyn, D, 3).mod,
+                                      plugin_kernel(pl, kPfSmcDyn, D, 4).mod, plugin_kernel(pl, kPfSmcDyn, D, 5).mod);
             } else if (pl && pl->smc_dyn) {
                 dyn_fn = SmcDynLaunch((SmcDynLaunchFn)pl->smc_dyn());
             }

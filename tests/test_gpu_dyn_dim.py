@@ -102,10 +102,16 @@ KABC_HD double kabc_user_cost(const double* x, int D, const double* params,
     assert np.array_equal(pri.rand(32, seed=3), orc.push_p(pri, orc.factored_rand(pri, 32, seed=3)))
 
 
+@pytest.mark.parametrize("team", [None, "0", "4", "8", "16"])
 @pytest.mark.parametrize("name", ["gauss_d20", "hier_d40_mixed", "shell_d17_retrys"])
-def test_smc_dynamic_dimension_bit_exact(k, orc, gpu_ctx, name):
+def test_smc_dynamic_dimension_bit_exact(k, orc, gpu_ctx, name, team, monkeypatch):
     """smc() beyond 16 parameters: run-time-dimension init / propose+accept kernels on the
-    kernel-per-phase path (csrc/smc_dyn_kernels.hpp), bit-exact vs the oracle."""
+    kernel-per-phase path (csrc/smc_dyn_kernels.hpp), bit-exact vs the oracle -- with the team of lanes
+    per particle the host picks (64 at these sizes), with teams of 4 / 8 / 16, and thread per particle."""
+    if team is None:
+        monkeypatch.delenv("KABC_SMC_DYN_TEAM", raising=False)
+    else:
+        monkeypatch.setenv("KABC_SMC_DYN_TEAM", team)
     rng = np.random.default_rng(8)
     cases = {
         "gauss_d20": (k.Factored(*[k.Normal(0, 2)] * 20), k.costs.GaussDist(rng.normal(size=20)),
