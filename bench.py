@@ -349,6 +349,27 @@ def latency_floor_inputs():
     return out
 
 
+def smc_sharded_world1():
+    """kabc_smc_run_dist_mode on an RCCL communicator of world size 1 (all a one-GPU box offers), in a child
+    process with its own rendezvous (tools/smc_dist_probe.py): wall per iteration of C4's model at 131 072
+    particles for kabc_smc_run, the sharded cost loop and the sharded particles, with the collectives and host
+    looks each made (kabc_smc_dist_stats).  The floor a multi-GPU run starts from, not a scaling figure."""
+    import socket
+    import subprocess
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+                   LOCAL_RANK="0", KABC_NO_TORCH_PRELOAD="1")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "smc_dist_probe.py"), "131072"], env=env,
+                           capture_output=True, text=True, timeout=240)
+        line = [ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def spawn_ranks(n, argv, stub=None, timeout=3600.0):
     """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per
     GPU, BEFORE this process has made any GPU call (the children are fresh interpreters; nothing
@@ -566,8 +587,11 @@ def main():
         cpu = cpu_baseline(k0, args.cpu_seconds, with_smc=not args.no_smc)
 
     floor_in = None
+    sharded1 = None
     if world == 1 and not emulate and not args.no_smc:
         floor_in = latency_floor_inputs()
+        if not args.no_alt:
+            sharded1 = smc_sharded_world1()
 
     # ... and so does the cold-cache leg of the default specialisation path (its own process: the
     # code-object cache must be empty and no unit loaded)
@@ -1090,6 +1114,8 @@ def main():
         out.update(extra)
         if smc is not None:
             out["smc_c4"] = smc
+            if sharded1 is not None:
+                out["smc_sharded_world1"] = sharded1
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -379,11 +379,13 @@ inline int ais_dyn_team(int64_t rows, int D) {
     // 32: 309, 64: 469 -- a wavefront's per-sub-step work is mostly the same whatever T (its Philox blocks, the
     // Box-Muller passes, the sequential sum / cost / accept on the lead lanes), so narrow teams -- more
     // walkers per wavefront -- win until the launch has fewer wavefronts than SIMDs (1024) to run on.
+    // ... and until a wavefront's rows fit 60 KB of LDS (5 rows of D per walker: 16 walkers of 200 parameters
+    // do not)
     int T = 4;
-    while (T < kWave && rows * T / kWave < 1024) T *= 2;
+    while (T < kWave && (rows * T / kWave < 1024 || ais_dyn_lds_bytes(D, T) > ((size_t)60 << 10))) T *= 2;
     if (const char* e = std::getenv("KABC_DYN_TEAM")) {
         const int v = std::atoi(e);
-        if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) T = v;
+        if ((v == 4 || v == 8 || v == 16 || v == 32 || v == 64) && ais_dyn_lds_bytes(D, v) <= ((size_t)60 << 10)) T = v;
     }
     return T;
 }

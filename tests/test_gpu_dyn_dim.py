@@ -72,6 +72,32 @@ def test_dynamic_dimension_limits_and_sharding(k, orc, gpu_ctx):
     grp.close()
 
 
+def test_many_walkers_of_many_parameters(k, orc, gpu_ctx, monkeypatch):
+    """the team kernels' rows live in dynamic LDS: a launch with enough walkers for teams of 4 lanes and 200
+    parameters per walker would ask for 143 KB per wavefront -- the host widens the team until the rows fit
+    (csrc/ais_dyn_kernels.hpp ais_dyn_team, csrc/smc_dyn_kernels.hpp smc_dyn_team)"""
+    monkeypatch.delenv("KABC_DYN_TEAM", raising=False)
+    monkeypatch.delenv("KABC_SMC_DYN_TEAM", raising=False)
+    D, N = 200, 36000
+    pri = k.Factored(*[k.Normal(0.1, 1.5)] * D)
+    cost = k.costs.GaussDist(np.linspace(-0.5, 0.5, D))
+    model = k.ApproxKernelizedPosterior(pri, cost, 3.0)
+    e = k.AisEnsemble(model, N, seed=2).init()
+    o = orc.OracleAIS(model, N, seed=2).init()
+    e.advance(1, 2)
+    o.generations_sync(1, 2, collect=False)
+    x, lp, ll = e.state()[:3]
+    xo, lpo, llo = o.state()[:3]
+    assert np.array_equal(x, xo) and np.array_equal(lp, lpo) and np.array_equal(ll, llo)
+    assert e.stats() == o.stats()
+    e.close()
+    kw = dict(nparticles=33000, alpha=0.5, epstol=13.0, seed=3)
+    got = k.smc(pri, cost, return_array=True, **kw)
+    ref = orc.smc(pri, cost, **kw)
+    assert got.info["log"] == ref["log"] and len(ref["log"]) >= 2
+    assert np.array_equal(got.info["theta_all"], ref["theta_all"]) and np.array_equal(got.C, ref["C"])
+
+
 @pytest.mark.parametrize("form", ["hiprtc", "hipcc"])
 def test_dynamic_dimension_user_cost_and_utilities(k, orc, gpu_ctx, monkeypatch, form):
     """A run-time compiled user cost at D = 20 -- compiled in process (hipRTC: the run-time-dimension
