@@ -44,7 +44,14 @@ __device__ __forceinline__ double dyn_cost(int cost_id, const double* x, int D, 
 #ifdef KABC_USER_COST_DEFINED
     if constexpr (COST == KABC_COST_USER) return kabc_user_cost(x, D, params, data, ndata, rng);
 #endif
-    return kabc_cost_eval(cost_id, x, D, params, data, ndata, rng);
+    // the built-in costs that take any number of parameters, dispatched at compile time: a kernel that carries
+    // every built-in cost allocates the registers of the hungriest one (292 against ~150: one wavefront per
+    // SIMD instead of three)
+    if constexpr (COST == KABC_COST_GAUSS_DIST) return kabc_cost_gauss_dist(x, D, params);
+    else if constexpr (COST == KABC_COST_ROSENBROCK) return kabc_cost_rosenbrock(x, D);
+    else if constexpr (COST == KABC_COST_HIER_GAUSS_SIM) return kabc_cost_hier_gauss_sim(x, D, data, rng);
+    else if constexpr (COST == KABC_COST_NORM_SHELL) return kabc_cost_norm_shell(x, D, params);
+    else return kabc_cost_eval(cost_id, x, D, params, data, ndata, rng);
 }
 
 // loglike(density, push_p(density, y)) with y, xp in memory, by ONE thread (step(init))
@@ -90,8 +97,8 @@ __device__ __forceinline__ void dyn_loglike(const AisDynArgs& A, const double* y
 //     kDynInFlight coordinates per lane and row requested at once, BEFORE the move's normals are
 //     generated, so the rows' L2 round trip hides under the Philox / Box-Muller arithmetic -- and the
 //     proposal, push_p and the component's log-density are per-coordinate work;
-//   * the normal pairs of a DE / walk move are dealt out over the team (pair m -> lane m mod T) and
-//     handed over through the walker's LDS rows;
+//   * the normal pairs of the wavefront's DE / walk moves are ONE list dealt out over all 64 lanes (a
+//     pair per lane and round) and handed over through the walkers' LDS rows;
 //   * the prepared prior is staged in LDS once per launch (a component is 72 bytes: read from global
 //     memory per coordinate and sub-step it was a third of the launch, for a box prior);
 //   * what the contract fixes as SEQUENTIAL stays sequential, on the team's lane 0: the left-to-right
@@ -186,31 +193,53 @@ __global__ void __launch_bounds__(kWave) ais_dyn_half_kernel(const AisDynArgs A)
             };
             fetch(0);
             double corr = 0.0, f0 = 0.0, f1 = 0.0, f2 = 0.0;  // the move's scalars: Z | gamma | z0, z1, z2
+            // -- the normal pairs of the wavefront's DE / walk moves (pair m of a walker = block 3 + m of its
+            //    stream; DE: gamma's and one per coordinate, D + 1 values; walk: three), dealt out over ALL 64
+            //    lanes: with a team of 4 and 17 parameters a DE walker's nine pairs were three rounds of
+            //    Philox + Box-Muller on its own four lanes while the stretch walkers' lanes idled -- and every
+            //    wavefront holds all three moves, so every wavefront paid them.  Now the wavefront's pairs
+            //    (about 0.29 (D + 2) / 2 + 0.29 per walker) are one list, a pair per lane and round.
+            {
+                const unsigned long long de_mask = __ballot(lead && move == 2), wk_mask = __ballot(lead && move == 3);
+                const int np_de = (D + 2) / 2;
+                int pre[kWalkers + 1];
+                pre[0] = 0;
+#pragma unroll
+                for (int q = 0; q < kWalkers; ++q)
+                    pre[q + 1] = pre[q] + (((de_mask >> (q * T)) & 1ull) ? np_de : ((wk_mask >> (q * T)) & 1ull) ? 2 : 0);
+                const int total = pre[kWalkers];
+                // (the lanes here: the wavefront's active teams = its first lanes)
+                const int nlanes = (int)__popcll(__ballot(true));
+                for (int item = lane; item < total; item += nlanes) {
+                    int tt = 0;
+#pragma unroll
+                    for (int q = 1; q < kWalkers; ++q) tt += (item >= pre[q]) ? 1 : 0;
+                    int base = 0;
+#pragma unroll
+                    for (int q = 1; q < kWalkers; ++q) base = (q == tt) ? pre[q] : base;
+                    const int m = item - base;
+                    const uint32_t wt = A.id_base + (uint32_t)(A.row_first + (int64_t)blockIdx.x * kWalkers + tt);
+                    double* const znt = rows0 + (size_t)tt * 5 * Dp + 4 * (size_t)Dp;
+                    const kabc_u128_t Bn = kabc_stream_block(A.seed, wt, t, 3u + (uint32_t)m, KABC_DOM_AIS_MOVE);
+                    double z0, z1;
+                    kabc_normal_pair(kabc_lo64(Bn), kabc_hi64(Bn), &z0, &z1);
+                    znt[2 * m] = z0;
+                    znt[2 * m + 1] = z1;
+                }
+                wave_lds_fence();
+            }
             if (move == 1) {  // stretch_propose  src/transition.jl:51-59
                 const double sq3 = kabc_sqrt(3.0), isq3 = kabc_sqrt(1.0 / 3.0);
                 const double u = kabc_u01(kabc_hi64(B1));
                 const double tz = u * (sq3 - isq3) + isq3;
                 f0 = tz * tz;
                 corr = (double)(D - 1) * kabc_log_pn(f0);
-            } else {
-                // pair m = block 3 + m of the stream (DE: gamma's and one per coordinate, D + 1 values;
-                // walk: three), dealt out over the team
-                const int npairs = move == 2 ? (D + 2) / 2 : 2;
-                for (int m = tl; m < npairs; m += T) {
-                    const kabc_u128_t Bn = kabc_stream_block(A.seed, w, t, 3u + (uint32_t)m, KABC_DOM_AIS_MOVE);
-                    double z0, z1;
-                    kabc_normal_pair(kabc_lo64(Bn), kabc_hi64(Bn), &z0, &z1);
-                    zn[2 * m] = z0;
-                    zn[2 * m + 1] = z1;
-                }
-                wave_lds_fence();
-                if (move == 2) {  // de_propose  src/transition.jl:2-22
-                    f0 = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp_bounded(zn[0] * 0.1);
-                } else {          // ais_walk_propose  src/transition.jl:24-43
-                    f0 = zn[0];
-                    f1 = zn[1];
-                    f2 = zn[2];
-                }
+            } else if (move == 2) {  // de_propose  src/transition.jl:2-22
+                f0 = 2.38 / kabc_sqrt((double)(2 * D)) * kabc_exp_bounded(zn[0] * 0.1);
+            } else {                 // ais_walk_propose  src/transition.jl:24-43
+                f0 = zn[0];
+                f1 = zn[1];
+                f2 = zn[2];
             }
             for (int ch = 0; ch < nchunk; ++ch) {
                 if (ch > 0) fetch(ch);
@@ -373,6 +402,14 @@ using AisDynLaunchFn = void (*)(const AisDynArgs&, hipStream_t, int init);
 inline size_t ais_dyn_lds_bytes(int D, int T) {
     return (size_t)D * sizeof(PriorDev) + (size_t)(kWave / T) * 5 * (size_t)ais_dyn_row(D) * sizeof(double);
 }
+// wavefronts per CU the rows in LDS must leave room for (KABC_DYN_LDS_WAVES: A/B runs)
+inline int dyn_lds_waves() {
+    if (const char* e = std::getenv("KABC_DYN_LDS_WAVES")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 16) return v;
+    }
+    return 8;
+}
 // lanes per walker (KABC_DYN_TEAM: A/B runs)
 inline int ais_dyn_team(int64_t rows, int D) {
     // Measured (D = 40, 8192 rows per launch, 20 transitions, us per launch): T = 4: 211, 8: 143, 16: 208,
@@ -380,9 +417,12 @@ inline int ais_dyn_team(int64_t rows, int D) {
     // Box-Muller passes, the sequential sum / cost / accept on the lead lanes), so narrow teams -- more
     // walkers per wavefront -- win until the launch has fewer wavefronts than SIMDs (1024) to run on.
     // ... and until a wavefront's rows fit 60 KB of LDS (5 rows of D per walker: 16 walkers of 200 parameters
-    // do not)
+    // do not) and a CU's 160 KB hold eight wavefronts' rows (two per SIMD; the kernel's registers allow three):
+    // D = 40, 32 768 rows: T = 4 (30 KB, five wavefronts per CU) 0.44 ms, T = 8 (16 KB) 0.34.
     int T = 4;
-    while (T < kWave && (rows * T / kWave < 1024 || ais_dyn_lds_bytes(D, T) > ((size_t)60 << 10))) T *= 2;
+    while (T < kWave && (rows * T / kWave < 1024 || ais_dyn_lds_bytes(D, T) > ((size_t)60 << 10) ||
+                         ((size_t)160 << 10) / ais_dyn_lds_bytes(D, T) < (size_t)dyn_lds_waves()))
+        T *= 2;
     if (const char* e = std::getenv("KABC_DYN_TEAM")) {
         const int v = std::atoi(e);
         if ((v == 4 || v == 8 || v == 16 || v == 32 || v == 64) && ais_dyn_lds_bytes(D, v) <= ((size_t)60 << 10)) T = v;

@@ -38,7 +38,7 @@ KABC_DECL_COST(9)
 KABC_DECL_COST(10)
 KABC_DECL_COST(11)
 
-AisDynLaunchFn find_ais_dyn_kernel();
+AisDynLaunchFn find_ais_dyn_kernel(int cost_id);
 constexpr int kAisInstSplit = 7;  // = KABC_INST_DHI of the low translation units (csrc/Makefile)
 static AisLaunchFn ais_inst_pick(int D, int pc, AisLaunchFn (*lo)(int, int), AisLaunchFn (*nrm)(int, int),
                                  AisLaunchFn (*hi)(int, int)) {
@@ -441,7 +441,7 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
                 dyn_fn = AisDynLaunch((AisDynLaunchFn)pl->ais_dyn());
             }
         } else {
-            dyn_fn = AisDynLaunch(find_ais_dyn_kernel());
+            dyn_fn = AisDynLaunch(find_ais_dyn_kernel(m->cost.id));
         }
         if (!dyn_fn) {
             if (!get_error()[0])

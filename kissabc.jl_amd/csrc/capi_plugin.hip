@@ -924,7 +924,11 @@ static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int 
         return k;
     const std::string d = std::to_string(big ? 0 : D), u = std::to_string(cost);
     // (the dyn kernels dispatch a built-in cost at run time: their COST argument only says "user cost")
-    const std::string udyn = std::to_string(cost == (int)KABC_COST_USER ? (int)KABC_COST_USER : 0);
+    // (run-time-dimension kernels: the user cost, one of the built-in costs that take any number of parameters
+    // -- compile-time dispatch, ais_dyn.hip -- or 0: dispatched inside the kernel)
+    const bool any_d = cost == (int)KABC_COST_GAUSS_DIST || cost == (int)KABC_COST_ROSENBROCK ||
+                       cost == (int)KABC_COST_HIER_GAUSS_SIM || cost == (int)KABC_COST_NORM_SHELL;
+    const std::string udyn = std::to_string(cost == (int)KABC_COST_USER ? (int)KABC_COST_USER : any_d ? cost : 0);
     const std::string ais_init = "kabc::ais_init_kernel<" + d + ">";
     auto smc_names = [&](int simple) {
         const std::string sb = simple ? "true" : "false";
@@ -1001,7 +1005,7 @@ static PluginKernel rtc_family_kernel(RtcCache* R, const std::string& head, int 
                                                 "kabc::smc_dyn_team_kernel<" + udyn + ", 8>",
                                                 "kabc::smc_dyn_team_kernel<" + udyn + ", 16>",
                                                 "kabc::smc_dyn_team_kernel<" + udyn + ", 64>",
-                                                "kabc::smc_dyn_part_kernel"};
+                                                "kabc::smc_dyn_part_kernel<" + udyn + ">"};
             if (variant < 0 || variant > 5) return k;
             k.mod = rtc_kernel(R, head, "smc_dyn_kernels.hpp", false, n, n[(size_t)variant]);
             break;

@@ -13,6 +13,10 @@
 #include "smc_small_kernel.hpp"
 #include "smc_dyn_kernels.hpp"
 #include "smc_dsel_kernels.hpp"
+
+namespace kabc {
+SmcDynLaunchFn find_smc_dyn_kernel(int cost_id);  // ais_dyn.hip
+}
 #include "abcde_kernels.hpp"
 #include "pfilter_kernels.hpp"
 
@@ -448,7 +452,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                 dyn_fn = SmcDynLaunch((SmcDynLaunchFn)pl->smc_dyn());
             }
         } else {
-            dyn_fn = SmcDynLaunch(&launch_smc_dyn<0>);
+            dyn_fn = SmcDynLaunch(find_smc_dyn_kernel(cost->id));
         }
     }
     if (!mcmc && !dyn_fn) {

@@ -3,8 +3,14 @@
 //
 // Rank r owns the particles [p_lo, p_hi) (whole workgroups of 64 of the propose/accept kernel).  It
 // holds the alive mask of its own range only and makes every pass of the selection over its own
-// costs; what the ranks have to agree on travels in four small all-gathers (every rank then folds the
-// world's contributions itself, in rank order: all ranks compute the same words, nothing is broadcast):
+// costs.  Two courses:
+//   * the ONE-exchange course (dsel2_*, second half of this file; round 6): the usual one -- a predicted
+//     key window shipped unasked, one all-gather, no host look; also taken, without any exchange, by the
+//     sharded cost loop and by single-GPU runs of 2^20 particles and more;
+//   * phase by phase (dsel_*, below; round 5): what a selection falls back to when the window misses,
+//     and the course of runs with retry passes.  What the ranks have to agree on travels in four small
+//     all-gathers (every rank then folds the world's contributions itself, in rank order: all ranks
+//     compute the same words, nothing is broadcast):
 //
 //   begin    n, NaNs, key range of the alive costs: from the producers' per-workgroup partials, which
 //            the pass's own all-gather already delivers (no exchange)

@@ -35,7 +35,14 @@ __device__ __forceinline__ double smc_dyn_cost(int cost_id, const double* x, int
 #ifdef KABC_USER_COST_DEFINED
     if constexpr (COST == KABC_COST_USER) return kabc_user_cost(x, D, params, data, ndata, rng);
 #endif
-    return kabc_cost_eval(cost_id, x, D, params, data, ndata, rng);
+    // the built-in costs that take any number of parameters, dispatched at compile time: a kernel that carries
+    // every built-in cost allocates the registers of the hungriest one (292 against ~150: one wavefront per
+    // SIMD instead of three)
+    if constexpr (COST == KABC_COST_GAUSS_DIST) return kabc_cost_gauss_dist(x, D, params);
+    else if constexpr (COST == KABC_COST_ROSENBROCK) return kabc_cost_rosenbrock(x, D);
+    else if constexpr (COST == KABC_COST_HIER_GAUSS_SIM) return kabc_cost_hier_gauss_sim(x, D, data, rng);
+    else if constexpr (COST == KABC_COST_NORM_SHELL) return kabc_cost_norm_shell(x, D, params);
+    else return kabc_cost_eval(cost_id, x, D, params, data, ndata, rng);
 }
 
 __device__ __forceinline__ double smc_dyn_logpdf_push(const SmcDynArgs& A, const double* x, double* xp) {
@@ -315,6 +322,7 @@ __global__ void __launch_bounds__(kWave) smc_dyn_team_kernel(const SmcDynArgs A)
 
 // count / NaNs / key range of the alive costs of every 64 particles of the pass just made (what the
 // thread-per-particle kernels leave with smc_block_stats at their end)
+template <int COST>  // (a template only so that every unit that instantiates the pass carries its own copy)
 __global__ void __launch_bounds__(kSmcBlock) smc_dyn_part_kernel(const SmcDynArgs A) {
     const int done0 = A.ctrl->done, open0 = A.ctrl->pass_open, cur = A.ctrl->cur;
     if (done0 || !open0) return;
@@ -337,7 +345,16 @@ inline int smc_dyn_team(int64_t N, int D) {
     // (measured, us per pass, tools/smc_dyn_probe.py, T = 4 / 8 / 16: 16 384 x 40: 25.5 / 22.4 / 29.8; 131 072 x 40:
     // 89.7 / 105.8 / 163.8; 16 384 x 128: 49.0 / 62.0 / 56.6 -- thread per particle: 48.9 / 442 / 138)
     int T = (N >= 32768 || D >= 96) ? 4 : 8;
-    while (T < kWave && (N * T / kWave < 1024 || smc_dyn_lds_bytes(D, T) > ((size_t)60 << 10))) T = T == 4 ? 8 : T == 8 ? 16 : 64;
+    auto waves_ok = [&](int t) {  // a CU's 160 KB hold four wavefronts' rows (measured: 16 384 x 128: 48 us against 58 with eight)
+        int want = 4;
+        if (const char* e = std::getenv("KABC_DYN_LDS_WAVES")) {
+            const int v = std::atoi(e);
+            if (v >= 1 && v <= 16) want = v;
+        }
+        return ((size_t)160 << 10) / smc_dyn_lds_bytes(D, t) >= (size_t)want;
+    };
+    while (T < kWave && (N * T / kWave < 1024 || smc_dyn_lds_bytes(D, T) > ((size_t)60 << 10) || !waves_ok(T)))
+        T = T == 4 ? 8 : T == 8 ? 16 : 64;
     if (const char* e = std::getenv("KABC_SMC_DYN_TEAM")) {
         const int v = e[0] ? std::atoi(e) : -1;
         if (v == 0 || ((v == 4 || v == 8 || v == 16 || v == 64) && smc_dyn_lds_bytes(D, v) <= ((size_t)60 << 10))) T = v;
@@ -350,7 +367,7 @@ template <int COST, int T>
 inline void launch_smc_dyn_team(const SmcDynArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((smc_dyn_team_kernel<COST, T>), dim3((unsigned)((a.N + kWave / T - 1) / (kWave / T))), dim3(kWave),
                        smc_dyn_lds_bytes(a.D, T), s, a);
-    hipLaunchKernelGGL(smc_dyn_part_kernel, dim3((unsigned)((a.N + kSmcBlock - 1) / kSmcBlock)), dim3(kSmcBlock), 0, s, a);
+    hipLaunchKernelGGL((smc_dyn_part_kernel<COST>), dim3((unsigned)((a.N + kSmcBlock - 1) / kSmcBlock)), dim3(kSmcBlock), 0, s, a);
 }
 
 template <int COST>
