@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KABC_VERSION 320 /* 0.3.2: kabc_smc_dist_stats, kabc_ais_driver, kabc_set_specialize, kabc_rtc_cache_dir, kabc_compile_mvprior_plugin; 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
+#define KABC_VERSION 321 /* 0.3.3: SmcDynArgs (shared with hipcc-built cost plugins) carries the particle range of a pass: sharded smc beyond KABC_MAX_DIM; 0.3.2: kabc_smc_dist_stats, kabc_ais_driver, kabc_set_specialize, kabc_rtc_cache_dir, kabc_compile_mvprior_plugin; 0.3.1: kernel argument structs shared with hipcc-built cost plugins changed (PfArgs, AbcdeArgs, PfCtrl, kabc_cost_rng_t); kabc_register_cost_plugin refuses a plugin built against another value */
 #define KABC_MAX_DIM 16  /* length(prior) up to which the register-resident kernels are instantiated */
 /* AIS, smc, ABCDE and pfilter accept length(prior) up to KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM
  * run-time-dimension kernels keep the walker / particle rows in memory (several times slower per
@@ -582,7 +582,8 @@ kabc_status_t kabc_smc_run(kabc_ctx_t* ctx, const kabc_prior_t* prior, int32_t D
  * Draws are keyed by particle: the result equals kabc_smc_run's bit for bit.
  * Communicators: kabc_comm_init_rank (one process per GPU, RCCL); the P2P communicators of
  * kabc_comm_init_all when each rank is driven by its own host thread (how the test-suite
- * runs several ranks on one GPU).  length(prior) <= KABC_MAX_DIM. */
+ * runs several ranks on one GPU).  length(prior) <= KABC_MAX_DIM_DYN: beyond KABC_MAX_DIM every rank draws and
+ * costs the whole initial ensemble itself (counter-based draws: the same on every rank), the passes are shared out. */
 kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, int32_t D,
                                 const kabc_cost_t* cost, const kabc_smc_opts_t* opts,
                                 kabc_smc_result_t* result);

@@ -7,7 +7,7 @@ import ctypes as C
 
 KABC_MAX_DIM = 16
 KABC_MAX_DIM_DYN = 256   # AIS only: run-time-dimension kernels beyond KABC_MAX_DIM
-KABC_VERSION = 320   # include/kabc.h
+KABC_VERSION = 321   # include/kabc.h
 KABC_COMM_ID_BYTES = 128
 KABC_MAX_EXCHANGE_CHUNKS = 16
 KABC_COMM_MAX_WORLD = 16

@@ -337,11 +337,6 @@ kabc_status_t kabc_smc_run_dist_mode(kabc_comm_t* comm, const kabc_prior_t* prio
         set_error("kabc_smc_run_dist_mode: mode is KABC_SMC_DIST_COST_LOOP or KABC_SMC_DIST_PARTICLES");
         return KABC_ERR_INVALID_ARG;
     }
-    if (D > KABC_MAX_DIM) {
-        set_error("kabc_smc_run_dist: length(prior) <= %d (the run-time-dimension kernels are single-GPU)",
-                  KABC_MAX_DIM);
-        return KABC_ERR_UNSUPPORTED;
-    }
     tl_smc_dist_mode = mode;
     // The select grid's "ordinary launch, bounded barrier wait, repeat cooperatively" turn is decided by
     // one rank from its own GPU: a rank that took it alone would restart from the initial exchange while
@@ -579,8 +574,17 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         da.prior = d_prior;
         da.raw = d_raw;
         da.part = part;
+        da.p0 = 0;
+        da.p1 = N;
+        // (a sharded run: every rank draws and costs ALL particles at the start -- the draws are counter-based,
+        // the ranks end up with the same ensemble, nothing is exchanged; the passes are shared out)
         dyn_fn(da, s, 1);
         KABC_HIP_CHECK(hipGetLastError());
+        if (comm) {
+            da.p0 = std::min<int64_t>(wg_lo * kSmcBlock, N);
+            da.p1 = std::min<int64_t>((wg_lo + wg_n) * kSmcBlock, N);
+            da.slots = slots + (size_t)rank * kSmcSlots * 8;  // this rank's block of counter lines
+        }
     }
     // :119-125
     if (!dyn) {
@@ -858,6 +862,10 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         ma.aux_ring = aux_ring;
     }
     auto run_pass = [&](hipStream_t st) {  // one propose / accept pass (+ its pre-pass)
+        if (dyn) {
+            dyn_fn(da, st, 0);
+            return;
+        }
         if (!mcmc_final) {  // the kernel-per-phase driver runs: the model's own kernel if it is there
             if (SmcLaunch m2 = find_smc_kernel(cost->id, D, simple, unit)) mcmc = m2;
             mcmc_final = true;
@@ -1236,8 +1244,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                 for (int r = r0; r < r1; ++r) {
                     const bool timed = (it == 0 && r == 0);
                     if (timed) KABC_HIP_CHECK(hipEventRecord(ev0, s));
-                    if (dyn) dyn_fn(da, s, 0);
-                    else run_pass(s);
+                    run_pass(s);
                     if (timed) KABC_HIP_CHECK(hipEventRecord(ev1, s));
                     ended = (r == R - 1);
                     hipLaunchKernelGGL(smc_pass_end_kernel, dim3(1), dim3(kSmcSlots), 0, s, ctrl,

@@ -27,6 +27,7 @@ struct SmcDynArgs {
     const kabc_prior_t* raw;    // [D] raw components (device; init)
     double* scratch;            // [N][2][D]: proposal, push_p(proposal)
     unsigned long long* part;
+    int64_t p0, p1;             // the particles of a pass: [p0, p1), p0 a multiple of 64 (a sharded run: this rank's)
 };
 
 template <int COST>
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_dyn_init_kernel(const SmcDynArg
 
 template <int COST>
 __global__ void __launch_bounds__(kSmcBlock) smc_dyn_mcmc_kernel(const SmcDynArgs A) {
-    const int64_t i = (int64_t)blockIdx.x * kSmcBlock + threadIdx.x;
+    const int64_t i = A.p0 + (int64_t)blockIdx.x * kSmcBlock + threadIdx.x;
     unsigned long long n_eval = 0, n_acc = 0, n_prop = 0;
     if (A.ctrl->done || !A.ctrl->pass_open) return;  // uniform no-op
     const int cur = A.ctrl->cur;
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_dyn_mcmc_kernel(const SmcDynArg
     const double* __restrict__ theta_src = A.theta[cur];
     double Xfin = 0.0;
     bool alive_i = false;
-    if (i < A.N) {
+    if (i < A.p1) {
         // idx = repeat(idxalive, ceil(N/m))[1:N]  (src/smc.jl:146-147), evaluated on the fly
         const bool remap = gather && A.ctrl->resampled != 0;
         const unsigned ess = (unsigned)A.ctrl->ess;
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(kSmcBlock) smc_dyn_mcmc_kernel(const SmcDynArg
         A.lpi[1 - cur][i] = lpi;
         Xfin = Xi;
     }
-    smc_block_stats(A.part, alive_i, Xfin);
+    smc_block_stats(A.part, alive_i, Xfin, A.p0 / kSmcBlock + (int64_t)blockIdx.x);
     const unsigned long long se = wave_sum(n_eval), sa = wave_sum(n_acc), sp = wave_sum(n_prop);
     if ((threadIdx.x & (kWave - 1)) == 0) {
         unsigned long long* sl = A.slots + (size_t)(blockIdx.x & (kSmcSlots - 1)) * 8;
@@ -217,11 +218,11 @@ __global__ void __launch_bounds__(kWave) smc_dyn_team_kernel(const SmcDynArgs A)
         const int nw = D * (int)(sizeof(PriorDev) / sizeof(double));
         for (int i = lane; i < nw; i += kWave) smc_dyn_lds[i] = reinterpret_cast<const double*>(A.prior)[i];
     }
-    const int64_t i = (int64_t)blockIdx.x * kP + team;
+    const int64_t i = A.p0 + (int64_t)blockIdx.x * kP + team;
     const bool lead = tl == 0;
     unsigned long long n_eval = 0, n_acc = 0, n_prop = 0;
     const double* __restrict__ theta_src = A.theta[cur];
-    if (i < A.N) {  // (team-uniform)
+    if (i < A.p1) {  // (team-uniform)
         const bool remap = gather && resampled != 0;
         const int64_t si = remap ? (int64_t)A.cidx[(unsigned)i % ess] : i;
         const double* th = theta_src + si * D;
@@ -326,11 +327,11 @@ template <int COST>  // (a template only so that every unit that instantiates th
 __global__ void __launch_bounds__(kSmcBlock) smc_dyn_part_kernel(const SmcDynArgs A) {
     const int done0 = A.ctrl->done, open0 = A.ctrl->pass_open, cur = A.ctrl->cur;
     if (done0 || !open0) return;
-    const int64_t i = (int64_t)blockIdx.x * kSmcBlock + threadIdx.x;
-    const bool in = i < A.N;
+    const int64_t i = A.p0 + (int64_t)blockIdx.x * kSmcBlock + threadIdx.x;
+    const bool in = i < A.p1;
     const bool alive_i = in && A.alive[i] != 0;
     const double x = in ? A.X[1 - cur][i] : 0.0;
-    smc_block_stats(A.part, alive_i, x);
+    smc_block_stats(A.part, alive_i, x, A.p0 / kSmcBlock + (int64_t)blockIdx.x);
 }
 
 #ifndef __HIPCC_RTC__  // host side
@@ -365,9 +366,11 @@ inline int smc_dyn_team(int64_t N, int D) {
 
 template <int COST, int T>
 inline void launch_smc_dyn_team(const SmcDynArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL((smc_dyn_team_kernel<COST, T>), dim3((unsigned)((a.N + kWave / T - 1) / (kWave / T))), dim3(kWave),
+    const int64_t n = a.p1 - a.p0;
+    if (n <= 0) return;
+    hipLaunchKernelGGL((smc_dyn_team_kernel<COST, T>), dim3((unsigned)((n + kWave / T - 1) / (kWave / T))), dim3(kWave),
                        smc_dyn_lds_bytes(a.D, T), s, a);
-    hipLaunchKernelGGL((smc_dyn_part_kernel<COST>), dim3((unsigned)((a.N + kSmcBlock - 1) / kSmcBlock)), dim3(kSmcBlock), 0, s, a);
+    hipLaunchKernelGGL((smc_dyn_part_kernel<COST>), dim3((unsigned)((n + kSmcBlock - 1) / kSmcBlock)), dim3(kSmcBlock), 0, s, a);
 }
 
 template <int COST>
@@ -377,12 +380,15 @@ inline void launch_smc_dyn(const SmcDynArgs& a, hipStream_t s, int init) {
         hipLaunchKernelGGL((smc_dyn_init_kernel<COST>), dim3(grid), dim3(kSmcBlock), 0, s, a);
         return;
     }
-    switch (smc_dyn_team(a.N, a.D)) {
+    const int64_t n = a.p1 - a.p0;
+    if (n <= 0) return;
+    switch (smc_dyn_team(n, a.D)) {
         case 4: launch_smc_dyn_team<COST, 4>(a, s); break;
         case 8: launch_smc_dyn_team<COST, 8>(a, s); break;
         case 16: launch_smc_dyn_team<COST, 16>(a, s); break;
         case 64: launch_smc_dyn_team<COST, 64>(a, s); break;
-        default: hipLaunchKernelGGL((smc_dyn_mcmc_kernel<COST>), dim3(grid), dim3(kSmcBlock), 0, s, a);
+        default:
+            hipLaunchKernelGGL((smc_dyn_mcmc_kernel<COST>), dim3((unsigned)((n + kSmcBlock - 1) / kSmcBlock)), dim3(kSmcBlock), 0, s, a);
     }
 }
 
@@ -410,13 +416,14 @@ struct SmcDynLaunch {
             fn(a, s, init);
             return;
         }
-        const unsigned grid = (unsigned)((a.N + kSmcBlock - 1) / kSmcBlock);
-        if (grid == 0) return;
-        int T = init ? 0 : smc_dyn_team(a.N, a.D);
+        const int64_t n = init ? a.N : a.p1 - a.p0;  // (init: every particle; a pass: its range)
+        const unsigned grid = (unsigned)((n + kSmcBlock - 1) / kSmcBlock);
+        if (n <= 0) return;
+        int T = init ? 0 : smc_dyn_team(n, a.D);
         if (T == 4) T = smc_dyn_lds_bytes(a.D, 8) <= ((size_t)60 << 10) ? 8 : 0;
         void* team = T == 8 ? mod_team[0] : T == 16 ? mod_team[1] : T == 64 ? mod_team[2] : nullptr;
         if (team && mod_part) {
-            (void)rtc_launch_lds(team, dim3((unsigned)((a.N + kWave / T - 1) / (kWave / T))), dim3(kWave), &a, s,
+            (void)rtc_launch_lds(team, dim3((unsigned)((n + kWave / T - 1) / (kWave / T))), dim3(kWave), &a, s,
                                  (unsigned)smc_dyn_lds_bytes(a.D, T));
             (void)rtc_launch(mod_part, dim3(grid), dim3(kSmcBlock), &a, s);
             return;

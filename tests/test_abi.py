@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(k):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/kabc.h but not exported"
     assert sorted(_cdefs.PROTOTYPES) == names, "ctypes prototypes out of sync with kabc.h"
-    assert lib.kabc_version() == _cdefs.KABC_VERSION == 320
+    assert lib.kabc_version() == _cdefs.KABC_VERSION == 321
 
 
 def test_struct_layouts(k):

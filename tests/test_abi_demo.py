@@ -48,5 +48,5 @@ def test_abi_demo_matches_python_mirror(tmp_path, k, gpu_ctx):
     assert float(got["smc_eps"]) == s.eps and int(got["smc_iterations"]) == s.info["iterations"]
     assert int(got["smc_alive"]) == s.info["n_alive"]
     assert float(got["smc_sum0"]) == float(np.cumsum(s.info["theta_all"][:, 0])[-1])
-    assert int(got["version"]) == 320 and int(got["sharded_equal"]) == 1
+    assert int(got["version"]) == 321 and int(got["sharded_equal"]) == 1
     assert int(got["smc_sharded_equal"]) == 1     # kabc_smc_run_dist_mode, particles sharded over two ranks

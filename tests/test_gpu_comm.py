@@ -425,6 +425,30 @@ def test_smc_sharded_particles_one_exchange_course(k, orc, gpu_ctx, world, monke
     assert d0["host_looks"] <= it // 2 + 8 * d0["phase_by_phase_selections"], d0
 
 
+@pytest.mark.parametrize("shard,world", [("cost_loop", 3), ("particles", 3), ("particles", 2)])
+def test_smc_sharded_beyond_16_parameters(k, orc, gpu_ctx, shard, world):
+    """sharded smc on the run-time-dimension kernels (csrc/smc_dyn_kernels.hpp): every rank draws and costs the
+    initial ensemble itself (counter-based draws), the team pass runs over the rank's particle range, the
+    selection is the D-independent one -- the oracle's result on every rank, both modes, uneven shards"""
+    rng = np.random.default_rng(8)
+    D = 20
+    pri = k.Factored(*[k.Normal(0, 2)] * (D - 1), k.DiscreteUniform(-3, 3))
+    cost = k.costs.GaussDist(rng.normal(size=D))
+    kw = dict(nparticles=2900, alpha=0.9, epstol=3.2, seed=4)
+    ref = orc.smc(pri, cost, **kw)
+    comms = k.comm.init_all([0] * world, "p2p")
+    out = _run_ranks(k, comms, lambda c: k.smc(pri, cost, return_array=True, comm=c, shard=shard, **kw))
+    for c in comms:
+        c.close()
+    assert ref["iterations"] > 5
+    for got in out:
+        assert got.info["log"] == ref["log"] and got.eps == ref["eps"]
+        assert np.array_equal(got.info["theta_all"], ref["theta_all"]) and np.array_equal(got.C, ref["C"])
+        assert np.array_equal(got.info["alive"], ref["alive"])
+        assert got.info["cost_evals"] == ref["cost_evals"] and got.info["proposals"] == ref["proposals"]
+        assert got.info["dist"]["batched"]
+
+
 def test_smc_sharded_cost_loop_batches(k, orc, gpu_ctx, monkeypatch):
     """the cost-loop mode with the reference's default mcmc_retrys = 0: select, pass, all-gather, pass end
     enqueued eight iterations at a time (one collective per iteration)"""
