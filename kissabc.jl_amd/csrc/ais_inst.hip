@@ -61,14 +61,13 @@ static AisLaunchFn table(int D, int pcx, std::integer_sequence<int, PCXs...>) {
 }
 
 // the one-workgroup kernel of small ensembles (ais_small_kernel.hpp): the classes BOX, NORMAL and
-// GENERAL (a SIMPLE prior runs on GENERAL: same bits; the model's own kernel replaces it anyway),
-// not for a cost with a grid-wide pre-pass (ais_aux_kernels.hpp)
+// GENERAL (a SIMPLE prior runs on GENERAL: same bits; the model's own kernel replaces it anyway)
 template <int COST, int D, int PCX>
 static AisSmallLaunchFn pick_small() {
     constexpr int pc = PCX % kPriorClasses;
     constexpr bool is_normal = pc == kPriorNormal;
     constexpr bool pc_ok = KABC_INST_PCSEL == 0 || (KABC_INST_PCSEL == 1) == is_normal;
-    if constexpr (pc_ok && pc != kPriorSimple && COST != KABC_COST_NORMAL_MEANSTD_SIM && D >= KABC_INST_DLO &&
+    if constexpr (pc_ok && pc != kPriorSimple && D >= KABC_INST_DLO &&
                   D <= KABC_INST_DHI && cost_dim_ok_c(COST, D))
         return &launch_ais_small<D, COST, pc, PCX / kPriorClasses + 1>;
     else return nullptr;

@@ -63,6 +63,10 @@ struct AisSmallArgs {
     double eps, reps, box_lp;
     const PriorDev* prior;   // [D]
     const uint64_t* seeds;   // [nchains] (batch handles), else NULL
+    // a prepared cost with a grid-wide pre-pass (ais_aux_kernels.hpp): its words for EVERY sub-step of the
+    // launch, per half [chain][ngen * nt][W][rows[h]]; NULL = the producers compute them
+    const double* aux[2];
+    int64_t stride_aux[2];   // doubles per chain
 };
 
 // one ring slot = the record of ONE (batch, sub-step) unit
@@ -244,13 +248,23 @@ __global__ void __launch_bounds__(kAisSmallBlock) ais_small_kernel(const AisSmal
                 produce_substep<D, NoMid, false, RecBuf<D, 1>, AisSmallProdCtx>(
                     ctx, seed_v, SL.rec, 0, t, w_base, n_active, SL.listB, lane, slogtab, nullptr, NoMid(), SL.counts);
                 if constexpr (kAuxW > 0) {
-                    // (a prepared cost without a grid-wide pre-pass: the same sequential arithmetic
-                    // kabc_cost_eval would do in place -- include/kabc_costs.h)
-                    kabc_cost_rng_t rng = {seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u, 0u, nullptr, slogtab};
-                    double a[kAuxW];
-                    kabc_cost_prepare(COST, A.cost_params, A.cost_data, A.cost_ndata, &rng, a);
+                    if (A.aux[h]) {  // (wave-uniform) the pre-pass has them: lane = walker copies its words
+                        if (lane < n_active) {
+                            const double* ax = A.aux[h] + chain * A.stride_aux[h];
+                            const int64_t sa = (int64_t)g * (int64_t)nt + (int64_t)s;
 #pragma unroll
-                    for (int jw = 0; jw < kAuxW; ++jw) SL.aux[jw][lane] = a[jw];
+                            for (int jw = 0; jw < kAuxW; ++jw)
+                                SL.aux[jw][lane] = ax[(sa * kAuxW + jw) * (int64_t)rows_h + (int64_t)b * kBatch + lane];
+                        }
+                    } else {
+                        // (a prepared cost without a grid-wide pre-pass: the same sequential arithmetic
+                        // kabc_cost_eval would do in place -- include/kabc_costs.h)
+                        kabc_cost_rng_t rng = {seed, t, w_base + (uint32_t)lane, KABC_DOM_AIS_COST, 0u, 0u, nullptr, slogtab};
+                        double a[kAuxW];
+                        kabc_cost_prepare(COST, A.cost_params, A.cost_data, A.cost_ndata, &rng, a);
+#pragma unroll
+                        for (int jw = 0; jw < kAuxW; ++jw) SL.aux[jw][lane] = a[jw];
+                    }
                 }
                 if constexpr (kPre > 0) produce_cost_normals<kPre>(seed_v, t, w_base, lane, SL.pre, slogtab);
                 lds_word_publish(&s_full[c * S + (int)slot], u + 1u, lane);

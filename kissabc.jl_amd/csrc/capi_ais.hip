@@ -485,14 +485,15 @@ static kabc_status_t ais_create_common(kabc_ctx_t* ctx, const kabc_model_t* m, i
     h->d_strace = nullptr;
     h->strace_cap = 0;
     // Small ensembles (both halves fit one workgroup's LDS, ais_small_kernel.hpp): one workgroup per
-    // chain runs every generation of a kabc_ais_advance call in one launch.  Not for sharded handles,
-    // caller-lent halves, the run-time-dimension kernels, nor a cost with a grid-wide pre-pass
-    // (ais_aux_kernels.hpp); KABC_AIS_SMALL=0 keeps the launch per half-generation.
+    // chain runs every generation of a kabc_ais_advance call in one launch (a cost with a grid-wide
+    // pre-pass, ais_aux_kernels.hpp: one pre-pass launch per half for all of the call's sub-steps first).
+    // Not for sharded handles, caller-lent halves, the run-time-dimension kernels; KABC_AIS_SMALL=0 keeps
+    // the launch per half-generation.
     {
         const char* e = std::getenv("KABC_AIS_SMALL");
         const bool off = e && e[0] == '0';
         if (!off && !dyn && !comm && world == 1 && ext0 == nullptr &&
-            (n_total + 1) / 2 <= (int64_t)ais_small_rmax(m->D) && aux_prepass_words(m->cost.id) == 0) {
+            (n_total + 1) / 2 <= (int64_t)ais_small_rmax(m->D)) {
             const int pk_off = kPriorClasses * (m->posterior - 1);
             // prebuilt classes of the small kernel: BOX, NORMAL up to kAisInstSplit parameters (the two
             // the default path never specialises), GENERAL for everything else -- same bits
@@ -1081,8 +1082,31 @@ static kabc_status_t ais_small_run(kabc_ais_t* h, int64_t ngenerations, int32_t 
         const int64_t fit = (int64_t)(target / gen_bytes);
         if (fit < block) block = fit;
     }
+    // a prepared cost's words for every sub-step of a block, from the grid-wide pre-pass: W per (walker,
+    // sub-step), bounded like the half-generation path's buffer (KABC_AUX_KIB)
+    const int auxW = aux_prepass_words(h->cost_id);
+    const size_t aux_gen_bytes = sizeof(double) * (size_t)auxW * (size_t)h->N * (size_t)h->nchains * (size_t)ntransitions;
+    if (auxW) {
+        size_t cap = (size_t)256 << 20;
+        if (const char* e = std::getenv("KABC_AUX_KIB")) {  // tests: force several blocks
+            const long kib = std::atol(e);
+            if (kib > 0) cap = (size_t)kib << 10;
+        }
+        const int64_t fit = (int64_t)(cap / aux_gen_bytes);
+        if (fit < block) block = fit;
+    }
     if (block < 1) block = 1;
     if (block > ngenerations) block = ngenerations;
+    if (auxW && aux_gen_bytes * (size_t)block > h->aux_cap) {
+        if (h->d_aux) {
+            KABC_HIP_CHECK(hipStreamSynchronize(s));
+            KABC_HIP_CHECK(hipFree(h->d_aux));
+            h->d_aux = nullptr;
+            h->aux_cap = 0;
+        }
+        KABC_HIP_CHECK(dev_malloc(&h->d_aux, aux_gen_bytes * (size_t)block));
+        h->aux_cap = aux_gen_bytes * (size_t)block;
+    }
     if (out_samples && gen_bytes * (size_t)block > h->strace_cap) {
         if (h->d_strace) {
             KABC_HIP_CHECK(hipStreamSynchronize(s));
@@ -1127,6 +1151,29 @@ static kabc_status_t ais_small_run(kabc_ais_t* h, int64_t ngenerations, int32_t 
         a.seeds = h->d_seeds;
         const bool t_on = h->timing && (h->ev_used + 2 <= h->ev.size());
         if (t_on && h->open_count == 0) KABC_HIP_CHECK(hipEventRecord(h->ev[h->ev_used], s));
+        if (auxW) {  // (inside the timed region, like the half-generation path's pre-pass)
+            double* base = reinterpret_cast<double*>(h->d_aux);
+            for (int hf = 0; hf < 2; ++hf) {
+                AuxArgs x;
+                std::memset(&x, 0, sizeof x);
+                x.aux = base;
+                x.cost_params = h->d_cost_params;
+                x.cost_data = h->d_cost_data;
+                x.cost_ndata = h->cost_ndata;
+                x.row_first = 0;
+                x.rows = h->rows[hf];
+                x.seed = h->seed;
+                x.t0 = h->t;
+                x.id_base = h->id_base[hf];
+                x.nt = (int32_t)(gc * (int64_t)ntransitions);
+                x.seeds = h->d_seeds;
+                x.stride_aux = (int64_t)x.nt * auxW * h->rows[hf];
+                launch_aux_prepass(h->cost_id, x, s, (unsigned)h->nchains);
+                a.aux[hf] = base;
+                a.stride_aux[hf] = x.stride_aux;
+                base += (size_t)x.stride_aux * (size_t)h->nchains;
+            }
+        }
         h->small(a, s);
         if (t_on && ++h->open_count >= h->timing_stride)
             if (kabc_status_t st = timing_close_pair(h)) return st;

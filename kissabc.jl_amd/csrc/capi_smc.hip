@@ -367,6 +367,8 @@ kabc_status_t kabc_smc_run_dist(kabc_comm_t* comm, const kabc_prior_t* prior, in
 static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc_prior_t* prior,
                                   int32_t D, const kabc_cost_t* cost, const kabc_smc_opts_t* o,
                                   kabc_smc_result_t* res) {
+    std::memset(tl_dist_stats, 0, sizeof tl_dist_stats);  // (kabc_smc_dist_stats: of THIS run, whatever becomes of it)
+    tl_dist_stats[7] = -1;
     if (!ctx || !prior || !cost || !o || !res) {
         set_error("kabc_smc_run: NULL argument");
         return KABC_ERR_INVALID_ARG;

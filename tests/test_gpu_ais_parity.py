@@ -50,8 +50,8 @@ NAMES = ["C3_rosenbrock_d8", "C2_gauss_d2", "threshold_d2", "odd_N_d3", "d1_dira
 
 
 # the cases that fit the one-workgroup driver of small ensembles (csrc/ais_small_kernel.hpp: N <= 512,
-# <= 256 from nine parameters on, no grid-wide pre-pass) run on BOTH drivers
-SMALL = ["d1_dirac_kernelized", "d1_mixture_threshold", "d2_discrete_threshold", "d2_general_negbin_beta",
+# <= 256 from nine parameters on) run on BOTH drivers
+SMALL = ["d1_dirac_kernelized", "d1_mixture_threshold", "d2_readme_sim", "d2_discrete_threshold", "d2_general_negbin_beta",
          "d5_general_mixed", "d16_box", "d2_wiener", "d2_banana_inf"]
 CASES = [(n, "halves") for n in NAMES] + [(n, "small") for n in SMALL]
 
@@ -102,7 +102,9 @@ def test_prepared_cost_prepass_bit_exact(k, orc, gpu_ctx, monkeypatch, N, n_draw
     sharing its draws in the contract's summation order (include/kabc_costs.h) -- the oracle runs
     the same slices one after the other.  README size (AIS(10), 1000 draws), an odd number of
     draws, fewer pairs than lanes; `kib` bounds the pre-pass buffer so that a launch is cut into
-    blocks of sub-steps (debug records and trace still line up)."""
+    blocks of sub-steps (debug records and trace still line up).  (The launch-per-half-generation driver;
+    the one-workgroup driver with this cost: tests/test_gpu_ais_small.py.)"""
+    monkeypatch.setenv("KABC_AIS_SMALL", "0")
     if kib:
         monkeypatch.setenv("KABC_AUX_KIB", str(kib))
     prior = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
@@ -124,8 +126,9 @@ def test_prepared_cost_prepass_bit_exact(k, orc, gpu_ctx, monkeypatch, N, n_draw
     assert ens.stats() == o.stats()
 
 
-def test_prepared_cost_prepass_batched_chains(k, orc, gpu_ctx):
+def test_prepared_cost_prepass_batched_chains(k, orc, gpu_ctx, monkeypatch):
     """chains as a grid dimension: the pre-pass keys every chain's draws by its own seed"""
+    monkeypatch.setenv("KABC_AIS_SMALL", "0")
     prior = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
     model = k.ApproxKernelizedPosterior(prior, k.costs.NormalMeanStdSim(100, 2.0, 0.04), 0.005)
     seeds = [5, 6, 7]

@@ -70,12 +70,44 @@ def test_small_driver_limits(k, gpu_ctx, monkeypatch):
     assert k.AisEnsemble(_u8(k), 513).driver == "halves"
     assert k.AisEnsemble(_h16(k), 256).driver == "small"
     assert k.AisEnsemble(_h16(k), 257).driver == "halves"
-    # a cost with a grid-wide pre-pass keeps the launches (README.md:31-57's simulator)
+    # a cost with a grid-wide pre-pass (README.md:31-57's simulator): one pre-pass launch per half for all of a
+    # call's sub-steps, then the one workgroup
     readme = k.ApproxKernelizedPosterior(k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100)),
                                          k.costs.NormalMeanStdSim(100, 2.0, 0.04), 0.005)
-    assert k.AisEnsemble(readme, 10).driver == "halves"
+    assert k.AisEnsemble(readme, 10).driver == "small"
     monkeypatch.setenv("KABC_AIS_SMALL", "0")
     assert k.AisEnsemble(_u8(k), 100).driver == "halves"
+
+
+@pytest.mark.parametrize("N,nt,n_draws,kib", [(10, 100, 1000, 0), (10, 7, 999, 0), (12, 5, 37, 0), (130, 3, 64, 0),
+                                              (10, 20, 200, 4)])
+def test_prepared_cost_on_the_small_driver(k, orc, gpu_ctx, monkeypatch, N, nt, n_draws, kib):
+    """README.md:31-57's simulator on the one-workgroup driver: the words of every (walker, sub-step) of a call
+    from one pre-pass launch per half (csrc/ais_aux_kernels.hpp), copied into the ring by the producers;
+    `kib` bounds the pre-pass buffer so that the call is cut into blocks of generations.  README size, an odd
+    number of draws, fewer pairs than lanes, more than one batch per half; chains as a grid dimension."""
+    monkeypatch.delenv("KABC_AIS_SMALL", raising=False)
+    if kib:
+        monkeypatch.setenv("KABC_AUX_KIB", str(kib))
+    prior = k.Factored(k.Uniform(1, 3), k.Truncated(k.Normal(0, 0.1), 0, 100))
+    model = k.ApproxKernelizedPosterior(prior, k.costs.NormalMeanStdSim(n_draws, 2.0, 0.04), 0.005)
+    ens = k.AisEnsemble(model, N, seed=3).init()
+    assert ens.driver == "small"
+    o = orc.OracleAIS(model, N, seed=3).init()
+    gens = 6 if kib else 3
+    assert np.array_equal(ens.advance(gens, nt, collect=True), o.generations_sync(gens, nt))
+    assert np.array_equal(ens.advance(2, nt, collect=True), o.generations_sync(2, nt))      # resumed: t goes on
+    xs, lps, lls, _ = ens.state()
+    xo, lpo, llo, _ = o.state()
+    assert np.array_equal(xs, xo) and np.array_equal(lps, lpo) and np.array_equal(lls, llo)
+    assert ens.stats() == o.stats()
+    if N == 12:
+        seeds = [5, 6, 7]
+        b = k.AisEnsemble(model, 12, seeds=seeds).init()
+        assert b.driver == "small"
+        got = b.advance(3, 4, collect=True)                    # [gen][chain][N][D]
+        for c, sd in enumerate(seeds):
+            assert np.array_equal(got[:, c], orc.OracleAIS(model, 12, seed=sd).init().generations_sync(3, 4)), c
 
 
 def test_reference_shaped_calls(k, orc, gpu_ctx):
