@@ -683,7 +683,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         KABC_HIP_CHECK(bufs.alloc(&dz.cand, (size_t)world * kDselCandStride));
         KABC_HIP_CHECK(bufs.alloc(&dz.misc, (size_t)world * 8));
         KABC_HIP_CHECK(bufs.alloc(&dz.seg, (size_t)world * dz.seg_len));
-        KABC_HIP_CHECK(bufs.alloc(&dz.sub_cnt, (size_t)kDselMaxGrid));
+        KABC_HIP_CHECK(bufs.alloc(&dz.sub_cnt, (size_t)kDsel2MaxGrid));
         KABC_HIP_CHECK(hipMemsetAsync(dz.hist, 0, sizeof(unsigned) * world * kSelBins, s));
         KABC_HIP_CHECK(hipMemsetAsync(dz.cand, 0, sizeof(unsigned long long) * world * kDselCandStride, s));
         KABC_HIP_CHECK(hipMemsetAsync(dz.misc, 0, sizeof(unsigned long long) * world * 8, s));
@@ -711,7 +711,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
             dz.world = 1;
             dz.seg_len = N;
             KABC_HIP_CHECK(bufs.alloc(&dz.st, 1));
-            KABC_HIP_CHECK(bufs.alloc(&dz.sub_cnt, (size_t)kDselMaxGrid));
+            KABC_HIP_CHECK(bufs.alloc(&dz.sub_cnt, (size_t)kDsel2MaxGrid));
         }
         KABC_HIP_CHECK(hipMemsetAsync(dz.st, 0, sizeof(DselState), s));
         dz.spec_cap = std::max<int64_t>(kSelCand, (dz.seg_len / 8 + 1) & ~(int64_t)1);
@@ -722,7 +722,11 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         KABC_HIP_CHECK(hipMemsetAsync(dz.bin, 0, sizeof(unsigned long long) * 8, s));
         KABC_HIP_CHECK(hipMemsetAsync(dz.bin + 1, 0xff, sizeof(unsigned long long), s));
         const int64_t g2 = (N + 2 * kSelBlock - 1) / (2 * kSelBlock);  // (2048 particles per workgroup)
-        dsel2G = (unsigned)std::min<int64_t>(std::max<int64_t>(g2, 1), kDselMaxGrid);
+        // (KABC_DSEL2_G: A/B of the passes' grid -- 128 / 256 / 512 workgroups at 2 M particles: 417 / 412 / 433 us per
+        // iteration, at 524 288: 134 / 140 / 138: more workgroups are more atomics on the payload, not more bandwidth)
+        int64_t gmax = kDselMaxGrid;
+        if (const char* eg = std::getenv("KABC_DSEL2_G")) gmax = std::max(1, std::min(atoi(eg), (int)kDsel2MaxGrid));
+        dsel2G = (unsigned)std::min<int64_t>(std::max<int64_t>(g2, 1), gmax);
         return KABC_OK;
     };
     DselState hz;
@@ -1061,7 +1065,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
         if (sel2)
             if (kabc_status_t st = dsel2_setup()) return st;
         constexpr int kDistBatch = 8;
-        unsigned decideG = dsel2G;  // (KABC_DSEL2_DECIDE_G: A/B of the deciding kernel's grid)
+        unsigned decideG = std::min<unsigned>(dsel2G, (unsigned)kDselMaxGrid);  // (KABC_DSEL2_DECIDE_G: A/B of the deciding kernel's grid)
         if (const char* eg = std::getenv("KABC_DSEL2_DECIDE_G")) decideG = (unsigned)std::max(1, std::min(atoi(eg), (int)kDselMaxGrid));
         Dsel2End e2;
         std::memset(&e2, 0, sizeof e2);

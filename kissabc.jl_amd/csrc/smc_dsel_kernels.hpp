@@ -38,6 +38,7 @@ namespace kabc {
 
 constexpr int kDselCandStride = kSelCand + 8;  // per rank: [0] count, [8 ...] keys
 constexpr int kDselMaxGrid = 128;              // workgroups of a pass over one rank's particles
+constexpr int kDsel2MaxGrid = 512;             // ... of the one-exchange course's passes (spec, apply, index)
 constexpr int kDselSpecHead = 8;               // header words of a rank's slot of the one-exchange payload
 constexpr int kDselSpecKeys = kDselSpecHead + kSelBins / 2;  // word offset of the keys
 constexpr int kDselStage = 4096;               // window keys a workgroup stages in LDS
@@ -74,7 +75,7 @@ struct DselArgs {
     unsigned long long* misc;  // [world][8]: [0] smallest key above the range, [1] new alive count
     int32_t* seg;              // [world][seg_len]: compacted indices of each rank's range
     int64_t seg_len;
-    unsigned int* sub_cnt;     // [kDselMaxGrid] new alive count per workgroup slice
+    unsigned int* sub_cnt;     // [kDsel2MaxGrid] new alive count per workgroup slice
     // the one-exchange course: [world][spec_stride] words, per rank kDselSpecHead header words
     // ([0] alive keys below the window, [1] keys inside, [2] smallest alive key above, [3] alive keys,
     // [4] NaNs among them, [5] smallest alive key, [6] ~largest), 1024 bin counts of the keys inside
@@ -1229,11 +1230,12 @@ __global__ void __launch_bounds__(kSelBlock) dsel2_index_kernel(const DselArgs A
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wid = tid >> 6;
     __shared__ long long s_base0;
     const Dsel2Head H = dsel2_head(A);
-    // the slices before this one (<= kDselMaxGrid = 128 counts: two per lane of wave 0)
+    // the slices before this one (<= kDsel2MaxGrid = 512 counts: eight per lane of wave 0)
     unsigned long long mine = 0;
     if (wid == 0) {
-        if ((unsigned)lane < blockIdx.x) mine += A.sub_cnt[lane];
-        if ((unsigned)lane + 64u < blockIdx.x) mine += A.sub_cnt[lane + 64];
+#pragma unroll
+        for (int q = 0; q < kDsel2MaxGrid / kWave; ++q)
+            if ((unsigned)lane + (unsigned)q * kWave < blockIdx.x) mine += A.sub_cnt[lane + q * kWave];
     }
     if (H.done | H.stalled | (H.state != 3) | !H.resample) return;
     const double* __restrict__ X = A.Xbuf[H.cur];
