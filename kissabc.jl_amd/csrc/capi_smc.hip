@@ -1219,7 +1219,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
                                o->mcmc_tol, ended ? 1 : 0, d_log, log_cap, lpz, world);
             KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipStreamSynchronize(s));
-        ++n_looks;
+            ++n_looks;
             if (timed) {
                 float ms = 0.f;
                 if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) {
@@ -1232,7 +1232,7 @@ static kabc_status_t smc_run_impl(kabc_ctx_t* ctx, kabc_comm_t* comm, const kabc
             hipLaunchKernelGGL(smc_iter_end_kernel, dim3(1), dim3(1), 0, s, ctrl, d_log, log_cap, N, lpz);
             KABC_HIP_CHECK(hipMemcpyAsync(&hc, ctrl, sizeof hc, hipMemcpyDeviceToHost, s));
             KABC_HIP_CHECK(hipStreamSynchronize(s));
-        ++n_looks;
+            ++n_looks;
         }
         if (hc.done) break;
     }
