@@ -42,7 +42,7 @@ def _cases(k):
 @pytest.fixture(params=["loop", "kernels", "kernels-select", "default"])
 def smc_path(request, monkeypatch):
     """The device drivers of the ε-loop: the persistent cooperative kernel
-    (csrc/smc_loop_kernel.hpp, the default from 257 to 131 072 particles), the
+    (csrc/smc_loop_kernel.hpp, the default from 257 to 65 536 particles), the
     kernel-per-phase path (KABC_SMC_LOOP=0; larger ensembles) -- "kernels": with mcmc_retrys = 0 its
     selection is the speculative one-exchange course (csrc/smc_dsel_kernels.hpp dsel2_*, the select
     kernel for the first two iterations and after a stall; KABC_SMC_SPEC_SELECT=1, the default from
